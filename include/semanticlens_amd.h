@@ -1,0 +1,176 @@
+/*
+ * semanticlens_amd.h — C ABI of libsemanticlens_hip.so (gfx950 / MI355X).
+ *
+ * The reference (jim-berend/semanticlens v0.2.1) is pure Python and has no FFI;
+ * its drop-in boundary is the Python plugin API (Lens / ComponentVisualizer /
+ * foundation_models).  This header is the native boundary the
+ * build places *behind* that API: every entry point replaces the stock-torch
+ * arithmetic of one reference call site, cited per function as
+ * `semanticlens/<file>:<line>` (paths relative to the reference root).
+ *
+ * Conventions
+ *  - Plain pointers and sizes only.  Pointers named d_* are DEVICE pointers
+ *    (HBM, e.g. torch.Tensor.data_ptr()); h_* are host pointers read during
+ *    the call.  Nothing is retained after a call returns.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All
+ *    work is enqueued asynchronously on it; no entry point synchronises except
+ *    sl_prof_read().
+ *  - Return value: 0 (or a non-negative code where documented) on success,
+ *    negative SL_E_* on failure; sl_last_error() returns a thread-local message.
+ *  - No entry point allocates device memory; scratch is passed in by the caller.
+ *  - Strides are in ELEMENTS.
+ */
+#ifndef SEMANTICLENS_AMD_H
+#define SEMANTICLENS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SL_ABI_VERSION 1
+
+/* error codes */
+#define SL_E_INVALID (-1)   /* bad argument (message says which) */
+#define SL_E_HIP (-2)       /* a HIP runtime call failed */
+#define SL_E_UNSUPPORTED (-3)
+
+/* element types of activation tensors */
+#define SL_F32 0
+#define SL_F16 1
+#define SL_BF16 2
+
+/* aggregation over H*W of a (B,C,H,W) activation — component_visualization/aggregators.py:38-87 */
+#define SL_CONV_MAX 0  /* aggregate_conv_max  (:64-87)  */
+#define SL_CONV_MEAN 1 /* aggregate_conv_mean (:38-61)  */
+
+/* aggregation over tokens of a (B,T,F) activation — aggregators.py:90-244 */
+#define SL_TOK_MEAN 0    /* aggregate_transformer_mean    (:90-114)  */
+#define SL_TOK_ABSMEAN 1 /* aggregate_transformer_absmean (:117-141) */
+#define SL_TOK_MAX 2     /* aggregate_transformer_max     (:144-168) */
+#define SL_TOK_ABSMAX 3  /* aggregate_transformer_absmax  (:171-195) */
+#define SL_TOK_TOKEN 4   /* get_aggregate_transformer_special_token(pos) (:198-244) */
+
+/* tie order of the streaming top-k */
+#define SL_TIES_TOTAL 0 /* value desc (NaN first, -0 == +0), then sample id asc — batch/shard invariant */
+#define SL_TIES_ATEN 1  /* torch.topk's CPU order on cat([state, batch]) — bit-identical to the reference */
+
+#define SL_MAX_SLOTS 16
+
+const char* sl_last_error(void);
+int sl_abi_version(void);
+/* number of HIP devices visible, or SL_E_HIP */
+int sl_device_count(void);
+
+/* ---- K1: spatial reduce of a conv activation -------------------------------------------
+ * Replaces `tensor.clone().flatten(2).amax(-1)` / `.mean(-1)` (aggregators.py:61, :87) and
+ * the bf16 cast `acts.T.to(bfloat16)` (activation_caching.py:133).
+ * d_act: (B,C,S) with element strides (sb,sc,ss); S = H*W flattened (NCHW: sc=S, ss=1;
+ * channels_last: sc=1, ss=C).
+ * d_cand_bf16 (B,C) u16, may be NULL: aggregated value rounded like the reference does
+ *   (to the activation dtype, then to bf16 RNE; NaN -> 0x7FC0).
+ * d_out_f32 (B,C), may be NULL: aggregated value before the bf16 cast (what the Python
+ *   aggregator returns).  At least one output must be non-NULL. */
+int sl_reduce_conv(const void* d_act, int dtype, int64_t B, int64_t C, int64_t S, int64_t sb, int64_t sc,
+                   int64_t ss, int agg, uint16_t* d_cand_bf16, float* d_out_f32, void* stream);
+
+/* ---- K2: token reduce of a transformer activation ---------------------------------------
+ * Replaces aggregators.py:114,141,168,195,242.  d_act: (B,T,F), strides (sb,st,sf).
+ * `pos` is used by SL_TOK_TOKEN only (python-style negative index allowed). */
+int sl_reduce_tokens(const void* d_act, int dtype, int64_t B, int64_t T, int64_t F, int64_t sb, int64_t st,
+                     int64_t sf, int agg, int64_t pos, uint16_t* d_cand_bf16, float* d_out_f32, void* stream);
+
+/* ---- K3: streaming top-k state (ActMax) --------------------------------------------------
+ * State = d_vals (C,k) bf16 bit patterns + d_ids (C,k) int64, sorted best-first per row.
+ * sl_actmax_init: activation_caching.py:101-110 (values -0.0, ids -1). */
+int sl_actmax_init(uint16_t* d_vals, int64_t* d_ids, int64_t C, int64_t k, void* stream);
+
+/* Merge `nslots` candidate batches into the state under SL_TIES_TOTAL
+ * (ActMax.update, activation_caching.py:112-141, for several batches at once).
+ * Slot s holds h_slot_rows[s] samples as a (rows,C) bf16 matrix at
+ * d_cand + s*slot_stride (elements); sample b of slot s has id
+ * h_slot_id_base[s] + b (the per-layer counter of activation_caching.py:410-413). */
+int sl_actmax_merge(uint16_t* d_vals, int64_t* d_ids, int64_t C, int64_t k, const uint16_t* d_cand,
+                    int64_t slot_stride, const int64_t* h_slot_id_base, const int64_t* h_slot_rows, int nslots,
+                    void* stream);
+
+/* One ActMax.update (activation_caching.py:112-141): d_cand (B,C) bf16; sample b has id
+ * d_sample_ids[b] (device int64 array) or, when d_sample_ids is NULL, id_base + b.
+ * ties = SL_TIES_TOTAL or SL_TIES_ATEN.  SL_TIES_ATEN needs d_ws of
+ * sl_actmax_aten_ws_bytes(C,k,B) bytes and k + B <= 16384. */
+int sl_actmax_update(uint16_t* d_vals, int64_t* d_ids, int64_t C, int64_t k, const uint16_t* d_cand,
+                     const int64_t* d_sample_ids, int64_t id_base, int64_t B, int ties, void* d_ws, size_t ws_bytes,
+                     void* stream);
+size_t sl_actmax_aten_ws_bytes(int64_t C, int64_t k, int64_t B);
+
+/* ---- K4: merge R other states (e.g. all-gathered per-rank states) into this one ----------
+ * No reference counterpart (the reference is single-process); semantics = SL_TIES_TOTAL
+ * top-k of the union.  d_other_vals/ids are (R,C,k). */
+int sl_actmax_merge_states(uint16_t* d_vals, int64_t* d_ids, int64_t C, int64_t k, const uint16_t* d_other_vals,
+                           const int64_t* d_other_ids, int64_t R, void* stream);
+
+/* ---- K5: concept_db[layer] = embeds[sample_ids] (activation_based.py:387-390) ------------
+ * d_emb (N,D) f32, d_ids (n_ids) int64; negative ids wrap (id -1 -> row N-1).  An id
+ * outside [-N, N) sets *d_err_flag (int32, may be NULL) to 1 and reads row 0. */
+int sl_gather_rows(const float* d_emb, int64_t N, int64_t D, const int64_t* d_ids, int64_t n_ids, float* d_out,
+                   int32_t* d_err_flag, void* stream);
+
+/* ---- K6: similarity_score (scores.py:84-128) ---------------------------------------------
+ * Returns the branch taken: 0 row-wise cosine (shapes equal; out (xr,)), 1 normalize(x) @
+ * normalize(y) (xc == yr; out (xr,yc)), 2 normalize(x) @ normalize(y)^T (xc == yc; out
+ * (xr,yr)); SL_E_INVALID for incompatible shapes (the reference raises ValueError).
+ * d_ws: scratch of sl_similarity_ws_bytes(...) bytes. */
+int sl_similarity(const float* d_x, int64_t xr, int64_t xc, const float* d_y, int64_t yr, int64_t yc, float* d_out,
+                  void* d_ws, size_t ws_bytes, void* stream);
+size_t sl_similarity_ws_bytes(int64_t xr, int64_t xc, int64_t yr, int64_t yc);
+
+/* ---- K7: clarity_score (scores.py:18-47): V (C,n,D) -> out (C) ---------------------------- */
+int sl_clarity(const float* d_V, int64_t C, int64_t n, int64_t D, float* d_out, void* stream);
+
+/* ---- K8: redundancy_score (scores.py:50-81): V (Bt,C,D) -> out (Bt) ----------------------- */
+int sl_redundancy(const float* d_V, int64_t Bt, int64_t C, int64_t D, float* d_out, void* d_ws, size_t ws_bytes,
+                  void* stream);
+size_t sl_redundancy_ws_bytes(int64_t Bt, int64_t C, int64_t D);
+
+/* ---- K9: polysemanticity_score (scores.py:131-185): V (C,n,D) -> out (C) float64 ----------
+ * Per component: scikit-learn KMeans(n_clusters=2, n_init, random_state) restated on the
+ * component's n x n Gram matrix (k-means++ seeding with the caller-supplied random draws,
+ * Lloyd iterations with sklearn's tolerance / strict-convergence rules, best-of-n_init by
+ * inertia), then 1 - cos(center_1, center_2); rows whose smaller cluster has < 2 samples use
+ * the reference's fallback (scores.py:173-184).
+ * h_first_center (n_init) int32 and h_rand (n_init,2) float64 are the draws
+ * numpy.random.RandomState(random_state) yields for `choice(n, p=uniform)` and
+ * `uniform(size=2)` of each init (data independent; produced by the host wrapper).
+ * replace_empty_clusters: apply that fallback (the reference's default) or not.
+ * d_min_count (C) int32, may be NULL: size of the smaller cluster of the chosen clustering. */
+int sl_poly2means(const float* d_V, int64_t C, int64_t n, int64_t D, const int32_t* h_first_center, int n_init,
+                  const double* h_rand, int replace_empty_clusters, double* d_out, int32_t* d_min_count, void* d_ws,
+                  size_t ws_bytes, void* stream);
+size_t sl_poly2means_ws_bytes(int64_t C, int64_t n, int64_t D);
+
+/* ---- K10: template-difference mean of text embeddings (lens.py:196-199) ------------------
+ * E (Q*T,D) read as "(q t) d", E0 (T,D); out (Q,D) = mean_t(E[q,t] - E0[t]). */
+int sl_template_mean(const float* d_E, const float* d_E0, int64_t Q, int64_t T, int64_t D, float* d_out,
+                     void* stream);
+
+/* ---- measurement --------------------------------------------------------------------------
+ * When enabled, every launch of a profiled kernel family is bracketed by HIP events on its
+ * own stream.  sl_prof_read synchronises those events and returns the totals. */
+#define SL_PROF_REDUCE 0 /* K1/K2 reduce kernels */
+#define SL_PROF_MERGE 1  /* K3/K4 merge kernels */
+#define SL_PROF_GEMM 2   /* K6 cosine GEMM */
+#define SL_PROF_GATHER 3
+#define SL_PROF_SCORES 4
+#define SL_PROF_NFAM 5
+int sl_prof_enable(int on);
+int sl_prof_reset(void);
+/* total_ms: sum of event-bracketed durations; launches: count; bytes: algorithmic bytes
+ * (or flops for SL_PROF_GEMM) summed over those launches */
+int sl_prof_read(int family, double* total_ms, int64_t* launches, double* work);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEMANTICLENS_AMD_H */

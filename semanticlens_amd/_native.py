@@ -1,0 +1,336 @@
+"""ctypes binding of ``libsemanticlens_hip.so`` (C ABI: ``include/semanticlens_amd.h``).
+
+This is the only module that talks to the native library.  There is NO CPU
+fallback: if the library is missing, or a tensor cannot be placed on a HIP
+device, the call raises.  PyTorch is used for device memory and streams only
+(``tensor.data_ptr()`` / ``torch.cuda.current_stream()``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+
+import torch
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "lib" / "libsemanticlens_hip.so"
+
+# enums of include/semanticlens_amd.h
+SL_F32, SL_F16, SL_BF16 = 0, 1, 2
+SL_CONV_MAX, SL_CONV_MEAN = 0, 1
+SL_TOK_MEAN, SL_TOK_ABSMEAN, SL_TOK_MAX, SL_TOK_ABSMAX, SL_TOK_TOKEN = 0, 1, 2, 3, 4
+SL_TIES_TOTAL, SL_TIES_ATEN = 0, 1
+SL_MAX_SLOTS = 16
+SL_PROF_REDUCE, SL_PROF_MERGE, SL_PROF_GEMM, SL_PROF_GATHER, SL_PROF_SCORES = 0, 1, 2, 3, 4
+TIE_MODES = {"total": SL_TIES_TOTAL, "aten": SL_TIES_ATEN}
+
+_DTYPES = {torch.float32: SL_F32, torch.float16: SL_F16, torch.bfloat16: SL_BF16}
+
+_i64 = ctypes.c_int64
+_vp = ctypes.c_void_p
+_int = ctypes.c_int
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/semanticlens_amd.h declares
+SIGNATURES = {
+    "sl_last_error": (ctypes.c_char_p, []),
+    "sl_abi_version": (_int, []),
+    "sl_device_count": (_int, []),
+    "sl_reduce_conv": (_int, [_vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp]),
+    "sl_reduce_tokens": (_int, [_vp, _int, _i64, _i64, _i64, _i64, _i64, _i64, _int, _i64, _vp, _vp, _vp]),
+    "sl_actmax_init": (_int, [_vp, _vp, _i64, _i64, _vp]),
+    "sl_actmax_merge": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _int, _vp]),
+    "sl_actmax_update": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _int, _vp, _sz, _vp]),
+    "sl_actmax_aten_ws_bytes": (_sz, [_i64, _i64, _i64]),
+    "sl_actmax_merge_states": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),
+    "sl_gather_rows": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "sl_similarity": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "sl_similarity_ws_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "sl_clarity": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "sl_redundancy": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "sl_redundancy_ws_bytes": (_sz, [_i64, _i64, _i64]),
+    "sl_template_mean": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "sl_poly2means": (_int, [_vp, _i64, _i64, _i64, _vp, _int, _vp, _int, _vp, _vp, _vp, _sz, _vp]),
+    "sl_poly2means_ws_bytes": (_sz, [_i64, _i64, _i64]),
+    "sl_prof_enable": (_int, [_int]),
+    "sl_prof_reset": (_int, []),
+    "sl_prof_read": (_int, [_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)]),
+}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    """The HIP library is missing or a native call failed."""
+
+
+def lib():
+    """Load (once) and return the native library; raise loudly if it is not built."""
+    global _lib
+    if _lib is None:
+        path = Path(os.environ.get("SEMANTICLENS_AMD_LIB", LIB_PATH))
+        if not path.exists():
+            raise NativeLibraryError(
+                f"{path} not found. semanticlens_amd has no CPU fallback: build the HIP library first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C semanticlens_amd/csrc)."
+            )
+        handle = ctypes.CDLL(str(path))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def _check(rc: int, what: str) -> int:
+    if rc < 0:
+        msg = lib().sl_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(msg or f"{what}: invalid argument")
+        raise NativeLibraryError(f"{what} failed ({rc}): {msg}")
+    return rc
+
+
+def default_device() -> torch.device:
+    """The HIP device native state lives on.  Raises when there is none (no CPU fallback)."""
+    if not torch.cuda.is_available():
+        raise NativeLibraryError(
+            "semanticlens_amd needs a HIP device (MI355X): torch.cuda.is_available() is False and there is "
+            "no CPU fallback for the concept-DB hot path."
+        )
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def to_device(t: torch.Tensor, device: torch.device | None = None) -> torch.Tensor:
+    """Place ``t`` on a HIP device (host->device copies are plumbing, not compute)."""
+    if t.is_cuda:
+        return t
+    return t.to(device or default_device())
+
+
+def _stream(t: torch.Tensor):
+    return _vp(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t: torch.Tensor | None):
+    return _vp(t.data_ptr()) if t is not None and t.numel() > 0 else _vp(None)
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    try:
+        return _DTYPES[t.dtype]
+    except KeyError:
+        raise TypeError(f"activation dtype {t.dtype} is not supported (float32, float16, bfloat16)") from None
+
+
+# ------------------------------------------------------------------------------------------------
+# K1 / K2
+# ------------------------------------------------------------------------------------------------
+def _flatten_spatial(x: torch.Tensor):
+    """(B,C,H,W) -> strides (sb, sc, ss) of the (B,C,H*W) view, making a copy only if H,W cannot merge."""
+    B, C, H, W = x.shape
+    sb, sc, sh, sw = x.stride()
+    if H == 1:
+        return x, sb, sc, sw
+    if sh != W * sw:
+        x = x.contiguous()
+        sb, sc, sh, sw = x.stride()
+    return x, sb, sc, sw
+
+
+def reduce_conv(x: torch.Tensor, agg: int, cand: torch.Tensor | None, out_f32: torch.Tensor | None):
+    """Launch K1 on a 4-D device tensor.  ``cand`` (B,C) bf16 and/or ``out_f32`` (B,C) f32 are filled."""
+    assert x.is_cuda and x.ndim == 4
+    B, C, H, W = x.shape
+    x, sb, sc, ss = _flatten_spatial(x)
+    with torch.cuda.device(x.device):
+        rc = lib().sl_reduce_conv(_ptr(x), _dtype_code(x), B, C, H * W, sb, sc, ss, agg, _ptr(cand), _ptr(out_f32), _stream(x))
+    _check(rc, "sl_reduce_conv")
+
+
+def reduce_tokens(x: torch.Tensor, agg: int, pos: int, cand: torch.Tensor | None, out_f32: torch.Tensor | None):
+    """Launch K2 on a 3-D device tensor (B,T,F)."""
+    assert x.is_cuda and x.ndim == 3
+    B, T, F = x.shape
+    sb, st, sf = x.stride()
+    with torch.cuda.device(x.device):
+        rc = lib().sl_reduce_tokens(
+            _ptr(x), _dtype_code(x), B, T, F, sb, st, sf, agg, pos, _ptr(cand), _ptr(out_f32), _stream(x)
+        )
+    _check(rc, "sl_reduce_tokens")
+
+
+# ------------------------------------------------------------------------------------------------
+# K3 / K4
+# ------------------------------------------------------------------------------------------------
+def actmax_init(vals: torch.Tensor, ids: torch.Tensor):
+    C, k = vals.shape
+    with torch.cuda.device(vals.device):
+        _check(lib().sl_actmax_init(_ptr(vals), _ptr(ids), C, k, _stream(vals)), "sl_actmax_init")
+
+
+def actmax_merge(vals, ids, cand: torch.Tensor, slot_stride: int, id_bases: list[int], rows: list[int]):
+    C, k = vals.shape
+    n = len(rows)
+    hb = (_i64 * max(n, 1))(*id_bases)
+    hr = (_i64 * max(n, 1))(*rows)
+    with torch.cuda.device(vals.device):
+        rc = lib().sl_actmax_merge(_ptr(vals), _ptr(ids), C, k, _ptr(cand), slot_stride, hb, hr, n, _stream(vals))
+    _check(rc, "sl_actmax_merge")
+
+
+def actmax_aten_ws_bytes(C: int, k: int, B: int) -> int:
+    return int(lib().sl_actmax_aten_ws_bytes(C, k, B))
+
+
+def actmax_update(vals, ids, cand: torch.Tensor, sample_ids: torch.Tensor | None, id_base: int, B: int, ties: int,
+                  ws: torch.Tensor | None):
+    C, k = vals.shape
+    with torch.cuda.device(vals.device):
+        rc = lib().sl_actmax_update(
+            _ptr(vals), _ptr(ids), C, k, _ptr(cand), _ptr(sample_ids), id_base, B, ties, _ptr(ws),
+            ws.numel() * ws.element_size() if ws is not None else 0, _stream(vals),
+        )
+    _check(rc, "sl_actmax_update")
+
+
+def actmax_merge_states(vals, ids, other_vals: torch.Tensor, other_ids: torch.Tensor):
+    C, k = vals.shape
+    R = other_vals.shape[0]
+    with torch.cuda.device(vals.device):
+        rc = lib().sl_actmax_merge_states(_ptr(vals), _ptr(ids), C, k, _ptr(other_vals), _ptr(other_ids), R, _stream(vals))
+    _check(rc, "sl_actmax_merge_states")
+
+
+# ------------------------------------------------------------------------------------------------
+# K5
+# ------------------------------------------------------------------------------------------------
+def gather_rows(emb: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    """``emb[ids]`` for emb (N,D) f32 on the device; negative ids wrap; out-of-range raises IndexError."""
+    assert emb.is_cuda and emb.dtype == torch.float32 and emb.ndim == 2
+    emb = emb.contiguous()
+    ids_d = to_device(ids, emb.device).to(torch.int64).contiguous()
+    N, D = emb.shape
+    out = torch.empty(tuple(ids_d.shape) + (D,), dtype=torch.float32, device=emb.device)
+    flag = torch.zeros(1, dtype=torch.int32, device=emb.device)
+    with torch.cuda.device(emb.device):
+        rc = lib().sl_gather_rows(_ptr(emb), N, D, _ptr(ids_d), ids_d.numel(), _ptr(out), _ptr(flag), _stream(emb))
+    _check(rc, "sl_gather_rows")
+    if int(flag.item()) != 0:
+        raise IndexError(f"index out of range in embeds[sample_ids] (dataset size {N})")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# K6 / K7 / K8 / K10
+# ------------------------------------------------------------------------------------------------
+def _f32c(t: torch.Tensor, device=None) -> torch.Tensor:
+    return to_device(t, device).to(torch.float32).contiguous()
+
+
+def similarity(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    xd = _f32c(x)
+    yd = _f32c(y, xd.device)
+    if xd.ndim != 2 or yd.ndim != 2:
+        raise ValueError("similarity_score expects 2-D tensors")
+    xr, xc = xd.shape
+    yr, yc = yd.shape
+    if xd.shape == yd.shape:
+        out = torch.empty((xr,), dtype=torch.float32, device=xd.device)
+    elif xc == yr:
+        out = torch.empty((xr, yc), dtype=torch.float32, device=xd.device)
+    elif xc == yc:
+        out = torch.empty((xr, yr), dtype=torch.float32, device=xd.device)
+    else:
+        raise ValueError("x and y must have the same shape")
+    nbytes = int(lib().sl_similarity_ws_bytes(xr, xc, yr, yc))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=xd.device)
+    with torch.cuda.device(xd.device):
+        rc = lib().sl_similarity(_ptr(xd), xr, xc, _ptr(yd), yr, yc, _ptr(out), _ptr(ws), nbytes, _stream(xd))
+    _check(rc, "sl_similarity")
+    return out
+
+
+def clarity(V: torch.Tensor) -> torch.Tensor:
+    Vd = _f32c(V)
+    lead = Vd.shape[:-2]
+    n, D = Vd.shape[-2:]
+    C = int(torch.tensor(lead).prod().item()) if len(lead) else 1
+    out = torch.empty((C,), dtype=torch.float32, device=Vd.device)
+    with torch.cuda.device(Vd.device):
+        _check(lib().sl_clarity(_ptr(Vd), C, n, D, _ptr(out), _stream(Vd)), "sl_clarity")
+    return out.reshape(lead)
+
+
+def redundancy(V: torch.Tensor) -> torch.Tensor:
+    Vd = _f32c(V)
+    lead = Vd.shape[:-2]
+    C, D = Vd.shape[-2:]
+    Bt = int(torch.tensor(lead).prod().item()) if len(lead) else 1
+    out = torch.empty((Bt,), dtype=torch.float32, device=Vd.device)
+    nbytes = int(lib().sl_redundancy_ws_bytes(Bt, C, D))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=Vd.device)
+    with torch.cuda.device(Vd.device):
+        _check(lib().sl_redundancy(_ptr(Vd), Bt, C, D, _ptr(out), _ptr(ws), nbytes, _stream(Vd)), "sl_redundancy")
+    return out.reshape(lead)
+
+
+def template_mean(E: torch.Tensor, E0: torch.Tensor, Q: int) -> torch.Tensor:
+    Ed = _f32c(E)
+    E0d = _f32c(E0, Ed.device)
+    T, D = E0d.shape
+    if Ed.shape != (Q * T, D):
+        raise ValueError(f"templated embeddings have shape {tuple(Ed.shape)}, expected {(Q * T, D)}")
+    out = torch.empty((Q, D), dtype=torch.float32, device=Ed.device)
+    with torch.cuda.device(Ed.device):
+        _check(lib().sl_template_mean(_ptr(Ed), _ptr(E0d), Q, T, D, _ptr(out), _stream(Ed)), "sl_template_mean")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# measurement
+# ------------------------------------------------------------------------------------------------
+def prof_enable(on: bool = True):
+    _check(lib().sl_prof_enable(1 if on else 0), "sl_prof_enable")
+
+
+def prof_reset():
+    _check(lib().sl_prof_reset(), "sl_prof_reset")
+
+
+def prof_read(family: int):
+    """(total_ms, launches, work) for one kernel family; synchronises the recorded events."""
+    ms, n, w = ctypes.c_double(), _i64(), ctypes.c_double()
+    _check(lib().sl_prof_read(family, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(w)), "sl_prof_read")
+    return ms.value, n.value, w.value
+
+
+# ------------------------------------------------------------------------------------------------
+# K9
+# ------------------------------------------------------------------------------------------------
+def poly2means(V: torch.Tensor, first_center, rand, replace_empty_clusters: bool = True) -> torch.Tensor:
+    """polysemanticity of V (C,n,D): 2-means per component on the device; float64 (C,) result."""
+    import numpy as np
+
+    Vd = _f32c(V)
+    if Vd.ndim != 3:
+        raise ValueError("polysemanticity_score expects a (n_components, n_samples, n_features) tensor")
+    C, n, D = Vd.shape
+    first_center = np.ascontiguousarray(first_center, dtype=np.int32)
+    rand = np.ascontiguousarray(rand, dtype=np.float64)
+    n_init = int(first_center.shape[0])
+    out = torch.empty((C,), dtype=torch.float64, device=Vd.device)
+    mincnt = torch.empty((C,), dtype=torch.int32, device=Vd.device)
+    nbytes = int(lib().sl_poly2means_ws_bytes(C, n, D))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=Vd.device)
+    with torch.cuda.device(Vd.device):
+        rc = lib().sl_poly2means(
+            _ptr(Vd), C, n, D, first_center.ctypes.data_as(_vp), n_init, rand.ctypes.data_as(_vp),
+            1 if replace_empty_clusters else 0, _ptr(out), _ptr(mincnt), _ptr(ws), nbytes, _stream(Vd),
+        )
+    if rc == -3:
+        raise NotImplementedError(lib().sl_last_error().decode())
+    _check(rc, "sl_poly2means")
+    return out

@@ -1,0 +1,235 @@
+"""ActivationComponentVisualizer — collect top-activating samples per component, then embed them.
+
+Mirror of ``semanticlens/component_visualization/activation_based.py`` (reference v0.2.1):
+same constructor, properties, cache layout and ``Lens`` contract.  Differences, all inside the
+hot loops:
+
+* ``_run`` (activation_based.py:341-358): hooks run the fused device path (K1/K2 + K3); the
+  per-layer ``.cpu()`` of the reference's aggregators and the per-batch ``model(...).cpu()``
+  are gone, so the loop never synchronises with the host.  ``sample_range`` restricts the pass
+  to one shard of the dataset (multi-GPU, see ``semanticlens_amd.distributed``).
+* ``_embed_vision_dataset`` (:392-433): embeddings are written into one ``(N, D)`` buffer that
+  stays in HBM (1.28 M x 512 x 4 B = 2.6 GB) instead of ``.cpu()`` per batch + ``torch.cat``.
+* ``embeds[sample_ids]`` (:387-390) is the K5 gather kernel; ``-1`` ids wrap to the last row
+  exactly like torch indexing.
+"""
+from __future__ import annotations
+
+import logging
+import warnings
+from pathlib import Path
+
+import torch
+from torch import nn
+from tqdm import tqdm
+
+from semanticlens_amd import _native as N
+from semanticlens_amd.component_visualization import aggregators
+from semanticlens_amd.component_visualization.activation_caching import ActMaxCache
+from semanticlens_amd.component_visualization.base import AbstractComponentVisualizer
+from semanticlens_amd.utils.helper import get_fallback_name
+
+logger = logging.getLogger(__name__)
+
+
+class MissingNameWarning(UserWarning):
+    """The model or dataset has no ``.name``; a hash-based fallback names the cache directory."""
+
+
+class ActivationComponentVisualizer(AbstractComponentVisualizer):
+    """Activation-maximisation visualizer (reference: activation_based.py:41-561).
+
+    Parameters are those of the reference plus ``tie_mode`` (``"aten"`` / ``"total"``, see
+    ``activation_caching``).
+    """
+
+    AGGREGATION_DEFAULTS = {
+        "mean": aggregators.aggregate_conv_mean,
+        "max": aggregators.aggregate_conv_max,
+    }
+
+    def __init__(
+        self,
+        model: nn.Module,
+        dataset_model,
+        dataset_fm,
+        layer_names: list[str],
+        num_samples: int,
+        device=None,
+        aggregate_fn=None,
+        cache_dir: str | None = None,
+        tie_mode: str | None = None,
+    ):
+        # NB: like the reference, AbstractComponentVisualizer.__init__ is not called.
+        self.model = model
+        self.dataset = dataset_model
+        self.dataset_fm = dataset_fm
+        self._init_cache_dir(cache_dir)
+        self._validate_args()
+
+        self.layer_names = layer_names
+        self._check_layers()
+
+        device = device or next(model.parameters()).device
+        self.model.to(device)
+
+        if aggregate_fn is None:
+            logger.warning(f"No aggregation_fn provided using default: {aggregators.aggregate_conv_mean.__name__}")
+            aggregate_fn = aggregators.aggregate_conv_mean
+
+        self.actmax_cache = ActMaxCache(
+            self.layer_names, n_collect=num_samples, aggregation_fn=aggregate_fn, tie_mode=tie_mode
+        )
+
+        if self.caching:
+            try:
+                self.actmax_cache.load(self.storage_dir)
+                logger.info(f"Results loaded from {self.storage_dir}")
+            except FileNotFoundError:
+                logger.info(f"Results will be stored in {self.storage_dir}")
+
+    # ---- argument / cache-path handling (activation_based.py:187-307) ----------------------------
+    def _validate_args(self):
+        for obj, what in ((self.model, "Model"), (self.dataset, "Dataset")):
+            if hasattr(obj, "name"):
+                continue
+            name = get_fallback_name(obj)
+            if self.caching:
+                warnings.warn(
+                    f"{what} does not have a name attribute, which is required for reliable caching.\n"
+                    f"Using a fallback name: {name}.",
+                    MissingNameWarning,
+                    stacklevel=3,
+                )
+            obj.name = name
+        if len(self.dataset) != len(self.dataset_fm):
+            raise ValueError(
+                "Model and foundation model datasets should have the same length.",
+                (len(self.dataset), len(self.dataset_fm)),
+            )
+
+    def _check_layers(self):
+        modules = dict(self.model.named_modules())
+        for layer in self.layer_names:
+            if layer not in modules:
+                raise ValueError(f"Layer '{layer}' not found in model.")
+
+    def _init_cache_dir(self, cache_dir):
+        if cache_dir is None:
+            logger.warning("No cache dir provided. Results will not be cached!")
+            self._cache_root = None
+        else:
+            self._cache_root = Path(cache_dir)
+            self._cache_root.mkdir(parents=True, exist_ok=True)
+
+    @property
+    def device(self):
+        return next(self.model.parameters()).device
+
+    def to(self, device):
+        return self.model.to(device)  # returns the model, like the reference (:258-272)
+
+    @property
+    def caching(self) -> bool:
+        return self._cache_root is not None
+
+    @property
+    def storage_dir(self):
+        assert self._cache_root, "No cache dir provided"
+        return self._cache_root / self.__class__.__name__ / self.dataset.name / self.model.name
+
+    @property
+    def metadata(self) -> dict[str, str]:
+        return {**self.actmax_cache.metadata, "dataset": self.dataset.name, "model": self.model.name}
+
+    # ---- hot loop 1: collect (activation_based.py:309-358) ----------------------------------------
+    def run(self, batch_size=32, num_workers=0):
+        """Top-activating samples per component for every layer; loads the cache when present."""
+        if self._cache_root is None:
+            return self._run(batch_size=batch_size, num_workers=num_workers)
+        try:
+            self.actmax_cache.load(self.storage_dir)
+            return self.actmax_cache.cache
+        except FileNotFoundError:
+            logger.debug(f"Activation maximization cache not found at {self.storage_dir}. Running computation...")
+            return self._run(batch_size=batch_size, num_workers=num_workers)
+
+    @torch.no_grad()
+    def _run(self, batch_size: int = 64, num_workers: int = 0, sample_range: tuple[int, int] | None = None):
+        dataset = self.dataset
+        if sample_range is not None:  # one shard: ids stay global dataset indices
+            start, stop = sample_range
+            dataset = torch.utils.data.Subset(self.dataset, range(start, stop))
+            for name in self.layer_names:
+                self.actmax_cache.sample_idx_counter[name] = start
+        dataloader = torch.utils.data.DataLoader(dataset, batch_size=batch_size, shuffle=False, num_workers=num_workers)
+        device = self.device
+        with self.actmax_cache.hook_context(self.model):
+            for images, _ in tqdm(dataloader, total=len(dataloader), desc="Collecting ActMax"):
+                self.model(images.to(device, non_blocking=True))
+
+        if self._cache_root and sample_range is None:
+            self.actmax_cache.store(self.storage_dir)
+            logger.debug(f"Stored activation maximization cache at {self.storage_dir}")
+        return self.actmax_cache.cache
+
+    # ---- hot loop 2 + gather (activation_based.py:360-451) ---------------------------------------
+    @torch.no_grad()
+    def _compute_concept_db(self, fm, batch_size=32, keep_on_device: bool = False, **kwargs):
+        """``{layer: (n_components, n_samples, D)}`` = embeddings of each component's top samples.
+
+        Returns host tensors like the reference unless ``keep_on_device`` is set.
+        """
+        self.run(batch_size=batch_size, **kwargs)
+        embeds = self._embed_vision_dataset(fm, batch_size, **kwargs)
+        concept_db = dict()
+        for layer_name in self.layer_names:
+            ids = self.get_max_reference(layer_name)
+            gathered = N.gather_rows(embeds, ids)
+            concept_db[layer_name] = gathered if keep_on_device else gathered.cpu()
+        return concept_db
+
+    def _embed_vision_dataset(self, fm, batch_size, **kwargs):
+        """Embed every ``dataset_fm`` sample with ``fm``; returns the ``(N, D)`` fp32 table resident on the device."""
+        fm.to(self.device)
+
+        def pil_list_collate(batch):
+            if isinstance(batch[0], (tuple, list)):
+                return [item[0] for item in batch]
+            return list(batch)
+
+        loader = torch.utils.data.DataLoader(
+            self.dataset_fm, batch_size=batch_size, shuffle=False, collate_fn=pil_list_collate, **kwargs
+        )
+        n_total = len(self.dataset_fm)
+        embeds = None
+        filled = 0
+        with tqdm(total=len(self.dataset), desc="Embedding Dataset") as pbar:
+            for pil_list in loader:
+                out = fm.encode_image(fm.preprocess(pil_list))
+                out = N.to_device(out.detach()).to(torch.float32)
+                if embeds is None:
+                    embeds = torch.empty((n_total, out.shape[1]), dtype=torch.float32, device=out.device)
+                embeds[filled : filled + out.shape[0]] = out
+                filled += out.shape[0]
+                pbar.update(batch_size)
+        if embeds is None:
+            raise RuntimeError("dataset_fm is empty: nothing to embed")
+        assert filled == n_total, "Number of embeddings does not match number of ids!"
+        return embeds
+
+    def get_max_reference(self, layer_name) -> torch.Tensor:
+        """``(n_components, n_samples)`` int64 dataset indices (``-1`` = slot never filled)."""
+        self._check_layer_name(layer_name)
+        return self.actmax_cache.cache[layer_name].sample_ids
+
+    def visualize_components(self, *args, **kwargs):
+        """Plotting of the reference (activation_based.py:453-543) is outside the concept-DB hot path."""
+        raise NotImplementedError(
+            "visualize_components (matplotlib grid rendering) is out of scope of semanticlens_amd; "
+            "use get_max_reference(layer) and plot the samples with the reference package."
+        )
+
+    def _check_layer_name(self, layer_name):
+        if layer_name not in self.layer_names:
+            raise ValueError(f"Layer '{layer_name}' not found in model layers: {self.layer_names}")

@@ -1,0 +1,420 @@
+"""Streaming top-k activation collection (ActMax / ActCache / ActMaxCache) on the MI355X.
+
+Mirror of ``semanticlens/component_visualization/activation_caching.py`` (reference v0.2.1):
+same classes, attributes, cache-file layout and error behaviour.  What differs is where the
+work happens.  The reference aggregates on the device, copies a ``(B, C)`` tensor to the host
+per layer per batch and runs ``cat -> torch.topk -> gather`` on the CPU
+(activation_caching.py:133-141).  Here the top-k state ``(C, k)`` bf16 + int64 lives in HBM and
+a forward hook launches two kernels on torch's current stream, with no host synchronisation:
+
+* K1/K2 (``csrc/reduce.hip``): activation -> ``(B, C)`` bf16 candidates,
+* K3 (``csrc/actmax.hip`` / ``actmax_aten.hip``): merge candidates into the state.
+
+Tie modes (``tie_mode`` argument, default from ``$SEMANTICLENS_AMD_TIES``, else ``"aten"``):
+
+``"aten"``   bit-identical to the reference: one merge per batch reproducing torch.topk's CPU
+             tie order on ``cat([state, batch])``.
+``"total"``  value descending then sample id ascending.  Independent of batch size and of how
+             the dataset is sharded (used for multi-GPU); candidate batches are queued in a ring
+             and merged every ``$SEMANTICLENS_AMD_MERGE_EVERY`` (default 8) batches.
+Both store the same bf16 values; they can differ only in which of several equal-valued samples
+is listed (see DESIGN.md "Tie semantics").
+"""
+from __future__ import annotations
+
+import inspect
+import logging
+import os
+from collections import Counter, OrderedDict
+from collections.abc import Callable
+from contextlib import contextmanager
+from pathlib import Path
+from typing import Any
+
+import safetensors
+import safetensors.torch
+import torch
+
+from semanticlens_amd import _native as N
+
+from . import aggregators
+
+logger = logging.getLogger(__name__)
+
+DEFAULT_AGGREGATION_FUNCTION_MAP = {name: func for name, func in inspect.getmembers(aggregators, inspect.isfunction)}
+
+
+def default_tie_mode() -> str:
+    mode = os.environ.get("SEMANTICLENS_AMD_TIES", "aten").lower()
+    if mode not in N.TIE_MODES:
+        raise ValueError(f"SEMANTICLENS_AMD_TIES must be one of {sorted(N.TIE_MODES)}, got {mode!r}")
+    return mode
+
+
+def _merge_every() -> int:
+    return max(1, min(N.SL_MAX_SLOTS, int(os.environ.get("SEMANTICLENS_AMD_MERGE_EVERY", "8"))))
+
+
+class ActMax:
+    """Top-``n_collect`` activations (bf16) and their sample ids (int64) per latent.
+
+    Reference: activation_caching.py:64-216.  ``activations`` / ``sample_ids`` are host tensors
+    as in the reference; reading them flushes pending device work and copies the state down.
+    """
+
+    def __init__(self, n_collect: int, n_latents: int | None = None, tie_mode: str | None = None):
+        self.n_collect = n_collect
+        self.n_latents = n_latents
+        self.is_setup = False
+        self.tie_mode = tie_mode or default_tie_mode()
+        if self.tie_mode not in N.TIE_MODES:
+            raise ValueError(f"tie_mode must be one of {sorted(N.TIE_MODES)}, got {self.tie_mode!r}")
+        self._host_vals: torch.Tensor | None = None
+        self._host_ids: torch.Tensor | None = None
+        self._dev_vals: torch.Tensor | None = None  # (C,k) bf16 in HBM
+        self._dev_ids: torch.Tensor | None = None  # (C,k) int64 in HBM
+        self._dev_newer = False
+        self._ring: torch.Tensor | None = None  # (slots, Bcap, C) bf16 candidate batches awaiting a merge
+        self._pending: list[tuple[int, int]] = []  # (id_base, rows) per queued slot
+        self._ws: torch.Tensor | None = None
+        if n_latents is not None:
+            self._setup_tensors()
+
+    # ---- state -------------------------------------------------------------------------------
+    def _setup_tensors(self):
+        """Initial state: values -0.0, ids -1 (activation_caching.py:101-110)."""
+        self._host_vals = -torch.zeros(self.n_latents, self.n_collect, dtype=torch.bfloat16)
+        self._host_ids = -torch.ones(self.n_latents, self.n_collect, dtype=torch.int64)
+        self._dev_vals = self._dev_ids = None
+        self._dev_newer = False
+        self.is_setup = True
+
+    def _device_state(self, device: torch.device):
+        if self._dev_vals is None or self._dev_vals.device != device:
+            self.flush()
+            self._sync_host()
+            self._dev_vals = self._host_vals.to(device).contiguous()
+            self._dev_ids = self._host_ids.to(device).contiguous()
+            self._ring = None
+        return self._dev_vals, self._dev_ids
+
+    def _sync_host(self):
+        if self._dev_newer:
+            self._host_vals = self._dev_vals.cpu()
+            self._host_ids = self._dev_ids.cpu()
+            self._dev_newer = False
+
+    @property
+    def activations(self) -> torch.Tensor:
+        self.flush()
+        self._sync_host()
+        return self._host_vals
+
+    @activations.setter
+    def activations(self, value: torch.Tensor):
+        self.flush()
+        self._sync_host()
+        self._host_vals = value.detach().to("cpu", torch.bfloat16)
+        self._dev_vals = self._dev_ids = None
+
+    @property
+    def sample_ids(self) -> torch.Tensor:
+        self.flush()
+        self._sync_host()
+        return self._host_ids
+
+    @sample_ids.setter
+    def sample_ids(self, value: torch.Tensor):
+        self.flush()
+        self._sync_host()
+        self._host_ids = value.detach().to("cpu", torch.int64)
+        self._dev_vals = self._dev_ids = None
+
+    def device_state(self, device=None):
+        """(values bf16, ids int64) resident on the HIP device, pending merges applied."""
+        device = torch.device(device) if device is not None else (
+            self._dev_vals.device if self._dev_vals is not None else N.default_device()
+        )
+        state = self._device_state(device)
+        self.flush()
+        return state
+
+    # ---- updates -----------------------------------------------------------------------------
+    def update(self, acts: torch.Tensor, sample_ids: torch.Tensor):
+        """Merge a ``(B, n_latents)`` batch with explicit sample ids (activation_caching.py:112-141)."""
+        assert acts.ndim == 2
+        if not self.is_setup:
+            self.n_latents = acts.shape[1]
+            self._setup_tensors()
+        a = N.to_device(acts.detach())
+        B, C = a.shape
+        if C != self.n_latents:
+            raise RuntimeError(f"activation batch has {C} latents, ActMax was set up for {self.n_latents}")
+        if self.n_collect == 0 or B == 0:
+            return
+        vals, ids = self._device_state(a.device)
+        self.flush()
+        cand = torch.empty((B, C), dtype=torch.bfloat16, device=a.device)
+        # (B, C) -> bf16 exactly as `acts.T.to(bfloat16)` (:133): K1 with a 1-element reduction axis
+        N.reduce_conv(a.reshape(B, C, 1, 1), N.SL_CONV_MAX, cand, None)
+        sid = N.to_device(sample_ids.detach(), a.device).to(torch.int64).contiguous()
+        if sid.shape != (B,):
+            raise RuntimeError(f"sample_ids has shape {tuple(sid.shape)}, expected ({B},)")
+        N.actmax_update(vals, ids, cand, sid, 0, B, N.TIE_MODES[self.tie_mode], self._aten_ws(B, a.device))
+        self._dev_newer = True
+
+    def collect(self, outs: torch.Tensor, native: tuple, id_base: int):
+        """Fused hook path: reduce ``outs`` on the device and merge; samples get ids id_base + b."""
+        kind, code, pos = native
+        x = N.to_device(outs.detach())
+        B = x.shape[0]
+        C = x.shape[1] if kind == "conv" else x.shape[2]
+        if not self.is_setup:
+            self.n_latents = C
+            self._setup_tensors()
+        if C != self.n_latents:
+            raise RuntimeError(f"layer output has {C} components, ActMax was set up for {self.n_latents}")
+        if self.n_collect == 0 or B == 0:
+            return
+        vals, ids = self._device_state(x.device)
+        slots = 1 if self.tie_mode == "aten" else _merge_every()
+        if self._ring is None or self._ring.shape[1] < B or self._ring.shape[0] != slots:
+            self.flush()
+            self._ring = torch.empty((slots, B, C), dtype=torch.bfloat16, device=x.device)
+        slot = self._ring[len(self._pending)]
+        cand = slot[:B]
+        if kind == "conv":
+            N.reduce_conv(x, code, cand, None)
+        else:
+            N.reduce_tokens(x, code, pos, cand, None)
+        if self.tie_mode == "aten":
+            N.actmax_update(vals, ids, cand, None, id_base, B, N.SL_TIES_ATEN, self._aten_ws(B, x.device))
+            self._dev_newer = True
+        else:
+            self._pending.append((id_base, B))
+            if len(self._pending) == slots:
+                self.flush()
+
+    def flush(self):
+        """Merge every queued candidate batch into the state (total-order mode)."""
+        if self._pending:
+            ring = self._ring
+            N.actmax_merge(
+                self._dev_vals, self._dev_ids, ring, ring.stride(0), [p[0] for p in self._pending],
+                [p[1] for p in self._pending],
+            )
+            self._pending = []
+            self._dev_newer = True
+
+    def merge_states(self, other_vals: torch.Tensor, other_ids: torch.Tensor):
+        """K4: fold ``R`` other states ``(R, C, k)`` (e.g. all-gathered ranks) into this one, total order."""
+        if not self.is_setup:
+            raise RuntimeError("merge_states on an ActMax that is not set up")
+        ov = N.to_device(other_vals)
+        vals, ids = self._device_state(ov.device)
+        self.flush()
+        oi = N.to_device(other_ids, ov.device).to(torch.int64).contiguous()
+        ov = ov.to(torch.bfloat16).contiguous()
+        if ov.shape[1:] != vals.shape or oi.shape != ov.shape:
+            raise RuntimeError(f"states to merge have shape {tuple(ov.shape)}, expected (R, {vals.shape[0]}, {vals.shape[1]})")
+        N.actmax_merge_states(vals, ids, ov, oi)
+        self._dev_newer = True
+
+    def _aten_ws(self, B: int, device):
+        if self.tie_mode != "aten":
+            return None
+        need = N.actmax_aten_ws_bytes(self.n_latents, self.n_collect, B)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws
+
+    # ---- reference utilities -------------------------------------------------------------------
+    @property
+    def alive_latents(self) -> torch.Tensor:
+        """Indices of latents with any non-zero stored activation (activation_caching.py:143-156)."""
+        if not self.is_setup:
+            return torch.tensor([], dtype=torch.int64)
+        return torch.where(self.activations.abs().sum(dim=1) > 0)[0]
+
+    def store(self, file_path: str | Path, metadata: dict[str, str] | None = None):
+        """Write ``activations`` / ``sample_ids`` + metadata as safetensors (activation_caching.py:158-182)."""
+        if not self.is_setup:
+            logger.warning("Attempted to store an un-initialized ActMax instance; skipping.")
+            return
+        tensors = {"activations": self.activations, "sample_ids": self.sample_ids}
+        safetensors.torch.save_file(tensors, file_path, metadata=metadata)
+        logger.debug(f"Stored ActMax data to {file_path}")
+
+    @classmethod
+    def load(cls, file_path: str | Path) -> ActMax:
+        """Read a file written by :meth:`store` (or by the reference; activation_caching.py:184-216)."""
+        with safetensors.safe_open(file_path, framework="pt") as f:
+            metadata = f.metadata()
+            if metadata is None:
+                raise ValueError(f"File {file_path} is missing required metadata for loading.")
+            tensors = {k: f.get_tensor(k) for k in f.keys()}
+        instance = cls(n_collect=int(metadata["n_collect"]), n_latents=int(metadata["n_latents"]))
+        instance.activations = tensors["activations"]
+        instance.sample_ids = tensors["sample_ids"]
+        return instance
+
+
+class ActCache:
+    """Forward-hook plumbing: keeps each hooked layer's raw output (activation_caching.py:219-315)."""
+
+    def __init__(self, layer_names: list[str]):
+        self.layer_names = layer_names
+        self.cache: dict[str, Any] = OrderedDict()
+        self.handles: list[torch.utils.hooks.RemovableHandle] = []
+
+    def _get_hook(self, name: str) -> Callable:
+        def hook_fn(module, ins, outs):
+            self.cache[name] = outs.detach().cpu()
+
+        return hook_fn
+
+    def _register_hooks(self, model: torch.nn.Module):
+        for name, module in model.named_modules():
+            if name in self.layer_names:
+                self.handles.append(module.register_forward_hook(self._get_hook(name)))
+
+    def _finalize(self):
+        pass
+
+    @contextmanager
+    def hook_context(self, model: torch.nn.Module):
+        """Register the hooks for the duration of the ``with`` block; always removes them."""
+        self._register_hooks(model)
+        try:
+            yield
+        finally:
+            for handle in self.handles:
+                handle.remove()
+            self.handles.clear()
+            self._finalize()
+
+
+class ActMaxCache(ActCache):
+    """Per-layer :class:`ActMax` instances fed by forward hooks (activation_caching.py:318-534)."""
+
+    def __init__(self, layer_names: list[str], aggregation_fn: Callable, n_collect: int, tie_mode: str | None = None):
+        super().__init__(layer_names)
+        self.aggregation_fn = aggregation_fn
+        self.n_collect = n_collect
+        self.tie_mode = tie_mode or default_tie_mode()
+        self.sample_idx_counter = Counter()  # per layer, never reset (activation_caching.py:359,410-413)
+
+        agg_fn_name = getattr(self.aggregation_fn, "__name__", None)
+        if agg_fn_name is None or agg_fn_name == "<lambda>":
+            raise ValueError("Aggregation function must be a defined function, not a lambda.")
+        self.agg_fn_name = agg_fn_name
+
+        self.cache: dict[str, ActMax] = {
+            name: ActMax(n_collect=n_collect, tie_mode=self.tie_mode) for name in layer_names
+        }
+
+    def __getitem__(self, layer_name: str) -> ActMax:
+        return self.cache[layer_name]
+
+    def __iter__(self):
+        return iter(self.cache.values())
+
+    def _get_hook(self, layer_name: str) -> Callable:
+        native = getattr(self.aggregation_fn, "_sl_native", None)
+
+        def hook_fn(module, ins, outs):
+            start = self.sample_idx_counter[layer_name]
+            if native is not None:
+                # same argument check (and error text) the aggregator itself makes
+                want = 4 if native[0] == "conv" else 3
+                if outs.ndim != want:
+                    raise ValueError(f"Input tensor should be {want}D. \n" + aggregators._ERROR_MESSAGE)
+                batch_size = outs.shape[0]
+                self.sample_idx_counter[layer_name] += batch_size
+                self.cache[layer_name].collect(outs, native, start)
+                return
+            # user-defined aggregator: (B, C) tensor on any device, then K3 alone
+            aggregated_acts = self.aggregation_fn(outs)
+            batch_size = aggregated_acts.shape[0]
+            assert aggregated_acts.ndim == 2, "Something is wrong with the aggregation_fn"
+            sample_ids = torch.arange(start, start + batch_size)
+            self.sample_idx_counter[layer_name] += batch_size
+            self.cache[layer_name].update(aggregated_acts, sample_ids)
+
+        return hook_fn
+
+    def _finalize(self):
+        for act_max in self.cache.values():
+            act_max.flush()
+
+    def __repr__(self) -> str:
+        agg_name = getattr(self.aggregation_fn, "__name__", "custom_function")
+        return f"ActMaxCache(layers={list(self.layer_names)}, aggregation_fn='{agg_name}', n_collect={self.n_collect})"
+
+    @property
+    def metadata(self) -> dict[str, str]:
+        return dict(
+            aggregation_fn_name=self.agg_fn_name,
+            n_collect=str(self.n_collect),
+            layer_names=str(list(self.cache.keys())),
+        )
+
+    def _file_name(self, layer_name: str) -> str:
+        # "<aggregation fn>-<n_collect>-<layer>.safetensors" (activation_caching.py:454-461, 495-501)
+        return "-".join([self.agg_fn_name, str(self.n_collect), layer_name]) + ".safetensors"
+
+    def store(self, directory: Path | str):
+        """One safetensors file per layer, byte-compatible with the reference (activation_caching.py:434-465)."""
+        directory = Path(directory)
+        directory.mkdir(parents=True, exist_ok=True)
+        for layer_name, act_max_instance in self.cache.items():
+            if not act_max_instance.is_setup:
+                logger.warning(f"Skipping layer '{layer_name}' as it has no data.")
+                continue
+            metadata = {
+                "aggregation_fn_name": self.agg_fn_name,
+                "n_collect": str(self.n_collect),
+                "n_latents": str(act_max_instance.n_latents),
+                "layer_name": layer_name,
+            }
+            act_max_instance.store(directory / self._file_name(layer_name), metadata=metadata)
+        logger.info(f"Cache saved successfully to {directory}")
+
+    def load(self, directory: Path | str):
+        """Load every layer's file; any missing/mismatching file raises FileNotFoundError = cache miss
+        (activation_caching.py:467-534)."""
+        directory = Path(directory)
+        if not directory.is_dir():
+            raise FileNotFoundError(f"Cache directory not found: {directory}")
+        expected_agg_fn_name = self.aggregation_fn.__name__
+        logger.info(f"Loading cache for aggregation fn: '{expected_agg_fn_name}'")
+        loaded_count = 0
+        for layer_name in self.layer_names:
+            fpath = directory / self._file_name(layer_name)
+            if not fpath.exists():
+                logger.warning(f"File not found for layer '{layer_name}': {fpath}")
+                raise FileNotFoundError(f"Expected file not found: {fpath}")
+            try:
+                with safetensors.safe_open(fpath, framework="pt") as f:
+                    metadata = f.metadata()
+                    if metadata.get("aggregation_fn_name") != expected_agg_fn_name:
+                        raise ValueError(
+                            f"Mismatch in aggregation function for layer '{layer_name}'. "
+                            f"Expected '{expected_agg_fn_name}', but file has '{metadata.get('aggregation_fn_name')}'."
+                        )
+                    if int(metadata.get("n_collect")) != self.n_collect:
+                        raise ValueError(
+                            f"Mismatch in n_collect for layer '{layer_name}'. "
+                            f"Expected '{self.n_collect}', but file has '{metadata.get('n_collect')}'."
+                        )
+            except ValueError as e:
+                logger.warning(f"Validation failed for layer '{layer_name}': {e}")
+                raise FileNotFoundError(f"Expected file not found: {fpath}")
+            loaded = ActMax.load(fpath)
+            loaded.tie_mode = self.tie_mode
+            self.cache[layer_name] = loaded
+            loaded_count += 1
+        if loaded_count == 0:
+            logger.warning(f"No matching cache files were found and loaded from {directory}")
+        else:
+            logger.info(f"Successfully loaded data for {loaded_count} layer(s) from {directory}")

@@ -1,0 +1,5 @@
+"""Foundation-model plugins (reference: foundation_models/__init__.py:12-14)."""
+from semanticlens_amd.foundation_models.base import AbstractVLM
+from semanticlens_amd.foundation_models.clip import ClipMobile, OpenClip, SigLipV2
+
+__all__ = ["AbstractVLM", "OpenClip", "ClipMobile", "SigLipV2"]

@@ -1,0 +1,137 @@
+"""Lens — orchestration of concept-DB build, probing and evaluation.
+
+Mirror of ``semanticlens/lens.py`` (reference v0.2.1): same module-level functions and ``Lens``
+methods, same cache-file naming.  Text/image probing runs the template-difference mean (K10)
+and the cosine GEMM (K6) on the device; query embeddings are not bounced through the host
+between the text tower and the GEMM.
+"""
+from __future__ import annotations
+
+import logging
+
+import torch
+from safetensors.torch import load_file, save_file
+from tqdm.auto import tqdm
+
+from semanticlens_amd import _native as N
+from semanticlens_amd.component_visualization.base import AbstractComponentVisualizer
+from semanticlens_amd.foundation_models.base import AbstractVLM
+from semanticlens_amd.scores import clarity_score, polysemanticity_score, redundancy_score, similarity_score
+from semanticlens_amd.utils.helper import get_fallback_name
+
+logger = logging.getLogger(__name__)
+
+
+def compute_concept_db(cv: AbstractComponentVisualizer, fm: AbstractVLM):
+    """Stateless concept-DB build: delegates to ``cv._compute_concept_db(fm)`` (lens.py:27-56)."""
+    return cv._compute_concept_db(fm)
+
+
+def text_probing(fm, query, aggregated_concept_db, templates=None, batch_size=None):
+    """Cosine similarity of text queries against ``(n_components, D)`` concept embeddings (lens.py:59-121)."""
+    queries = query if isinstance(query, list) else [query]
+    query_embeds = _embed_text_probes(fm, queries, templates, batch_size)
+    assert query_embeds.ndim == 2
+    assert query_embeds.shape[0] == len(queries)
+    return _probe(query_embeds, aggregated_concept_db)
+
+
+def image_probing(fm, query, aggregated_concept_db):
+    """Cosine similarity of an image query (several images are averaged) against the DB (lens.py:124-162)."""
+    with torch.no_grad():
+        query_embed = fm.encode_image(fm.preprocess(query).to(fm.device))
+    query_embed = query_embed.mean(0)[None] if query_embed.shape[0] > 1 else query_embed
+    return _probe(query_embed, aggregated_concept_db)
+
+
+@torch.no_grad()
+def _embed_text_probes(fm, query: list[str], templates: list[str] | None, batch_size: int | None):
+    """Tokenise + encode the (templated) queries; with templates, subtract the empty-template
+    embedding and average over templates (lens.py:165-203).
+
+    The reference builds the templated list template-major (``for t in templates for q in query``,
+    :174) but regroups it query-major (``"(q t) d -> q t d"``, :197).  That grouping is kept
+    (SURVEY.md finding 4) so probing scores equal the reference's.
+    """
+    if templates:
+        query_templated = [t.format(q) for t in templates for q in query]
+        empty_templates = [t.format("") for t in templates]
+        batch_size = batch_size or len(query_templated)
+        chunks = []
+        for start in tqdm(
+            range(0, len(query_templated), batch_size),
+            desc="text embedding ...",
+            leave=False,
+            disable=batch_size == len(query_templated),
+        ):
+            chunk = query_templated[start : start + batch_size]
+            chunks.append(fm.encode_text(fm.tokenize(chunk).to(fm.device)))
+        templated = torch.cat(chunks, dim=0)
+        empty = fm.encode_text(fm.tokenize(empty_templates).to(fm.device))
+        return N.template_mean(templated, empty, len(query))
+    return fm.encode_text(fm.tokenize(query).to(fm.device))
+
+
+@torch.no_grad()
+def _probe(query: torch.Tensor, aggregated_concept_db):
+    if isinstance(aggregated_concept_db, torch.Tensor):
+        return similarity_score(query.to(aggregated_concept_db.device), aggregated_concept_db)
+    return {key: similarity_score(query.to(value.device), value) for key, value in aggregated_concept_db.items()}
+
+
+class Lens:
+    """Holds the foundation model and wraps the workflow (reference: lens.py:217-480)."""
+
+    def __init__(self, fm, device=None):
+        self.fm = fm
+        self.device = device or self.fm.device
+        self.fm.to(self.device)
+        if not hasattr(self.fm, "name"):
+            self.fm.name = get_fallback_name(self.fm)
+            logger.debug(f"Assigned fallback name to foundation model: {self.fm.name}")
+
+    def compute_concept_db(self, cv: AbstractComponentVisualizer, **kwargs) -> dict[str, torch.Tensor]:
+        """Build the concept DB through ``cv``, or load it from ``cv``'s cache directory.
+
+        Cache file: ``<storage_dir>/concept_database/<fm.name>/concept_db-<metadata values except
+        dataset,model joined by '-'>.safetensors`` (lens.py:308-316).
+        """
+        if not cv.caching:
+            logger.debug("Caching is not enabled. Computing Concept DB")
+            return cv._compute_concept_db(self.fm, **kwargs)
+        fdir = cv.storage_dir / "concept_database" / self.fm.name
+        fdir.mkdir(parents=True, exist_ok=True)
+        fname = "concept_db-" + "-".join(v for k, v in cv.metadata.items() if k not in ["dataset", "model"]) + ".safetensors"
+        fpath = fdir / fname
+        if fpath.exists():
+            logger.debug("Loading concept DB from cache")
+            return load_file(filename=fpath)
+        logger.debug("Computing concept DB and saving to cache")
+        concept_db = cv._compute_concept_db(self.fm, **kwargs)
+        save_file(tensors=concept_db, filename=fpath)
+        logger.debug(f"Saved concept DB to cache {fpath}")
+        return concept_db
+
+    def text_probing(self, query, aggregated_concept_db, templates=None, batch_size=None):
+        return text_probing(self.fm, query, aggregated_concept_db, templates, batch_size)
+
+    def image_probing(self, query, aggregated_concept_db):
+        return image_probing(self.fm, query, aggregated_concept_db)
+
+    @staticmethod
+    def _per_layer(fn, db):
+        if isinstance(db, torch.Tensor):
+            return fn(db)
+        return {key: fn(value) for key, value in db.items()}
+
+    def eval_clarity(self, concept_db):
+        """``clarity_score`` of a ``(C, n, D)`` tensor or of each layer of a dict (lens.py:391-419)."""
+        return self._per_layer(clarity_score, concept_db)
+
+    def eval_redundancy(self, aggregated_concept_db):
+        """``redundancy_score`` of a ``(C, D)`` tensor or dict of tensors (lens.py:421-449)."""
+        return self._per_layer(redundancy_score, aggregated_concept_db)
+
+    def eval_polysemanticity(self, concept_db):
+        """``polysemanticity_score`` of a ``(C, n, D)`` tensor or dict of tensors (lens.py:451-480)."""
+        return self._per_layer(polysemanticity_score, concept_db)

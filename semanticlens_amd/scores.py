@@ -1,0 +1,81 @@
+"""Concept-quality scores (reference: semanticlens/scores.py:18-185) on HIP kernels.
+
+Same names, arguments and shape conventions as the reference — including the shape-dependent
+branches of ``similarity_score`` (scores.py:119-128).  Inputs may live on the host or the
+device; results come back on the input's device, as with the reference.  There is no CPU
+implementation behind these functions: without a HIP device they raise.
+"""
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+import torch
+
+from semanticlens_amd import _native as N
+
+logger = logging.getLogger(__name__)
+
+
+@torch.inference_mode()
+def clarity_score(V):
+    """Mean off-diagonal cosine among each component's samples.  V (..., n_samples, D) -> (...).
+
+    Reference: scores.py:18-47 — ``((mean_j normalize(v_j))**2).sum(-1) - 1/n) / (n-1) * n``.  Kernel K7.
+    """
+    return N.clarity(V).to(V.device)
+
+
+@torch.inference_mode()
+def redundancy_score(cones):
+    """Mean over components of the max cosine to any *other* component.  (..., C, D) -> (...).
+
+    Reference: scores.py:50-81 (diagonal removed by ``- 2 * eye``).  Kernel K8 = K6's MFMA GEMM + row max.
+    """
+    return N.redundancy(cones).to(cones.device)
+
+
+@torch.inference_mode()
+def similarity_score(x, y):
+    """Cosine similarity with the reference's shape branches (scores.py:84-128):
+
+    * ``x.shape == y.shape``        -> row-wise cosine, shape ``(n,)``
+    * ``x.shape[1] == y.shape[0]``  -> ``normalize(x) @ normalize(y)`` (no transpose)
+    * ``x.shape[1] == y.shape[1]``  -> ``normalize(x) @ normalize(y).T``  (the probing GEMM, K6)
+    * otherwise ``ValueError("x and y must have the same shape")``
+    """
+    return N.similarity(x, y).to(x.device)
+
+
+def kmeans_draws(n_samples: int, n_init: int, random_state: int):
+    """The random draws scikit-learn's ``KMeans(n_init, random_state)`` consumes, per init.
+
+    ``KMeans.fit`` seeds one ``RandomState(random_state)`` and, for each of the ``n_init`` k-means++
+    seedings with 2 clusters, draws ``choice(n_samples, p=uniform)`` for the first centre and
+    ``uniform(size=2 + int(log(2)))`` for the two candidate second centres
+    (sklearn/cluster/_kmeans.py ``_kmeans_plusplus``).  None of it depends on the data, so the host
+    produces the draws and the device kernel consumes them.
+    """
+    rs = np.random.RandomState(random_state)
+    weights = np.ones(n_samples, dtype=np.float32)
+    p = weights / weights.sum()
+    first = np.empty(n_init, dtype=np.int32)
+    rand = np.empty((n_init, 2), dtype=np.float64)
+    for i in range(n_init):
+        first[i] = rs.choice(n_samples, p=p)
+        rand[i] = rs.uniform(size=2)
+    return first, rand
+
+
+@torch.inference_mode()
+def polysemanticity_score(V, replace_empty_clusters=True, random_state=123, n_clusters=2):
+    """``1 - cos(centre_1, centre_2)`` of a 2-means clustering of each component's samples.
+
+    Reference: scores.py:131-185 (scikit-learn ``KMeans(n_clusters=2, n_init=10, random_state=123)``
+    per component in a Python loop).  Kernel K9 restates that procedure per component on the
+    device; rows whose smaller cluster has fewer than 2 samples use the reference's fallback.
+    """
+    if n_clusters != 2:
+        raise NotImplementedError("the device kernel restates KMeans for n_clusters=2 (the reference's default)")
+    first, rand = kmeans_draws(V.shape[-2], 10, random_state)
+    return N.poly2means(V, first, rand, replace_empty_clusters).to(V.device)

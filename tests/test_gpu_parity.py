@@ -1,0 +1,411 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden fixtures.
+
+Bars (BASELINE.json north_star): top-k values and indices bit-exact; cosine / embedding values
+within 1e-4 fp32 (we assert 1e-5).  Mean-type aggregators are order sensitive in fp32 and are
+checked to 1 bf16 ulp on the stored value.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from semanticlens_amd import _native as N
+from semanticlens_amd import scores
+from semanticlens_amd.component_visualization import aggregators as agg
+from semanticlens_amd.component_visualization.activation_caching import ActMax, ActMaxCache
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def bits(t: torch.Tensor) -> np.ndarray:
+    return t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def feq(a, b):
+    """float equality that treats NaN == NaN and -0 == +0 (torch.equal semantics + NaN)."""
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.nan_to_num(a, nan=7e37), np.nan_to_num(b, nan=7e37))
+
+
+def _parse(case):
+    tag, k, B, every = case.split("|")
+    return tag, int(k[2:]), int(B[2:]), bool(int(every[6:]))
+
+
+# ---------------------------------------------------------------------------------------------- K3
+def test_known_answer_of_reference_test(golden):
+    g = golden("actmax_known_answer")
+    for mode in ("aten", "total"):
+        am = ActMax(n_collect=5, n_latents=3, tie_mode=mode)
+        am.update(torch.from_numpy(g["acts1"]), torch.from_numpy(g["ids1"]))
+        am.update(torch.from_numpy(g["acts2"]), torch.from_numpy(g["ids2"]))
+        assert torch.allclose(am.activations[0], torch.tensor([0.9, 0.8, 0.2, 0.1, 0.0]).to(torch.bfloat16))
+        assert torch.allclose(am.sample_ids[0], torch.tensor([2, 3, 1, 0, -1]))
+        assert np.array_equal(bits(am.activations), g["vals"])
+        assert np.array_equal(am.sample_ids.numpy(), g["ids"])
+
+
+def test_golden_streams_aten_mode_bit_exact(golden):
+    """tie_mode='aten' equals the reference after EVERY batch, ties included."""
+    g = golden("actmax_streams")
+    for idx, case in enumerate(g["cases"]):
+        tag, k, B, every = _parse(str(case))
+        acts = g[f"acts_{idx}"]
+        am = ActMax(n_collect=k, n_latents=acts.shape[1], tie_mode="aten")
+        step = 0
+        for s in range(0, acts.shape[0], B):
+            e = min(acts.shape[0], s + B)
+            am.update(torch.from_numpy(acts[s:e]), torch.arange(s, e))
+            if every:
+                assert np.array_equal(bits(am.activations), g[f"vals_{idx}"][step]), (tag, k, B, step)
+                assert np.array_equal(am.sample_ids.numpy(), g[f"ids_{idx}"][step]), (tag, k, B, step)
+            step += 1
+        assert np.array_equal(bits(am.activations), g[f"vals_{idx}"][-1]), (tag, k, B)
+        assert np.array_equal(am.sample_ids.numpy(), g[f"ids_{idx}"][-1]), (tag, k, B)
+
+
+def test_golden_streams_total_mode(golden):
+    """tie_mode='total' == oracle(total) bit-exact; == the reference itself on tie-free inputs."""
+    g = golden("actmax_streams")
+    for idx, case in enumerate(g["cases"]):
+        tag, k, B, every = _parse(str(case))
+        acts = g[f"acts_{idx}"]
+        N_, C = acts.shape
+        am = ActMax(n_collect=k, n_latents=C, tie_mode="total")
+        ref = oracle.ActMaxOracle(k, C, oracle.MODE_TOTAL)
+        for s in range(0, N_, B):
+            e = min(N_, s + B)
+            am.update(torch.from_numpy(acts[s:e]), torch.arange(s, e))
+            ref.update(acts[s:e], np.arange(s, e))
+        assert np.array_equal(bits(am.activations), ref.vals), (tag, k, B)
+        assert np.array_equal(am.sample_ids.numpy(), ref.ids), (tag, k, B)
+        if tag in ("tiefree", "allneg"):
+            assert np.array_equal(bits(am.activations), g[f"vals_{idx}"][-1])
+            assert np.array_equal(am.sample_ids.numpy(), g[f"ids_{idx}"][-1])
+        else:
+            assert feq(oracle.bf16_to_f32(bits(am.activations)), oracle.bf16_to_f32(g[f"vals_{idx}"][-1]))
+
+
+@pytest.mark.parametrize("C,k,B,N_", [(512, 20, 64, 1000), (2048, 100, 256, 1024), (37, 7, 50, 333), (5, 300, 64, 400)])
+def test_random_streams_vs_oracle_both_modes(C, k, B, N_):
+    rng = np.random.RandomState(C + k)
+    acts = np.maximum(rng.randn(N_, C), 0).astype(np.float32)  # ReLU-like: many exact zeros + bf16 ties
+    for mode, omode in (("aten", oracle.MODE_ATEN), ("total", oracle.MODE_TOTAL)):
+        am = ActMax(n_collect=k, n_latents=C, tie_mode=mode)
+        ref = oracle.ActMaxOracle(k, C, omode)
+        for s in range(0, N_, B):
+            e = min(N_, s + B)
+            am.update(torch.from_numpy(acts[s:e]).to(DEV), torch.arange(s, e))
+            ref.update(acts[s:e], np.arange(s, e))
+        assert np.array_equal(bits(am.activations), ref.vals), mode
+        assert np.array_equal(am.sample_ids.numpy(), ref.ids), mode
+
+
+def test_total_mode_is_batch_invariant_and_shard_mergeable():
+    rng = np.random.RandomState(3)
+    N_, C, k = 3000, 256, 20
+    acts = (rng.randint(0, 64, size=(N_, C)) / 8.0).astype(np.float32)  # tie-heavy
+    x = torch.from_numpy(acts).to(DEV)
+    results = []
+    for B in (64, 256, 1000):
+        am = ActMax(n_collect=k, n_latents=C, tie_mode="total")
+        for s in range(0, N_, B):
+            am.update(x[s : s + B], torch.arange(s, min(N_, s + B)))
+        results.append((bits(am.activations), am.sample_ids.numpy()))
+    for v, i in results[1:]:
+        assert np.array_equal(v, results[0][0]) and np.array_equal(i, results[0][1])
+    # 4 shards, merged with K4 == single stream
+    bounds = [0, 700, 1500, 2300, N_]
+    shards = []
+    for r in range(4):
+        am = ActMax(n_collect=k, n_latents=C, tie_mode="total")
+        for s in range(bounds[r], bounds[r + 1], 128):
+            e = min(bounds[r + 1], s + 128)
+            am.update(x[s:e], torch.arange(s, e))
+        shards.append(am)
+    ov = torch.stack([shards[r].device_state()[0] for r in (0, 1, 3)])
+    oi = torch.stack([shards[r].device_state()[1] for r in (0, 1, 3)])
+    shards[2].merge_states(ov, oi)
+    assert np.array_equal(bits(shards[2].activations), results[0][0])
+    assert np.array_equal(shards[2].sample_ids.numpy(), results[0][1])
+    ref = oracle.ActMaxOracle(k, C, oracle.MODE_TOTAL)
+    ref.update(acts, np.arange(N_))
+    assert np.array_equal(results[0][0], ref.vals) and np.array_equal(results[0][1], ref.ids)
+
+
+# ------------------------------------------------------------------------------------------- K1/K2
+CONV_SHAPES = [
+    (2, 3, 1, 1), (3, 5, 1, 3), (2, 4, 2, 2), (3, 7, 3, 3), (4, 8, 7, 7), (5, 6, 7, 7), (2, 16, 8, 8), (3, 5, 9, 9),
+    (2, 9, 13, 13), (2, 8, 14, 14), (3, 3, 15, 17), (2, 4, 28, 28), (1, 3, 56, 56), (2, 2, 57, 59), (1, 2, 100, 103),
+    (64, 256, 7, 7), (16, 64, 14, 14),
+]
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv_reduce_vs_oracle(shape):
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g)
+    x[0, 0, 0, 0] = float("nan")
+    if shape[1] > 1:
+        x[-1, 1].fill_(-3.0)
+        x[-1, 1, -1, -1] = float("inf")
+    xd = x.to(DEV)
+    B, C = shape[:2]
+    for name, code in (("max", N.SL_CONV_MAX), ("mean", N.SL_CONV_MEAN)):
+        cand = torch.empty((B, C), dtype=torch.bfloat16, device=DEV)
+        out = torch.empty((B, C), dtype=torch.float32, device=DEV)
+        N.reduce_conv(xd, code, cand, out)
+        want = oracle.agg_conv(x.numpy(), name)
+        if name == "max":
+            assert feq(out.cpu().numpy(), want), shape  # exact
+            assert np.array_equal(bits(cand), oracle.f32_to_bf16(want)), shape
+        else:
+            np.testing.assert_allclose(out.cpu().numpy(), want, rtol=2e-6, atol=1e-6, equal_nan=True)
+            d = np.abs(bits(cand).astype(np.int32) - oracle.f32_to_bf16(want).astype(np.int32))
+            assert d.max() <= 1, shape  # <= 1 bf16 ulp
+    # python-facing aggregators return the activation dtype on the host, like the reference
+    assert feq(agg.aggregate_conv_max(xd).numpy(), oracle.agg_conv(x.numpy(), "max"))
+    assert agg.aggregate_conv_max(xd).device.type == "cpu"
+
+
+def test_conv_reduce_layouts_and_dtypes():
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(6, 32, 7, 7, generator=g)
+    want = oracle.agg_conv(x.numpy(), "max")
+    xd = x.to(DEV)
+    for variant in (xd.contiguous(memory_format=torch.channels_last), xd[:, ::2], xd.transpose(2, 3), xd[:, :, 1:6, 2:5]):
+        ref = oracle.agg_conv(variant.cpu().contiguous().numpy(), "max")
+        out = torch.empty(variant.shape[:2], dtype=torch.float32, device=DEV)
+        N.reduce_conv(variant, N.SL_CONV_MAX, None, out)
+        assert feq(out.cpu().numpy(), ref)
+    assert feq(agg.aggregate_conv_max(xd.contiguous(memory_format=torch.channels_last)).numpy(), want)
+    for dt in (torch.float16, torch.bfloat16):
+        xh = xd.to(dt)
+        got = agg.aggregate_conv_max(xh)
+        assert got.dtype == dt
+        assert feq(got.float().numpy(), oracle.agg_conv(xh.float().cpu().numpy(), "max"))
+        cand = torch.empty((6, 32), dtype=torch.bfloat16, device=DEV)
+        N.reduce_conv(xh, N.SL_CONV_MAX, cand, None)
+        assert np.array_equal(bits(cand), oracle.f32_to_bf16(oracle.agg_conv(xh.float().cpu().numpy(), "max")))
+
+
+TOKEN_SHAPES = [(2, 10, 16), (3, 197, 24), (2, 5, 7), (4, 50, 768), (2, 197, 260), (1, 1, 4), (3, 33, 1000)]
+
+
+@pytest.mark.parametrize("shape", TOKEN_SHAPES)
+def test_token_reduce_vs_oracle(shape):
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g)
+    x[0, 0, 0] = float("nan")
+    xd = x.to(DEV)
+    B, T, F = shape
+    fns = {
+        "mean": agg.aggregate_transformer_mean, "absmean": agg.aggregate_transformer_absmean,
+        "max": agg.aggregate_transformer_max, "absmax": agg.aggregate_transformer_absmax,
+    }
+    for name, fn in fns.items():
+        want = oracle.agg_tokens(x.numpy(), name)
+        got = fn(xd).numpy()
+        if "mean" in name:
+            np.testing.assert_allclose(got, want, rtol=3e-6, atol=1e-6, equal_nan=True)
+        else:
+            assert feq(got, want), (shape, name)
+    for pos in (0, -1, T // 2):
+        got = agg.get_aggregate_transformer_special_token(pos)(xd).numpy()
+        assert feq(got, oracle.agg_tokens(x.numpy(), "token", pos)), (shape, pos)
+    # non-contiguous token tensor (e.g. a slice of a larger hidden state)
+    if F >= 8:
+        sl = xd[:, :, : F // 2]
+        assert feq(agg.aggregate_transformer_max(sl).numpy(), oracle.agg_tokens(x[:, :, : F // 2].contiguous().numpy(), "max"))
+
+
+def test_aggregator_goldens(golden):
+    g = golden("aggregators")
+    for tag in ("x4a", "x4b", "x4c", "x4n"):
+        x = torch.from_numpy(g[tag]).to(DEV)
+        assert feq(agg.aggregate_conv_max(x).numpy(), g[f"{tag}_conv_max"])
+        np.testing.assert_allclose(agg.aggregate_conv_mean(x).numpy(), g[f"{tag}_conv_mean"], rtol=3e-6, atol=2e-7, equal_nan=True)
+    for tag in ("x3a", "x3b"):
+        x = torch.from_numpy(g[tag]).to(DEV)
+        assert feq(agg.aggregate_transformer_max(x).numpy(), g[f"{tag}_max"])
+        assert feq(agg.aggregate_transformer_absmax(x).numpy(), g[f"{tag}_absmax"])
+        assert feq(agg.get_aggregate_transformer_special_token(0)(x).numpy(), g[f"{tag}_tok0"])
+        assert feq(agg.get_aggregate_transformer_special_token(-1)(x).numpy(), g[f"{tag}_tokm1"])
+        np.testing.assert_allclose(agg.aggregate_transformer_mean(x).numpy(), g[f"{tag}_mean"], rtol=3e-6, atol=3e-7)
+        np.testing.assert_allclose(agg.aggregate_transformer_absmean(x).numpy(), g[f"{tag}_absmean"], rtol=3e-6, atol=3e-7)
+    with pytest.raises(ValueError, match="Input tensor should be 4D"):
+        agg.aggregate_conv_max(torch.randn(2, 4, 8))
+    with pytest.raises(ValueError, match="Input tensor should be 3D"):
+        agg.aggregate_transformer_mean(torch.randn(2, 10, 16, 1))
+
+
+# ------------------------------------------------------------------------------- fused hook path
+@pytest.mark.parametrize("mode", ["aten", "total"])
+def test_fused_hook_path_matches_oracle_resnet_like_shapes(mode):
+    """ActMaxCache hooks on a conv stack: K1+K3 fused path vs oracle fed with the same activations."""
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(
+        torch.nn.Conv2d(3, 32, 3, stride=2, padding=1), torch.nn.ReLU(),
+        torch.nn.Conv2d(32, 64, 3, stride=2, padding=1), torch.nn.ReLU(),
+        torch.nn.Conv2d(64, 128, 3, stride=2, padding=1), torch.nn.ReLU(),
+    ).to(DEV).eval()
+    layers = ["1", "3", "5"]
+    k = 20
+    cache = ActMaxCache(layers, agg.aggregate_conv_max, n_collect=k, tie_mode=mode)
+    grabbed = {n: [] for n in layers}
+    hooks = [model[int(n)].register_forward_hook(lambda m, i, o, n=n: grabbed[n].append(o.detach().cpu().numpy())) for n in layers]
+    g = torch.Generator().manual_seed(1)
+    sizes = [48, 48, 48, 48, 17]  # ragged last batch
+    with torch.no_grad(), cache.hook_context(model):
+        for b in sizes:
+            model(torch.randn(b, 3, 56, 56, generator=g).to(DEV))
+    for h in hooks:
+        h.remove()
+    for n in layers:
+        C = grabbed[n][0].shape[1]
+        ref = oracle.ActMaxOracle(k, C, oracle.MODE_ATEN if mode == "aten" else oracle.MODE_TOTAL)
+        start = 0
+        for a in grabbed[n]:
+            ref.update(oracle.agg_conv(a, "max"), np.arange(start, start + a.shape[0]))
+            start += a.shape[0]
+        am = cache.cache[n]
+        assert np.array_equal(bits(am.activations), ref.vals), (mode, n)
+        assert np.array_equal(am.sample_ids.numpy(), ref.ids), (mode, n)
+        assert cache.sample_idx_counter[n] == sum(sizes)
+
+
+def test_token_hook_path_matches_oracle():
+    class Blocks(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(24, 48)
+            self.b = torch.nn.Linear(48, 40)
+
+        def forward(self, x):
+            return self.b(torch.relu(self.a(x)))
+
+    torch.manual_seed(0)
+    model = Blocks().to(DEV).eval()
+    for fn, name, pos in ((agg.aggregate_transformer_max, "max", 0), (agg.get_aggregate_transformer_special_token(0), "token", 0)):
+        cache = ActMaxCache(["a", "b"], fn, n_collect=7, tie_mode="aten")
+        grabbed = {"a": [], "b": []}
+        hooks = [getattr(model, n).register_forward_hook(lambda m, i, o, n=n: grabbed[n].append(o.detach().cpu().numpy())) for n in ("a", "b")]
+        g = torch.Generator().manual_seed(2)
+        with torch.no_grad(), cache.hook_context(model):
+            for _ in range(4):
+                model(torch.randn(9, 31, 24, generator=g).to(DEV))
+        for h in hooks:
+            h.remove()
+        for n in ("a", "b"):
+            ref = oracle.ActMaxOracle(7, grabbed[n][0].shape[2], oracle.MODE_ATEN)
+            for i, a in enumerate(grabbed[n]):
+                ref.update(oracle.agg_tokens(a, name, pos), np.arange(i * 9, i * 9 + 9))
+            assert np.array_equal(bits(cache.cache[n].activations), ref.vals)
+            assert np.array_equal(cache.cache[n].sample_ids.numpy(), ref.ids)
+
+
+def test_custom_python_aggregator_goes_through_update():
+    def my_l2_aggregate(t):  # a user-defined aggregator returning a host tensor, as the reference allows
+        return t.flatten(2).norm(dim=-1).detach().cpu()
+
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3)).to(DEV).eval()
+    cache = ActMaxCache(["0"], my_l2_aggregate, n_collect=4, tie_mode="aten")
+    ref = oracle.ActMaxOracle(4, 8, oracle.MODE_ATEN)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad(), cache.hook_context(model):
+        for i in range(3):
+            x = torch.randn(5, 3, 8, 8, generator=g).to(DEV)
+            ref.update(my_l2_aggregate(model(x)).numpy(), np.arange(5 * i, 5 * i + 5))
+    am = cache.cache["0"]
+    assert np.array_equal(bits(am.activations), ref.vals)
+    assert np.array_equal(am.sample_ids.numpy(), ref.ids)
+
+
+# ---------------------------------------------------------------------------------------------- K5
+def test_gather_rows(golden):
+    g = golden("pipeline")
+    emb = torch.from_numpy(g["embeds"]).to(DEV)
+    for name in ("0", "2"):
+        out = N.gather_rows(emb, torch.from_numpy(g[f"ids_{name}"]))
+        assert np.array_equal(out.cpu().numpy(), g[f"db_{name}"])
+    rng = np.random.RandomState(0)
+    for D in (5, 512, 1152):
+        e = rng.randn(1000, D).astype(np.float32)
+        ids = rng.randint(-1000, 1000, size=(64, 20))
+        out = N.gather_rows(torch.from_numpy(e).to(DEV), torch.from_numpy(ids))
+        assert np.array_equal(out.cpu().numpy(), oracle.gather_rows(e, ids))
+    with pytest.raises(IndexError):
+        N.gather_rows(emb, torch.tensor([emb.shape[0]]))
+
+
+# ------------------------------------------------------------------------------------------ K6..K10
+def test_scores_goldens(golden):
+    g = golden("scores")
+    t = lambda a: torch.from_numpy(g[a]).to(DEV)  # noqa: E731
+    tol = dict(rtol=0, atol=1e-5)
+    np.testing.assert_allclose(scores.similarity_score(t("sim_x"), t("sim_y")).cpu().numpy(), g["sim_xyT"], **tol)
+    np.testing.assert_allclose(scores.similarity_score(t("sim_x"), t("sim_y2")).cpu().numpy(), g["sim_xy2"], **tol)
+    np.testing.assert_allclose(scores.similarity_score(t("sim_x"), t("sim_y3")).cpu().numpy(), g["sim_rowwise"], **tol)
+    np.testing.assert_allclose(scores.similarity_score(t("sim_xz"), t("sim_y")).cpu().numpy(), g["sim_xzyT"], **tol)
+    np.testing.assert_allclose(scores.similarity_score(t("sim_xl"), t("sim_yl")).cpu().numpy(), g["sim_xlylT"], **tol)
+    with pytest.raises(ValueError, match="x and y must have the same shape"):
+        scores.similarity_score(torch.zeros(3, 4, device=DEV), torch.zeros(5, 6, device=DEV))
+    np.testing.assert_allclose(scores.clarity_score(t("V")).cpu().numpy(), g["V_clarity"], **tol)
+    np.testing.assert_allclose(scores.clarity_score(t("Vz")).cpu().numpy(), g["Vz_clarity"], **tol)
+    r3 = scores.redundancy_score(t("V")[:, :15])
+    assert r3.shape == (10,)
+    np.testing.assert_allclose(r3.cpu().numpy(), g["V_redundancy3d"], **tol)
+    r2 = scores.redundancy_score(t("V").mean(1))
+    assert r2.shape == ()
+    np.testing.assert_allclose(r2.cpu().numpy(), g["cones_redundancy"], **tol)
+    # host tensors in -> host tensors out
+    assert scores.clarity_score(torch.from_numpy(g["V"])).device.type == "cpu"
+
+
+@pytest.mark.parametrize("Q,C,D", [(1, 10, 128), (130, 257, 100), (64, 768, 1152), (1000, 512, 512), (33, 70, 7)])
+def test_cosine_gemm_vs_oracle(Q, C, D):
+    rng = np.random.RandomState(Q + C + D)
+    x = rng.randn(Q, D).astype(np.float32)
+    y = (rng.randn(C, D) * rng.rand(C, 1) * 10).astype(np.float32)
+    got = scores.similarity_score(torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV)).cpu().numpy()
+    assert got.shape == (Q, C)
+    np.testing.assert_allclose(got, oracle.similarity(x, y), rtol=0, atol=1e-5)
+
+
+def test_cosine_gemm_detects_transposes():
+    """A = I-like probe with an asymmetric B: out[q][c] must be cos(x_q, y_c), not its transpose."""
+    D = 64
+    x = np.eye(40, D, dtype=np.float32)
+    y = np.zeros((50, D), np.float32)
+    for c in range(50):
+        y[c, c % D] = 1.0
+        y[c, (3 * c + 1) % D] += 2.0
+    got = scores.similarity_score(torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV)).cpu().numpy()
+    np.testing.assert_allclose(got, oracle.similarity(x, y), rtol=0, atol=1e-6)
+
+
+def test_clarity_redundancy_vs_oracle_larger():
+    rng = np.random.RandomState(9)
+    V = rng.randn(300, 20, 512).astype(np.float32)
+    np.testing.assert_allclose(scores.clarity_score(torch.from_numpy(V).to(DEV)).cpu().numpy(), oracle.clarity(V), rtol=0, atol=1e-5)
+    cones = V.mean(1)
+    np.testing.assert_allclose(
+        scores.redundancy_score(torch.from_numpy(cones).to(DEV)).cpu().numpy(), oracle.redundancy(cones), rtol=0, atol=1e-5
+    )
+
+
+def test_text_probes_golden(golden):
+    from helpers import FakeVLM
+    from semanticlens_amd.lens import _embed_text_probes
+
+    g = golden("text_probes")
+    fm = FakeVLM().to(DEV)
+    queries = [str(q) for q in g["queries"]]
+    templates = [str(t) for t in g["templates"]]
+    for nq in (1, 3):
+        for nt in (0, 1, 2):
+            for bs in (0, 2):
+                emb = _embed_text_probes(fm, queries[:nq], templates[:nt] or None, bs or None)
+                assert np.array_equal(emb.cpu().numpy(), g[f"q{nq}_t{nt}_bs{bs}"]), (nq, nt, bs)

@@ -1,0 +1,108 @@
+"""End-to-end drop-in check on the GPU: Lens.compute_concept_db / text_probing / eval_* of the build
+against outputs of the unmodified reference on the same (integer-valued, hence order-independent) model
+and data — tests/golden/pipeline.npz, produced by tests/golden/make_golden.py."""
+import numpy as np
+import pytest
+import torch
+from safetensors import safe_open
+
+from helpers import FakeVLM, TensorPairDataset, make_int_conv_model, make_int_images
+from semanticlens_amd import Lens
+from semanticlens_amd.component_visualization import ActivationComponentVisualizer, aggregators
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def bits(t):
+    return t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def _build(tmp, tie_mode):
+    model = make_int_conv_model().to(DEV)
+    ds = TensorPairDataset(make_int_images(40))
+    cv = ActivationComponentVisualizer(
+        model, ds, ds, layer_names=["0", "2"], num_samples=6, aggregate_fn=aggregators.aggregate_conv_max,
+        cache_dir=tmp, tie_mode=tie_mode,
+    )
+    fm = FakeVLM().to(DEV)
+    return cv, Lens(fm, device=DEV)
+
+
+def test_pipeline_matches_reference_bit_exact_in_aten_mode(golden, tmp_path):
+    g = golden("pipeline")
+    cv, lens = _build(str(tmp_path), "aten")
+    db = lens.compute_concept_db(cv, batch_size=16)
+    for name in ("0", "2"):
+        am = cv.actmax_cache.cache[name]
+        assert np.array_equal(bits(am.activations), g[f"vals_{name}"])
+        assert np.array_equal(am.sample_ids.numpy(), g[f"ids_{name}"])  # top-k indices bit-exact
+        assert np.array_equal(cv.get_max_reference(name).numpy(), g[f"ids_{name}"])
+        assert db[name].device.type == "cpu" and db[name].dtype == torch.float32
+        assert np.array_equal(db[name].numpy(), g[f"db_{name}"])  # concept_db tensor
+    agg_db = {k: v.mean(1) for k, v in db.items()}
+    probe = lens.text_probing(["cat", "dog"], agg_db, templates=["a photo of a {}"])
+    clar = lens.eval_clarity(db)
+    red = lens.eval_redundancy(agg_db)
+    for name in ("0", "2"):
+        np.testing.assert_allclose(probe[name].numpy(), g[f"probe_{name}"], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(clar[name].numpy(), g[f"clarity_{name}"], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(red[name].numpy(), g[f"redundancy_{name}"], rtol=0, atol=1e-5)
+    # on-disk cache layout equals the reference's: same relative paths, tensor names and metadata
+    files = sorted(str(p.relative_to(tmp_path)) for p in tmp_path.rglob("*.safetensors"))
+    assert files == [str(f) for f in g["cache_files"]]
+    for f, want in zip(files, g["cache_meta"]):
+        with safe_open(str(tmp_path / f), framework="pt") as fh:
+            got = repr(sorted((fh.metadata() or {}).items())) + "|" + repr(sorted(fh.keys()))
+        assert got == str(want)
+    # second visualizer + lens: everything is served from the caches the first run wrote
+    cv2, lens2 = _build(str(tmp_path), "aten")
+    db2 = lens2.compute_concept_db(cv2, batch_size=16)
+    assert np.array_equal(db2["2"].numpy(), g["db_2"])
+    assert np.array_equal(cv2.get_max_reference("0").numpy(), g["ids_0"])
+
+
+def test_pipeline_total_mode_same_values_valid_ids(golden, tmp_path):
+    g = golden("pipeline")
+    cv, lens = _build(None, "total")
+    db = lens.compute_concept_db(cv, batch_size=16, keep_on_device=True)
+    images = torch.from_numpy(g["images"])
+    model = make_int_conv_model()
+    with torch.no_grad():
+        a0 = model[0](images)
+        acts = {"0": a0.flatten(2).amax(-1), "2": model[2](model[1](a0)).flatten(2).amax(-1)}
+    for name in ("0", "2"):
+        am = cv.actmax_cache.cache[name]
+        v = am.activations.float().numpy()
+        assert np.array_equal(v, torch.from_numpy(g[f"vals_{name}"].view(np.int16)).view(torch.bfloat16).float().numpy())
+        ids = am.sample_ids.numpy()
+        for c in range(ids.shape[0]):
+            real = ids[c] >= 0
+            assert len(set(ids[c][real])) == real.sum()
+            own = acts[name][ids[c][real], c].to(torch.bfloat16).float().numpy()
+            assert np.array_equal(own, v[c][real])
+        assert db[name].is_cuda
+        assert np.array_equal(db[name].cpu().numpy(), g["embeds"][ids])
+
+
+def test_batch_size_one_and_dataset_smaller_than_k(tmp_path):
+    model = make_int_conv_model().to(DEV)
+    ds = TensorPairDataset(make_int_images(5))
+    cv = ActivationComponentVisualizer(model, ds, ds, ["2"], num_samples=9, aggregate_fn=aggregators.aggregate_conv_max, tie_mode="aten")
+    db = Lens(FakeVLM().to(DEV)).compute_concept_db(cv, batch_size=1)
+    ids = cv.get_max_reference("2")
+    assert ids.shape == (16, 9) and (ids == -1).any()
+    emb = FakeVLM().encode_image(torch.stack([ds[i][0] for i in range(5)])).numpy()
+    assert np.array_equal(db["2"].numpy(), emb[ids.numpy()])  # -1 wraps to the LAST embedding (finding 2)
+
+
+def test_zero_samples_and_empty_layers(tmp_path):
+    # reference tests/component_visualization/test_activation_based.py:126-161
+    model = make_int_conv_model().to(DEV)
+    ds = TensorPairDataset(make_int_images(4))
+    cv = ActivationComponentVisualizer(model, ds, ds, [], num_samples=10)
+    assert cv.run() == {}
+    cv0 = ActivationComponentVisualizer(model, ds, ds, ["0"], num_samples=0, cache_dir=str(tmp_path))
+    cv0.run(batch_size=2)
+    am = cv0.actmax_cache.cache["0"]
+    assert am.n_collect == 0 and am.sample_ids.shape[1] == 0 and am.activations.shape[1] == 0

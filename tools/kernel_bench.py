@@ -1,0 +1,118 @@
+"""Kernel-only micro-benchmarks (SURVEY.md §8d micro-inputs): HBM GB/s of the reduce kernels at the
+BASELINE config shapes, merge-kernel latency, TFLOP/s of the cosine GEMM.  GPU only."""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from semanticlens_amd import _native as N  # noqa: E402
+from semanticlens_amd.component_visualization.activation_caching import ActMax  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def timed(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def bench_reduce(B, C, H, W, agg=N.SL_CONV_MAX, channels_last=False, flush_mb=512):
+    x = torch.randn(B, C, H, W, device=DEV).relu_()
+    if channels_last:
+        x = x.contiguous(memory_format=torch.channels_last)
+    cand = torch.empty((B, C), dtype=torch.bfloat16, device=DEV)
+    # rotate over several copies so the input does not sit in the 256 MiB Infinity Cache
+    nbytes = x.numel() * 4
+    ncopy = max(1, min(8, int(flush_mb * 2**20 // nbytes) + 1))
+    xs = [x] + [x.clone() for _ in range(ncopy - 1)]
+    i = [0]
+
+    def run():
+        N.reduce_conv(xs[i[0] % ncopy], agg, cand, None)
+        i[0] += 1
+
+    ms = timed(run, iters=4 * ncopy)
+    return {"shape": [B, C, H, W], "cl": channels_last, "agg": agg, "ms": ms, "GBps": nbytes / ms / 1e6, "copies": ncopy}
+
+
+def bench_tokens(B, T, F, agg=N.SL_TOK_MAX):
+    x = torch.randn(B, T, F, device=DEV)
+    cand = torch.empty((B, F), dtype=torch.bfloat16, device=DEV)
+    nbytes = x.numel() * 4
+    ncopy = max(1, min(8, int(512 * 2**20 // nbytes) + 1))
+    xs = [x] + [x.clone() for _ in range(ncopy - 1)]
+    i = [0]
+
+    def run():
+        N.reduce_tokens(xs[i[0] % ncopy], agg, 0, cand, None)
+        i[0] += 1
+
+    ms = timed(run, iters=4 * ncopy)
+    return {"shape": [B, T, F], "agg": agg, "ms": ms, "GBps": nbytes / ms / 1e6}
+
+
+def bench_merge(C, k, B, mode, steady=True):
+    am = ActMax(k, C, tie_mode=mode)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    # warm the state with 50 batches so the steady-state filter rate applies
+    for s in range(50 if steady else 0):
+        am.update(torch.randn(B, C, device=DEV, generator=g).relu_(), torch.arange(s * B, (s + 1) * B))
+    acts = torch.randn(B, C, device=DEV, generator=g).relu_()
+    ids = torch.arange(10**6, 10**6 + B, device=DEV)
+    ms = timed(lambda: am.update(acts, ids), iters=20)
+    return {"C": C, "k": k, "B": B, "mode": mode, "steady": steady, "ms_update_incl_cast": ms}
+
+
+def bench_gemm(Q, C, D):
+    x = torch.randn(Q, D, device=DEV)
+    y = torch.randn(C, D, device=DEV)
+    ms = timed(lambda: N.similarity(x, y), iters=10)
+    return {"Q": Q, "C": C, "D": D, "ms": ms, "TFLOPs": 2.0 * Q * C * D / ms / 1e9, "Msim_per_s": Q * C / ms / 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    out = []
+    shapes = [(256, 512, 28, 28), (256, 1024, 14, 14), (256, 2048, 7, 7), (64, 512, 28, 28), (64, 1024, 14, 14), (64, 2048, 7, 7)]
+    if not args.quick:
+        shapes += [(256, 192, 56, 56), (256, 1536, 7, 7), (32, 2048, 7, 7), (1024, 2048, 7, 7)]
+    for s in shapes:
+        out.append(("reduce_max", bench_reduce(*s)))
+        print(json.dumps(out[-1]), flush=True)
+    out.append(("reduce_mean", bench_reduce(256, 2048, 7, 7, agg=N.SL_CONV_MEAN)))
+    print(json.dumps(out[-1]), flush=True)
+    out.append(("reduce_max_cl", bench_reduce(256, 2048, 7, 7, channels_last=True)))
+    print(json.dumps(out[-1]), flush=True)
+    out.append(("reduce_max_cl", bench_reduce(256, 512, 28, 28, channels_last=True)))
+    print(json.dumps(out[-1]), flush=True)
+    out.append(("tokens_max", bench_tokens(256, 197, 768)))
+    print(json.dumps(out[-1]), flush=True)
+    for mode in ("total", "aten"):
+        for C, k, B in ((2048, 20, 256), (512, 20, 256), (2048, 100, 256), (2048, 20, 64)):
+            out.append(("merge", bench_merge(C, k, B, mode)))
+            print(json.dumps(out[-1]), flush=True)
+    out.append(("merge_cold", bench_merge(2048, 20, 256, "total", steady=False)))
+    print(json.dumps(out[-1]), flush=True)
+    for q, c, d in ((10000, 768, 1152), (10000, 9216, 1152), (4096, 4096, 512)):
+        out.append(("gemm", bench_gemm(q, c, d)))
+        print(json.dumps(out[-1]), flush=True)
+
+
+if __name__ == "__main__":
+    t0 = time.time()
+    main()
+    print(f"done in {time.time() - t0:.1f}s")
