@@ -117,6 +117,13 @@ int sl_actmax_merge_states(uint16_t* d_vals, int64_t* d_ids, int64_t C, int64_t 
 int sl_gather_rows(const float* d_emb, int64_t N, int64_t D, const int64_t* d_ids, int64_t n_ids, float* d_out,
                    int32_t* d_err_flag, void* stream);
 
+/* Sharded form (multi-GPU): d_emb_local holds rows [row_offset, row_offset +
+ * n_local) of a table of n_total rows.  Ids index the whole table (negative ids wrap by n_total);
+ * rows held elsewhere are written as ZEROS, so a sum (all-reduce) over the shards equals
+ * sl_gather_rows on the whole table. */
+int sl_gather_rows_shard(const float* d_emb_local, int64_t n_local, int64_t D, const int64_t* d_ids, int64_t n_ids,
+                         int64_t row_offset, int64_t n_total, float* d_out, int32_t* d_err_flag, void* stream);
+
 /* ---- K6: similarity_score (scores.py:84-128) ---------------------------------------------
  * Returns the branch taken: 0 row-wise cosine (shapes equal; out (xr,)), 1 normalize(x) @
  * normalize(y) (xc == yr; out (xr,yc)), 2 normalize(x) @ normalize(y)^T (xc == yc; out

@@ -45,6 +45,7 @@ SIGNATURES = {
     "sl_actmax_aten_ws_bytes": (_sz, [_i64, _i64, _i64]),
     "sl_actmax_merge_states": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),
     "sl_gather_rows": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "sl_gather_rows_shard": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "sl_similarity": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "sl_similarity_ws_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "sl_clarity": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
@@ -220,6 +221,25 @@ def gather_rows(emb: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     _check(rc, "sl_gather_rows")
     if int(flag.item()) != 0:
         raise IndexError(f"index out of range in embeds[sample_ids] (dataset size {N})")
+    return out
+
+
+def gather_rows_shard(emb_local: torch.Tensor, ids: torch.Tensor, row_offset: int, n_total: int) -> torch.Tensor:
+    """Sharded ``emb[ids]``: rows this shard does not hold come back as zeros (sum over shards = full gather)."""
+    assert emb_local.is_cuda and emb_local.dtype == torch.float32 and emb_local.ndim == 2
+    emb_local = emb_local.contiguous()
+    ids_d = to_device(ids, emb_local.device).to(torch.int64).contiguous()
+    n_local, D = emb_local.shape
+    out = torch.empty(tuple(ids_d.shape) + (D,), dtype=torch.float32, device=emb_local.device)
+    flag = torch.zeros(1, dtype=torch.int32, device=emb_local.device)
+    with torch.cuda.device(emb_local.device):
+        rc = lib().sl_gather_rows_shard(
+            _ptr(emb_local), n_local, D, _ptr(ids_d), ids_d.numel(), row_offset, n_total, _ptr(out), _ptr(flag),
+            _stream(emb_local),
+        )
+    _check(rc, "sl_gather_rows_shard")
+    if int(flag.item()) != 0:
+        raise IndexError(f"index out of range in embeds[sample_ids] (dataset size {n_total})")
     return out
 
 

@@ -163,15 +163,19 @@ class ActivationComponentVisualizer(AbstractComponentVisualizer):
             for name in self.layer_names:
                 self.actmax_cache.sample_idx_counter[name] = start
         dataloader = torch.utils.data.DataLoader(dataset, batch_size=batch_size, shuffle=False, num_workers=num_workers)
-        device = self.device
         with self.actmax_cache.hook_context(self.model):
             for images, _ in tqdm(dataloader, total=len(dataloader), desc="Collecting ActMax"):
-                self.model(images.to(device, non_blocking=True))
+                self.collect_batch(images)
 
         if self._cache_root and sample_range is None:
             self.actmax_cache.store(self.storage_dir)
             logger.debug(f"Stored activation maximization cache at {self.storage_dir}")
         return self.actmax_cache.cache
+
+    def collect_batch(self, images: torch.Tensor):
+        """One step of hot loop 1: forward ``images`` (host or device resident) under the active hooks.
+        Must be called inside ``self.actmax_cache.hook_context(self.model)``; never synchronises."""
+        self.model(images.to(self.device, non_blocking=True))
 
     # ---- hot loop 2 + gather (activation_based.py:360-451) ---------------------------------------
     @torch.no_grad()
@@ -206,17 +210,23 @@ class ActivationComponentVisualizer(AbstractComponentVisualizer):
         filled = 0
         with tqdm(total=len(self.dataset), desc="Embedding Dataset") as pbar:
             for pil_list in loader:
-                out = fm.encode_image(fm.preprocess(pil_list))
-                out = N.to_device(out.detach()).to(torch.float32)
-                if embeds is None:
-                    embeds = torch.empty((n_total, out.shape[1]), dtype=torch.float32, device=out.device)
-                embeds[filled : filled + out.shape[0]] = out
-                filled += out.shape[0]
+                embeds, filled = self.embed_batch(fm, pil_list, embeds, filled, n_total)
                 pbar.update(batch_size)
         if embeds is None:
             raise RuntimeError("dataset_fm is empty: nothing to embed")
         assert filled == n_total, "Number of embeddings does not match number of ids!"
         return embeds
+
+    @staticmethod
+    def embed_batch(fm, items, embeds, filled: int, n_total: int):
+        """One step of hot loop 2: ``fm.encode_image(fm.preprocess(items))`` written into rows
+        ``[filled, filled + B)`` of the device-resident ``(n_total, D)`` table (allocated on first use)."""
+        out = fm.encode_image(fm.preprocess(items))
+        out = N.to_device(out.detach()).to(torch.float32)
+        if embeds is None:
+            embeds = torch.empty((n_total, out.shape[1]), dtype=torch.float32, device=out.device)
+        embeds[filled : filled + out.shape[0]] = out
+        return embeds, filled + out.shape[0]
 
     def get_max_reference(self, layer_name) -> torch.Tensor:
         """``(n_components, n_samples)`` int64 dataset indices (``-1`` = slot never filled)."""

@@ -17,6 +17,8 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
+from semanticlens_amd import _native as N
+
 
 def shard_range(n_samples: int, rank: int, world_size: int) -> tuple[int, int]:
     """Contiguous ``[start, stop)`` of rank ``rank``: blocks of ``ceil(N / R)`` samples."""
@@ -29,7 +31,13 @@ def pack_states(states: list[tuple[torch.Tensor, torch.Tensor]]) -> torch.Tensor
     """[(vals (C,k) bf16, ids (C,k) int64), ...] -> one flat uint8 tensor (ids first: 8-byte aligned)."""
     parts = [ids.contiguous().view(torch.uint8).reshape(-1) for _, ids in states]
     parts += [vals.contiguous().view(torch.uint8).reshape(-1) for vals, _ in states]
-    return torch.cat(parts) if parts else torch.empty(0, dtype=torch.uint8)
+    if not parts:
+        return torch.empty(0, dtype=torch.uint8)
+    n = sum(p.numel() for p in parts)
+    pad = (-n) % 16  # keep every rank's slice of the gathered buffer 16-byte aligned
+    if pad:
+        parts.append(torch.zeros(pad, dtype=torch.uint8, device=parts[0].device))
+    return torch.cat(parts)
 
 
 def unpack_states(buf: torch.Tensor, shapes: list[tuple[int, int]]):
@@ -88,3 +96,40 @@ def run_sharded(cv, batch_size: int = 64, num_workers: int = 0, group=None):
     cv._run(batch_size=batch_size, num_workers=num_workers, sample_range=shard_range(len(cv.dataset), rank, world))
     merge_actmax_cache(cv.actmax_cache, group)
     return cv.actmax_cache.cache
+
+
+def gather_concept_db_sharded(embeds_local: torch.Tensor, shard_start: int, n_total: int, ids: torch.Tensor, group=None):
+    """``embeds[ids]`` when rank r only holds ``embeds[shard_range(r)]``: each rank gathers the rows it
+    owns (zeros elsewhere, K5 sharded form) and one all-reduce sums the disjoint pieces.  Exchanges
+    ``C*k*D*4`` bytes per layer instead of the whole ``(N, D)`` table."""
+    part = N.gather_rows_shard(embeds_local, ids, shard_start, n_total)
+    dist.all_reduce(part, group=group)
+    return part
+
+
+@torch.no_grad()
+def compute_concept_db_sharded(cv, fm, batch_size: int = 64, num_workers: int = 0, group=None):
+    """Multi-GPU ``cv._compute_concept_db(fm)``: every rank returns the same ``{layer: (C, k, D)}`` (device tensors)."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    n_total = len(cv.dataset)
+    start, stop = shard_range(n_total, rank, world)
+    run_sharded(cv, batch_size=batch_size, num_workers=num_workers, group=group)
+    fm.to(cv.device)
+    loader = torch.utils.data.DataLoader(
+        torch.utils.data.Subset(cv.dataset_fm, range(start, stop)), batch_size=batch_size, shuffle=False,
+        collate_fn=lambda b: [i[0] if isinstance(i, (tuple, list)) else i for i in b], num_workers=num_workers,
+    )
+    embeds, filled = None, 0
+    for items in loader:
+        embeds, filled = cv.embed_batch(fm, items, embeds, filled, stop - start)
+    if embeds is None:  # empty shard: still take part in the collectives
+        dim = torch.zeros(1, dtype=torch.int64, device=cv.device)
+    else:
+        dim = torch.tensor([embeds.shape[1]], dtype=torch.int64, device=embeds.device)
+    dist.all_reduce(dim, op=dist.ReduceOp.MAX, group=group)
+    if embeds is None:
+        embeds = torch.empty((0, int(dim.item())), dtype=torch.float32, device=cv.device)
+    return {
+        name: gather_concept_db_sharded(embeds, start, n_total, cv.get_max_reference(name), group)
+        for name in cv.layer_names
+    }

@@ -1,0 +1,289 @@
+"""Synthetic workloads for bench.py / tests: the BASELINE.json configurations with random-init
+models and counter-based synthetic images (there is no network for datasets or checkpoints).
+
+Not part of the product package: plain-torch definitions of the probed models (ResNet-18/50,
+torchvision module names so the reference's layer names ``layer2/3/4`` apply), a CLIP-shaped
+foundation model behind ``AbstractVLM`` (ViT-B/32 image tower, 12x512 text tower, 512-d joint
+space — the OpenCLIP ViT-B/32 architecture with random weights), and a dataset whose sample
+``i`` is a pure function of ``(seed, i)`` so any shard reproduces any sample.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+from semanticlens_amd.foundation_models.base import AbstractVLM
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+# ------------------------------------------------------------------------------------------------
+# counter-based synthetic images
+# ------------------------------------------------------------------------------------------------
+def _mix(x: torch.Tensor) -> torch.Tensor:
+    """32-bit integer hash (murmur3 finaliser) on int64 tensors holding values < 2**32."""
+    m = 0xFFFFFFFF
+    x = x & m
+    x = ((x ^ (x >> 16)) * 0x85EBCA6B) & m
+    x = ((x ^ (x >> 13)) * 0xC2B2AE35) & m
+    return (x ^ (x >> 16)) & m
+
+
+def synth_images_u8(indices: torch.Tensor, size: int = 224, seed: int = 0) -> torch.Tensor:
+    """uint8 images (n, 3, size, size) for dataset indices ``indices`` (any device), a pure function
+    of (seed, index): hashed pixel noise modulated by a per-image low-frequency pattern and gain."""
+    dev = indices.device
+    idx = indices.to(torch.int64).reshape(-1, 1, 1, 1)
+    c = torch.arange(3, device=dev, dtype=torch.int64).reshape(1, 3, 1, 1)
+    y = torch.arange(size, device=dev, dtype=torch.int64).reshape(1, 1, size, 1)
+    x = torch.arange(size, device=dev, dtype=torch.int64).reshape(1, 1, 1, size)
+    key = _mix(idx * 0x9E3779B1 + seed * 0x7F4A7C15 + 1)
+    noise = _mix(key + ((c * size + y) * size + x) * 0x27D4EB2F) & 0xFF
+    # per-image parameters from the key
+    gain = 0.25 + 3.75 * ((_mix(key + 11) & 0xFFFF).to(torch.float32) / 65535.0)
+    fx = 1 + (_mix(key + 23) & 7).to(torch.float32)
+    fy = 1 + (_mix(key + 37) & 7).to(torch.float32)
+    ph = (_mix(key + 41) & 0xFFFF).to(torch.float32) / 65535.0 * (2 * math.pi)
+    wave = 0.5 + 0.5 * torch.sin(2 * math.pi * (fx * x.to(torch.float32) + fy * y.to(torch.float32)) / size + ph + c.to(torch.float32))
+    img = noise.to(torch.float32) * (0.35 + 0.65 * wave) * gain / 2.0
+    return img.clamp_(0, 255).to(torch.uint8)
+
+
+def normalize_u8(u8: torch.Tensor, mean, std) -> torch.Tensor:
+    m = torch.tensor(mean, device=u8.device, dtype=torch.float32).reshape(1, 3, 1, 1)
+    s = torch.tensor(std, device=u8.device, dtype=torch.float32).reshape(1, 3, 1, 1)
+    return (u8.to(torch.float32) / 255.0 - m) / s
+
+
+class SyntheticImageDataset(torch.utils.data.Dataset):
+    """``mode='model'`` yields ``(normalised fp32 tensor, 0)`` like the reference's ``dataset_model``;
+    ``mode='fm'`` yields the raw uint8 image for the foundation model's own preprocessing."""
+
+    def __init__(self, n: int, mode: str = "model", size: int = 224, seed: int = 0):
+        self.n, self.mode, self.size, self.seed = n, mode, size, seed
+        self.name = f"synthetic-{n}-s{seed}"
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        u8 = synth_images_u8(torch.tensor([i]), self.size, self.seed)[0]
+        if self.mode == "model":
+            return normalize_u8(u8[None], IMAGENET_MEAN, IMAGENET_STD)[0], 0
+        return u8
+
+
+# ------------------------------------------------------------------------------------------------
+# probed models: ResNet-18 / ResNet-50 (He et al.), torchvision naming
+# ------------------------------------------------------------------------------------------------
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, cin, planes, stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if stride != 1 or cin != planes:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + idt)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, cin, planes, stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if stride != 1 or cin != planes * 4:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, planes * 4, 1, stride, bias=False), nn.BatchNorm2d(planes * 4))
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + idt)
+
+
+class ResNet(nn.Module):
+    def __init__(self, block, layers, num_classes=1000):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.layer1 = self._make(block, 64, layers[0], 1)
+        self.layer2 = self._make(block, 128, layers[1], 2)
+        self.layer3 = self._make(block, 256, layers[2], 2)
+        self.layer4 = self._make(block, 512, layers[3], 2)
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Linear(512 * block.expansion, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def _make(self, block, planes, n, stride):
+        blocks = [block(self.inplanes, planes, stride)]
+        self.inplanes = planes * block.expansion
+        blocks += [block(self.inplanes, planes) for _ in range(1, n)]
+        return nn.Sequential(*blocks)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return self.fc(torch.flatten(self.avgpool(x), 1))
+
+
+def resnet18(seed: int = 0) -> nn.Module:
+    torch.manual_seed(seed)
+    m = ResNet(BasicBlock, [2, 2, 2, 2]).eval()
+    m.name = "resnet18-random"
+    return m
+
+
+def resnet50(seed: int = 0) -> nn.Module:
+    torch.manual_seed(seed)
+    m = ResNet(Bottleneck, [3, 4, 6, 3]).eval()
+    m.name = "resnet50-random"
+    return m
+
+
+# ------------------------------------------------------------------------------------------------
+# CLIP-shaped foundation model (ViT-B/32 architecture, random init)
+# ------------------------------------------------------------------------------------------------
+class _Block(nn.Module):
+    def __init__(self, width, heads):
+        super().__init__()
+        self.ln_1 = nn.LayerNorm(width)
+        self.attn = nn.MultiheadAttention(width, heads, batch_first=True)
+        self.ln_2 = nn.LayerNorm(width)
+        self.mlp = nn.Sequential(nn.Linear(width, width * 4), nn.GELU(), nn.Linear(width * 4, width))
+
+    def forward(self, x, mask=None):
+        h = self.ln_1(x)
+        x = x + self.attn(h, h, h, need_weights=False, attn_mask=mask)[0]
+        return x + self.mlp(self.ln_2(x))
+
+
+class _Tower(nn.Module):
+    def __init__(self, width, layers, heads):
+        super().__init__()
+        self.blocks = nn.ModuleList([_Block(width, heads) for _ in range(layers)])
+
+    def forward(self, x, mask=None):
+        for b in self.blocks:
+            x = b(x, mask)
+        return x
+
+
+class _ClipModel(nn.Module):
+    def __init__(self, embed_dim=512, image_size=224, patch=32, v_width=768, v_layers=12, v_heads=12, ctx=77,
+                 vocab=49408, t_width=512, t_layers=12, t_heads=8):
+        super().__init__()
+        self.context_length = ctx
+        self.conv1 = nn.Conv2d(3, v_width, patch, patch, bias=False)
+        n_tok = (image_size // patch) ** 2 + 1
+        self.class_embedding = nn.Parameter(v_width**-0.5 * torch.randn(v_width))
+        self.positional_embedding_v = nn.Parameter(v_width**-0.5 * torch.randn(n_tok, v_width))
+        self.ln_pre = nn.LayerNorm(v_width)
+        self.visual = _Tower(v_width, v_layers, v_heads)
+        self.ln_post = nn.LayerNorm(v_width)
+        self.proj_v = nn.Parameter(v_width**-0.5 * torch.randn(v_width, embed_dim))
+        self.token_embedding = nn.Embedding(vocab, t_width)
+        self.positional_embedding_t = nn.Parameter(0.01 * torch.randn(ctx, t_width))
+        self.text = _Tower(t_width, t_layers, t_heads)
+        self.ln_final = nn.LayerNorm(t_width)
+        self.proj_t = nn.Parameter(t_width**-0.5 * torch.randn(t_width, embed_dim))
+        self.register_buffer("causal", torch.full((ctx, ctx), float("-inf")).triu_(1), persistent=False)
+
+    def encode_image(self, img):
+        x = self.conv1(img).flatten(2).transpose(1, 2)
+        cls = self.class_embedding.to(x.dtype).expand(x.shape[0], 1, -1)
+        x = self.ln_pre(torch.cat([cls, x], 1) + self.positional_embedding_v)
+        x = self.visual(x)
+        return self.ln_post(x[:, 0]) @ self.proj_v
+
+    def encode_text(self, tokens):
+        x = self.token_embedding(tokens) + self.positional_embedding_t[: tokens.shape[1]]
+        x = self.ln_final(self.text(x, self.causal[: tokens.shape[1], : tokens.shape[1]]))
+        eot = tokens.argmax(dim=-1)  # end-of-text carries the highest id, as in CLIP's tokenizer
+        return x[torch.arange(x.shape[0], device=x.device), eot] @ self.proj_t
+
+
+class SyntheticClip(AbstractVLM):
+    """Random-init CLIP ViT-B/32 behind the ``AbstractVLM`` seam (what ``OpenClip('ViT-B-32')`` would be
+    without weights).  ``preprocess`` accepts uint8 tensors (or PIL images) and normalises on the device;
+    ``tokenize`` is a deterministic word-hash tokenizer (the BPE vocabulary is not available offline)."""
+
+    def __init__(self, device="cpu", seed: int = 1, embed_dim: int = 512, **arch):
+        torch.manual_seed(seed)
+        self.model = _ClipModel(embed_dim=embed_dim, **arch).eval().to(device)
+        self.name = f"synthetic-clip-vitb32-d{embed_dim}"
+
+    @property
+    def device(self):
+        return next(self.model.parameters()).device
+
+    def to(self, device):
+        return self.model.to(device)
+
+    @torch.no_grad()
+    def encode_image(self, img):
+        return self.model.encode_image(img)
+
+    @torch.no_grad()
+    def encode_text(self, tokens):
+        return self.model.encode_text(tokens)
+
+    def preprocess(self, img):
+        import numpy as np
+
+        def one(i):
+            if isinstance(i, torch.Tensor):
+                return i
+            return torch.from_numpy(np.asarray(i.convert("RGB"))).permute(2, 0, 1)
+
+        batch = torch.stack([one(i) for i in img]) if isinstance(img, (list, tuple)) else one(img)
+        if batch.ndim == 3:
+            batch = batch.unsqueeze(0)
+        return normalize_u8(batch.to(self.device), CLIP_MEAN, CLIP_STD)
+
+    def tokenize(self, txt, context_length=None):
+        ctx = context_length or self.model.context_length
+        if isinstance(txt, str):
+            txt = [txt]
+        out = torch.zeros(len(txt), ctx, dtype=torch.int64)
+        for r, s in enumerate(txt):
+            words = s.lower().split()[: ctx - 2]
+            ids = [49406] + [1 + (hash_str(w) % 49000) for w in words] + [49407]
+            out[r, : len(ids)] = torch.tensor(ids)
+        return out.to(self.device)
+
+
+def hash_str(s: str) -> int:
+    h = 2166136261
+    for ch in s.encode():
+        h = ((h ^ ch) * 16777619) & 0xFFFFFFFF
+    return h

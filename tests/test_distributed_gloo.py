@@ -1,0 +1,78 @@
+"""world_size-2 gloo test (CPU) of the sharded-collect plumbing in semanticlens_amd/distributed.py:
+shard ranges, state packing, the single fused all-gather, which ranks get merged.  The K4 merge kernel itself
+needs a GPU (tests/test_gpu_parity.py::test_total_mode_is_batch_invariant_and_shard_mergeable); here the
+per-rank states come from the oracle and ActMax's two device touch-points are replaced by host stand-ins
+that use the oracle as the merge — checker code standing in for the kernel, in a test only."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, acts, k, out_dir):
+    import oracle
+    from semanticlens_amd import distributed as sld
+    from semanticlens_amd.component_visualization import aggregators
+    from semanticlens_amd.component_visualization.activation_caching import ActMax, ActMaxCache
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        N_, C = acts["a"].shape
+        cache = ActMaxCache(["a", "b"], aggregators.aggregate_conv_max, k, tie_mode="total")
+        start, stop = sld.shard_range(N_, rank, world)
+        for name in ("a", "b"):
+            o = oracle.ActMaxOracle(k, acts[name].shape[1], oracle.MODE_TOTAL)
+            for s in range(start, stop, 16):
+                e = min(stop, s + 16)
+                o.update(acts[name][s:e], np.arange(s, e))
+            am = ActMax(k, acts[name].shape[1], tie_mode="total")
+            am.activations = torch.from_numpy(o.vals.view(np.int16)).view(torch.bfloat16)
+            am.sample_ids = torch.from_numpy(o.ids)
+            cache.cache[name] = am
+
+        def host_state(self, device=None):
+            return self.activations, self.sample_ids
+
+        def host_merge(self, other_vals, other_ids):
+            o = oracle.ActMaxOracle(self.n_collect, self.n_latents, oracle.MODE_TOTAL)
+            o.vals[:] = self.activations.view(torch.int16).numpy().view(np.uint16)
+            o.ids[:] = self.sample_ids.numpy()
+            o.merge_states(other_vals.contiguous().view(torch.int16).numpy().view(np.uint16), other_ids.numpy())
+            self.activations = torch.from_numpy(o.vals.view(np.int16)).view(torch.bfloat16)
+            self.sample_ids = torch.from_numpy(o.ids)
+
+        ActMax.device_state = host_state
+        ActMax.merge_states = host_merge
+        sld.merge_actmax_cache(cache)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"),
+                 **{f"v_{n}": cache.cache[n].activations.view(torch.int16).numpy() for n in ("a", "b")},
+                 **{f"i_{n}": cache.cache[n].sample_ids.numpy() for n in ("a", "b")})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_merge_two_ranks_gloo(tmp_path):
+    import oracle
+
+    rng = np.random.RandomState(0)
+    acts = {"a": (rng.randint(0, 40, size=(150, 12)) / 8.0).astype(np.float32),  # tie-heavy
+            "b": np.maximum(rng.randn(150, 5), 0).astype(np.float32)}
+    k = 9
+    mp.spawn(_worker, args=(2, _free_port(), acts, k, str(tmp_path)), nprocs=2, join=True)
+    for name in ("a", "b"):
+        ref = oracle.ActMaxOracle(k, acts[name].shape[1], oracle.MODE_TOTAL)
+        ref.update(acts[name], np.arange(150))
+        for r in (0, 1):
+            got = np.load(tmp_path / f"rank{r}.npz")
+            assert np.array_equal(got[f"v_{name}"].view(np.uint16), ref.vals), (name, r)
+            assert np.array_equal(got[f"i_{name}"], ref.ids), (name, r)

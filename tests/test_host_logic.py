@@ -1,0 +1,339 @@
+"""CPU-only tests (-m "not gpu"): C-ABI surface, host logic mirrored from the reference's own unit tests
+(reference tests/… cited per test), cache formats, loud failure without a HIP device."""
+import re
+import subprocess
+import sys
+from pathlib import Path
+from unittest import mock
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+from torch.utils.data import TensorDataset
+
+from semanticlens_amd import Lens
+from semanticlens_amd import _native as N
+from semanticlens_amd.component_visualization import ActivationComponentVisualizer
+from semanticlens_amd.component_visualization import aggregators as agg
+from semanticlens_amd.component_visualization.activation_based import MissingNameWarning
+from semanticlens_amd.component_visualization.activation_caching import ActMax, ActMaxCache
+from semanticlens_amd.utils import get_fallback_name
+
+ROOT = Path(__file__).resolve().parent.parent
+NO_GPU = not torch.cuda.is_available()
+
+
+# ------------------------------------------------------------------------------------------ C ABI
+def test_library_loads_and_exports_every_declared_symbol():
+    header = (ROOT / "include" / "semanticlens_amd.h").read_text()
+    declared = set(re.findall(r"\b(sl_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 20
+    handle = N.lib()  # resolves every name in N.SIGNATURES or raises AttributeError
+    assert declared == set(N.SIGNATURES), declared ^ set(N.SIGNATURES)
+    nm = subprocess.run(["nm", "-D", str(N.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (sl_[a-z0-9_]+)", nm))
+    assert declared <= exported, declared - exported
+    assert handle.sl_abi_version() == 1
+    assert "gfx950" in subprocess.run(["strings", str(N.LIB_PATH)], capture_output=True, text=True).stdout
+
+
+def test_argument_errors_are_reported_without_a_device():
+    lib = N.lib()
+    assert lib.sl_actmax_merge(None, None, 4, 5, None, 0, None, None, 1, None) == -1
+    assert lib.sl_last_error() == b"sl_actmax_merge: null state"
+    assert lib.sl_actmax_merge(1, 1, 4, 5000, None, 0, None, None, 1, None) == -1  # validated before any launch
+    assert b"exceeds the supported maximum" in lib.sl_last_error()
+    assert lib.sl_similarity(None, 3, 4, None, 5, 6, None, None, 0, None) == -1
+    assert lib.sl_last_error() == b"x and y must have the same shape"  # the reference's ValueError text
+    assert lib.sl_reduce_conv(None, 7, 1, 1, 1, 1, 1, 1, 0, None, None, None) == -1
+
+
+@pytest.mark.skipif(not NO_GPU, reason="checks the no-device behaviour")
+def test_no_cpu_fallback_compute_raises_without_device():
+    from semanticlens_amd import scores
+
+    with pytest.raises(N.NativeLibraryError, match="no CPU fallback"):
+        scores.similarity_score(torch.randn(3, 4), torch.randn(5, 4))
+    with pytest.raises(N.NativeLibraryError):
+        agg.aggregate_conv_max(torch.randn(2, 3, 4, 4))
+    am = ActMax(n_collect=2, n_latents=3)
+    with pytest.raises(N.NativeLibraryError):
+        am.update(torch.randn(4, 3), torch.arange(4))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(N, "_lib", None)
+    monkeypatch.setenv("SEMANTICLENS_AMD_LIB", str(tmp_path / "nope.so"))
+    with pytest.raises(N.NativeLibraryError, match="no CPU fallback"):
+        N.lib()
+
+
+# ------------------------------------------------------------------------------------- aggregators
+def test_aggregator_names_and_argument_checks():
+    # names are part of the cache file names (reference aggregators.py:27,32)
+    for name in ("aggregate_conv_mean", "aggregate_conv_max", "aggregate_transformer_mean", "aggregate_transformer_absmean",
+                 "aggregate_transformer_max", "aggregate_transformer_absmax"):
+        assert getattr(agg, name).__name__ == name
+    assert agg.get_aggregate_transformer_special_token(0).__name__ == "aggregate_transformer_special_token"
+    # reference tests/component_visualization/test_aggregators.py:28-31, 51-54
+    with pytest.raises(ValueError, match="Input tensor should be 4D"):
+        agg.aggregate_conv_mean(torch.randn(2, 4, 8))
+    with pytest.raises(ValueError, match="Input tensor should be 3D"):
+        agg.aggregate_transformer_max(torch.randn(2, 10, 16, 1))
+    with pytest.raises(AttributeError):  # tuple outputs fail on `.ndim`, as in the reference
+        agg.aggregate_conv_max((torch.randn(2, 3, 4, 4),))
+
+
+# ------------------------------------------------------------------------------------------ ActMax
+def test_actmax_initial_state_and_store_load_roundtrip(tmp_path):
+    am = ActMax(n_collect=5, n_latents=3)
+    assert am.is_setup and am.activations.dtype == torch.bfloat16 and am.sample_ids.dtype == torch.int64
+    assert torch.equal(am.sample_ids, -torch.ones(3, 5, dtype=torch.int64))
+    assert np.all(am.activations.view(torch.int16).numpy().view(np.uint16) == 0x8000)  # -0.0
+    assert am.alive_latents.numel() == 0
+    lazy = ActMax(n_collect=5)
+    assert not lazy.is_setup and lazy.alive_latents.numel() == 0
+    # store / load (reference tests/component_visualization/test_activation_caching.py:32-48)
+    am.activations = torch.rand(3, 5).to(torch.bfloat16)
+    am.sample_ids = torch.arange(15).reshape(3, 5)
+    path = tmp_path / "actmax.safetensors"
+    am.store(path, metadata={"n_collect": "5", "n_latents": "3"})
+    back = ActMax.load(path)
+    assert back.n_collect == 5 and back.n_latents == 3
+    assert torch.equal(back.activations, am.activations) and torch.equal(back.sample_ids, am.sample_ids)
+    assert set(back.alive_latents.tolist()) <= {0, 1, 2}
+
+
+def test_actmax_cache_naming_metadata_and_validation(tmp_path):
+    with pytest.raises(ValueError, match="must be a defined function, not a lambda"):
+        ActMaxCache(["a"], lambda t: t, 3)
+    with pytest.raises(ValueError, match="tie_mode"):
+        ActMaxCache(["a"], agg.aggregate_conv_max, 3, tie_mode="bogus")
+    cache = ActMaxCache(["layer4", "fc"], agg.aggregate_conv_max, 7)
+    assert cache.metadata == {"aggregation_fn_name": "aggregate_conv_max", "n_collect": "7", "layer_names": "['layer4', 'fc']"}
+    assert repr(cache) == "ActMaxCache(layers=['layer4', 'fc'], aggregation_fn='aggregate_conv_max', n_collect=7)"
+    for name in ("layer4", "fc"):
+        cache.cache[name] = ActMax(7, 4)
+    cache.store(tmp_path / "c")
+    assert sorted(p.name for p in (tmp_path / "c").iterdir()) == [
+        "aggregate_conv_max-7-fc.safetensors", "aggregate_conv_max-7-layer4.safetensors"]
+    again = ActMaxCache(["layer4", "fc"], agg.aggregate_conv_max, 7)
+    again.load(tmp_path / "c")
+    assert again["fc"].n_latents == 4
+    # any mismatch is a cache miss = FileNotFoundError (activation_caching.py:505-525)
+    with pytest.raises(FileNotFoundError):
+        ActMaxCache(["layer4"], agg.aggregate_conv_mean, 7).load(tmp_path / "c")
+    with pytest.raises(FileNotFoundError):
+        ActMaxCache(["layer4"], agg.aggregate_conv_max, 8).load(tmp_path / "c")
+    with pytest.raises(FileNotFoundError):
+        ActMaxCache(["layer4"], agg.aggregate_conv_max, 7).load(tmp_path / "missing")
+
+
+def test_tie_mode_default_comes_from_environment(monkeypatch):
+    monkeypatch.delenv("SEMANTICLENS_AMD_TIES", raising=False)
+    assert ActMax(3).tie_mode == "aten"
+    monkeypatch.setenv("SEMANTICLENS_AMD_TIES", "total")
+    assert ActMax(3).tie_mode == "total"
+    monkeypatch.setenv("SEMANTICLENS_AMD_TIES", "nope")
+    with pytest.raises(ValueError):
+        ActMax(3)
+
+
+# ------------------------------------------------------------------- ActivationComponentVisualizer
+@pytest.fixture
+def mock_model():
+    model = nn.Sequential(nn.Conv2d(3, 8, 3), nn.ReLU(), nn.Conv2d(8, 16, 3))
+    model.name = "mock_model"
+    return model
+
+
+@pytest.fixture
+def mock_dataset():
+    ds = TensorDataset(torch.randn(4, 3, 32, 32), torch.randn(4, 3, 32, 32))
+    ds.name = "mock_dataset"
+    return ds
+
+
+def test_visualizer_initialisation_and_errors(mock_model, mock_dataset, tmp_path):
+    # reference tests/component_visualization/test_activation_based.py:26-67
+    cv = ActivationComponentVisualizer(mock_model, mock_dataset, mock_dataset, ["0"], num_samples=10, cache_dir=None)
+    assert cv.model is mock_model and cv.layer_names == ["0"] and not cv.caching
+    assert cv.actmax_cache.agg_fn_name == "aggregate_conv_mean"  # default aggregator
+    assert cv.metadata == {"aggregation_fn_name": "aggregate_conv_mean", "n_collect": "10", "layer_names": "['0']",
+                           "dataset": "mock_dataset", "model": "mock_model"}
+    with pytest.raises(ValueError, match="Layer 'bad_layer' not found in model"):
+        ActivationComponentVisualizer(mock_model, mock_dataset, mock_dataset, ["bad_layer"], num_samples=10)
+    with pytest.raises(ValueError, match="should have the same length"):
+        ActivationComponentVisualizer(mock_model, mock_dataset, TensorDataset(torch.randn(3, 1)), ["0"], num_samples=1)
+    with pytest.raises(ValueError, match="not found in model layers"):
+        cv.get_max_reference("2")
+    del mock_model.name
+    with pytest.warns(MissingNameWarning, match="Model does not have a name attribute"):
+        cv2 = ActivationComponentVisualizer(mock_model, mock_dataset, mock_dataset, ["0"], 10, cache_dir=str(tmp_path))
+    assert mock_model.name == get_fallback_name(mock_model) and mock_model.name.startswith("Sequential-")
+    assert cv2.storage_dir == tmp_path / "ActivationComponentVisualizer" / "mock_dataset" / mock_model.name
+
+
+def test_run_uses_cache_when_available(mock_model, mock_dataset, tmp_path):
+    # reference test_activation_based.py:70-93: load called twice (ctor + run), _run never
+    with mock.patch.object(ActMaxCache, "load", return_value={}) as load, mock.patch.object(
+        ActivationComponentVisualizer, "_run"
+    ) as run:
+        cv = ActivationComponentVisualizer(mock_model, mock_dataset, mock_dataset, ["0"], 10, cache_dir=str(tmp_path))
+        cv.run()
+    assert load.call_count == 2
+    run.assert_not_called()
+
+
+def test_run_computes_on_cache_miss(mock_model, mock_dataset, tmp_path):
+    # reference test_activation_based.py:96-123 (the compute itself is patched: no device here)
+    with mock.patch.object(ActMaxCache, "load", side_effect=FileNotFoundError), mock.patch.object(
+        ActivationComponentVisualizer, "_run", return_value="computed"
+    ) as run:
+        cv = ActivationComponentVisualizer(mock_model, mock_dataset, mock_dataset, ["0"], 10, cache_dir=str(tmp_path))
+        assert cv.run(batch_size=2) == "computed"
+    run.assert_called_once_with(batch_size=2, num_workers=0)
+
+
+def test_empty_layer_list_runs_without_a_device(mock_model, mock_dataset):
+    # reference test_activation_based.py:126-139
+    cv = ActivationComponentVisualizer(mock_model, mock_dataset, mock_dataset, [], num_samples=10)
+    assert cv.run() == {}
+
+
+# -------------------------------------------------------------------------------------------- Lens
+@pytest.fixture
+def mock_fm():
+    fm = mock.MagicMock()
+    fm.device = "cpu"
+    fm.to.return_value = fm
+    return fm
+
+
+@pytest.fixture
+def mock_cv(tmp_path):
+    cv = mock.MagicMock()
+    cv.caching = True
+    cv.storage_dir = tmp_path
+    cv._compute_concept_db.return_value = {"layer1": torch.randn(10, 5, 128)}
+    cv.metadata = {"aggregation_fn_name": "aggregate_conv_max", "n_collect": "5", "layer_names": "['layer1']",
+                   "dataset": "d", "model": "m"}
+    return cv
+
+
+def test_lens_moves_fm_and_names_it(mock_fm):
+    # reference tests/test_lens.py:35-42
+    lens = Lens(fm=mock_fm, device="cpu")
+    assert lens.fm is mock_fm
+    mock_fm.to.assert_called_with("cpu")
+
+    class Nameless:
+        device = "cpu"
+
+        def to(self, d):
+            return self
+
+    fm = Nameless()
+    Lens(fm)
+    assert fm.name == get_fallback_name(fm)
+
+
+def test_lens_concept_db_cache_miss_then_hit(mock_fm, mock_cv, tmp_path):
+    # reference tests/test_lens.py:45-81, with the real safetensors round trip
+    mock_fm.name = "fm-x"
+    lens = Lens(fm=mock_fm)
+    db = lens.compute_concept_db(mock_cv, batch_size=8)
+    mock_cv._compute_concept_db.assert_called_once_with(mock_fm, batch_size=8)
+    f = tmp_path / "concept_database" / "fm-x" / "concept_db-aggregate_conv_max-5-['layer1'].safetensors"
+    assert f.exists()  # lens.py:308-316 naming
+    db2 = lens.compute_concept_db(mock_cv)
+    mock_cv._compute_concept_db.assert_called_once()  # served from the cache
+    assert torch.equal(db2["layer1"], db["layer1"])
+    mock_cv.caching = False
+    lens.compute_concept_db(mock_cv)
+    assert mock_cv._compute_concept_db.call_count == 2
+
+
+def test_text_probing_host_flow_with_patched_kernels(mock_fm):
+    # reference tests/test_lens.py:84-97: one encode_text call, (1, n_components) per layer
+    mock_fm.encode_text.return_value = torch.randn(1, 128)
+    lens = Lens(fm=mock_fm)
+    with mock.patch("semanticlens_amd.lens.similarity_score", side_effect=lambda q, d: torch.zeros(q.shape[0], d.shape[0])):
+        res = lens.text_probing("a test query", {"layer1": torch.randn(10, 128)})
+    mock_fm.encode_text.assert_called_once()
+    assert res["layer1"].shape == (1, 10)
+
+
+def test_text_probe_template_order_matches_reference(golden):
+    """lens.py:174 builds template-major; the regrouping quirk happens in K10.  Check the strings/batching."""
+    from helpers import FakeVLM
+    from semanticlens_amd import lens as L
+
+    fm = FakeVLM()
+    seen = []
+    orig = fm.tokenize
+    fm.tokenize = lambda txt: (seen.append(list(txt)), orig(txt))[1]
+    with mock.patch.object(L.N, "template_mean", side_effect=lambda E, E0, Q: torch.zeros(Q, E.shape[1])) as tm:
+        out = L._embed_text_probes(fm, ["cat", "dog"], ["a photo of a {}", "an image of {}"], 3)
+    assert seen == [["a photo of a cat", "a photo of a dog", "an image of cat"], ["an image of dog"],
+                    ["a photo of a ", "an image of "]]
+    E, E0, Q = tm.call_args[0]
+    assert E.shape == (4, 16) and E0.shape == (2, 16) and Q == 2 and out.shape == (2, 16)
+
+
+# ---------------------------------------------------------------------------------------------- K9
+def test_kmeans_draws_match_sklearn_seeding():
+    """The host-side draws equal what scikit-learn's KMeans consumes: replay them against sklearn's own
+    k-means++ (first centre = our draw; the candidate thresholds = our uniforms x potential)."""
+    from sklearn.cluster import _kmeans
+
+    from semanticlens_amd.scores import kmeans_draws
+
+    n, n_init, seed = 20, 10, 123
+    first, rand = kmeans_draws(n, n_init, seed)
+    X = np.random.RandomState(0).randn(n, 8).astype(np.float32)
+    rs = np.random.RandomState(seed)
+    sw = np.ones(n, dtype=np.float32)
+    norms = (X * X).sum(1)
+    for i in range(n_init):
+        state_before = rs.get_state()
+        centers, idx = _kmeans._kmeans_plusplus(X, 2, norms, sw, rs)
+        assert idx[0] == first[i]
+        replay = np.random.RandomState()
+        replay.set_state(state_before)
+        replay.choice(n, p=sw / sw.sum())
+        assert np.array_equal(replay.uniform(size=2), rand[i])
+
+
+# ------------------------------------------------------------------------------------ distributed
+def test_shard_ranges_cover_dataset():
+    from semanticlens_amd.distributed import shard_range
+
+    for n, w in ((10, 3), (1280000, 8), (5, 8), (0, 2), (50176, 1)):
+        spans = [shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert all(0 <= s <= e for s, e in spans)
+
+
+def test_pack_unpack_states_roundtrip():
+    from semanticlens_amd.distributed import pack_states, unpack_states
+
+    states = [(torch.randn(4, 3).to(torch.bfloat16), torch.randint(-1, 99, (4, 3))),
+              (torch.randn(2, 5).to(torch.bfloat16), torch.randint(-1, 99, (2, 5)))]
+    buf = pack_states(states)
+    assert buf.dtype == torch.uint8 and buf.numel() == 224  # (12 + 10) * 10 = 220, padded to 16
+    back = unpack_states(buf, [(4, 3), (2, 5)])
+    for (v, i), (v2, i2) in zip(states, back):
+        assert torch.equal(v, v2) and torch.equal(i, i2)
+
+
+def test_aten_order_restatement_matches_libstdcxx(tmp_path):
+    """csrc/aten_topk_order.hpp (compiled for the host) vs std::partial_sort / nth_element / sort."""
+    exe = tmp_path / "aten_order_check"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-include", "cstring", "-o", str(exe),
+                    str(ROOT / "tests" / "native" / "aten_order_check.cpp")], check=True)
+    res = subprocess.run([str(exe), "20000"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "mismatches=0" in res.stdout
