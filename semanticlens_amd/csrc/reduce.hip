@@ -102,72 +102,322 @@ __device__ inline void store_outputs(float r, int64_t idx, uint16_t* cand, float
 }
 
 // ---- rowreduce: contiguous rows -------------------------------------------------------------
-// x: 16-byte aligned, R rows of S floats back to back.
-template <int G, int U, int OP>
+// x: 16-byte aligned, R rows of S floats back to back.  A wave works on a batch of U tasks; a task
+// is 64/G consecutive rows covered by one 1-KiB wave-load per step (G lanes per row).
+//
+// Cost model (HBM-bound: ~13 B/clk/CU at 8 TB/s => one 1-KiB wave-load per ~78 clk per CU):
+//  * max: v_max_f32 ignores NaN, torch.amax propagates it.  Instead of testing every element, a
+//    running SUM rides along (NaN in => NaN out); only when a row's sum is NaN (a NaN, or +inf and
+//    -inf together) the row is re-scanned exactly.  4 max + 4 add per 16-byte piece.
+//  * element masks for rows that are not 16-byte aligned (e.g. 7x7 = 49 floats) depend only on the
+//    lane when 64/G is a multiple of 4, so they are computed once per kernel.
+//  * addressing: wave-uniform 64-bit batch base + 32-bit lane offsets.
+template <bool SUMOP>
+__device__ inline float dpp_combine(float v, float o) {
+  if constexpr (SUMOP) return v + o;
+  return __builtin_fmaxf(v, o);
+}
+template <int CTRL, bool SUMOP>
+__device__ inline float dpp_step(float v) {
+  return dpp_combine<SUMOP>(v, bits_f32((uint32_t)dpp_i32<CTRL>((int)f32_bits(v))));
+}
+// all-reduce (plain float max / add) over aligned groups of G lanes
+template <int G, bool SUMOP>
+__device__ inline float group_allreduce_f(float v) {
+  if constexpr (G >= 2) v = dpp_step<0xB1, SUMOP>(v);
+  if constexpr (G >= 4) v = dpp_step<0x4E, SUMOP>(v);
+  if constexpr (G >= 8) v = dpp_step<0x141, SUMOP>(v);
+  if constexpr (G >= 16) v = dpp_step<0x140, SUMOP>(v);
+  if constexpr (G >= 32) v = dpp_combine<SUMOP>(v, __shfl_xor(v, 16, 64));
+  if constexpr (G >= 64) v = dpp_combine<SUMOP>(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
+// TAIL: total = R*S is not a multiple of 4, so the tensor ends inside a 16-byte piece; the last
+// (total & 3) floats are masked out of the vector loads and added by scalar loads to the rows that
+// own them (up to three rows when S < 4).
+template <int G, int U, int OP, bool TAIL>
 __global__ __launch_bounds__(256) void rowreduce_kernel(const float* __restrict__ x, int64_t R, int S,
                                                          uint16_t* __restrict__ cand, float* __restrict__ outf) {
-  constexpr int RPT = kWave / G;  // rows per task (one wave-load covers RPT rows)
+  constexpr int RPT = kWave / G;
+  constexpr bool SUMOP = (OP == OP_SUM || OP == OP_ABSSUM);
+  constexpr bool ABS = (OP == OP_ABSMAX || OP == OP_ABSSUM);
+  constexpr bool HOIST_H = (RPT % 4 == 0);  // row phase h = (row * S) & 3 depends on the lane only
+  const float fill = SUMOP ? 0.f : -__builtin_huge_valf();
   const int lane = threadIdx.x & 63;
-  const int li = lane % G;
+  const int li = lane & (G - 1);
   const int g = lane / G;
   const int64_t total = R * (int64_t)S;
-  const int64_t ntasks = (R + RPT - 1) / RPT;
-  const int64_t nbatch = (ntasks + U - 1) / U;
-  const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t total4 = total & ~3ll;  // floats readable as whole 16-byte pieces
+  const int64_t nbatch = (R + U * RPT - 1) / (U * RPT);
+  // wave-uniform by construction; readfirstlane lets the compiler keep the batch base in SGPRs
+  const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block;
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-  const int nsteps = ((S + 6) / 4 + G - 1) / G;  // 16-byte pieces per row window, per lane
-  const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
+  const int nsteps = ((S + 6) / 4 + G - 1) / G;  // 16-byte pieces of a row window, per lane
+  const int h_lane = (g * S) & 3;
 
   for (int64_t tb = wave0; tb < nbatch; tb += nwaves) {
-    Acc<OP> acc[U];
-    int64_t e0[U];
+    const int64_t row0 = tb * (int64_t)(U * RPT);  // wave-uniform
+    const int64_t e_batch = row0 * (int64_t)S;
+    const int delta = (int)(e_batch & 3);
+    const int64_t a0 = e_batch - delta;
+    const float4* __restrict__ A = reinterpret_cast<const float4*>(x + a0);  // wave-uniform, 16-byte aligned
+    // last whole piece of the tensor, relative to A: lanes whose piece would start beyond it are
+    // clamped onto it; every element they then hold is masked by its row position anyway
+    const int64_t lim = (total4 - a0) / 4 - 1;
+    const int idx_max = lim > 0x7FFFFFFF ? 0x7FFFFFFF : (int)lim;
+    const int64_t rel = total4 - a0;  // floats of whole pieces left from A on
+    const int rel_lim = rel > 0x7FFFFFFF ? 0x7FFFFFFF : (int)rel;
+
+    float m[U], sum[U];
+    int rs[U];  // row start in elements relative to A
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      acc[u].init();
-      int64_t r = (tb * U + u) * RPT + g;
-      e0[u] = r < R ? r * (int64_t)S : -1;
+      m[u] = fill;
+      sum[u] = 0.f;
+      rs[u] = delta + (u * RPT + g) * S;
     }
+
     for (int step = 0; step < nsteps; ++step) {
-      const int q = step * G + li;  // piece index inside the row window
+      const int q = step * G + li;
       float4 v[U];
 #pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = A[min((rs[u] >> 2) + q, idx_max)];
+#pragma unroll
       for (int u = 0; u < U; ++u) {
-        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (e0[u] >= 0) {
-          const int64_t p4 = (e0[u] >> 2) + q;  // global 16-byte piece index
-          const int64_t pe = p4 << 2;
-          const int h = (int)(e0[u] & 3);
-          if (q * 4 - h < S) {  // piece overlaps the row
-            if (pe + 4 <= total) {
-              v[u] = x4[p4];
-            } else {  // last piece of the tensor: stay in bounds
-              float t[4] = {0.f, 0.f, 0.f, 0.f};
-              for (int i = 0; i < 4; ++i)
-                if (pe + i < total) t[i] = x[pe + i];
-              v[u] = make_float4(t[0], t[1], t[2], t[3]);
-            }
+        const int h = HOIST_H ? h_lane : (rs[u] & 3);
+        const int pos0 = q * 4 - h;  // row-local index of v.x (negative in the head piece)
+        int lim_s = S;
+        if constexpr (TAIL) {  // also drop elements at or beyond the last whole piece of the tensor
+          const int left = rel_lim - rs[u];  // row-local index of the first float not covered by whole pieces
+          lim_s = left < S ? (left > 0 ? left : 0) : S;
+        }
+        float e0 = v[u].x, e1 = v[u].y, e2 = v[u].z, e3 = v[u].w;
+        if constexpr (ABS) {
+          e0 = __builtin_fabsf(e0); e1 = __builtin_fabsf(e1); e2 = __builtin_fabsf(e2); e3 = __builtin_fabsf(e3);
+        }
+        e0 = (unsigned)(pos0 + 0) < (unsigned)lim_s ? e0 : fill;
+        e1 = (unsigned)(pos0 + 1) < (unsigned)lim_s ? e1 : fill;
+        e2 = (unsigned)(pos0 + 2) < (unsigned)lim_s ? e2 : fill;
+        e3 = (unsigned)(pos0 + 3) < (unsigned)lim_s ? e3 : fill;
+        if constexpr (!SUMOP)
+          m[u] = __builtin_fmaxf(__builtin_fmaxf(m[u], __builtin_fmaxf(e0, e1)), __builtin_fmaxf(e2, e3));
+        sum[u] += (e0 + e1) + (e2 + e3);
+      }
+    }
+
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = row0 + (u * RPT + g);
+      const bool row_ok = row < R;
+      if constexpr (TAIL) {
+        if (row_ok && li == 0 && (row + 1) * (int64_t)S > total4) {  // this row owns floats behind the last whole piece
+          const int64_t lo = row * (int64_t)S > total4 ? row * (int64_t)S : total4;
+          for (int64_t i = lo; i < (row + 1) * (int64_t)S; ++i) {
+            float e = x[i];
+            if constexpr (ABS) e = __builtin_fabsf(e);
+            if constexpr (!SUMOP) m[u] = __builtin_fmaxf(m[u], e);
+            sum[u] += e;
           }
         }
       }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int h = (int)(e0[u] & 3);
-        const int pos = q * 4 - h;  // row-local index of v.x
-        const bool row_ok = e0[u] >= 0;
-        acc[u].add(v[u].x, row_ok && (unsigned)(pos + 0) < (unsigned)S);
-        acc[u].add(v[u].y, row_ok && (unsigned)(pos + 1) < (unsigned)S);
-        acc[u].add(v[u].z, row_ok && (unsigned)(pos + 2) < (unsigned)S);
-        acc[u].add(v[u].w, row_ok && (unsigned)(pos + 3) < (unsigned)S);
+      float r;
+      if constexpr (SUMOP) {
+        r = group_allreduce_f<G, true>(sum[u]) / (float)S;  // torch: sum / n
+      } else {
+        r = group_allreduce_f<G, false>(m[u]);
+        const float sred = group_allreduce_f<G, true>(sum[u]);
+        if (__builtin_expect(__any(row_ok && sred != sred), 0)) {
+          // exact re-scan of this lane-group's row: does it really hold a NaN?
+          bool nan = false;
+          if (row_ok && sred != sred) {
+            const float* rowp = x + row * (int64_t)S;
+            for (int i = li; i < S; i += G) nan |= (rowp[i] != rowp[i]);
+          }
+          const float f = group_allreduce_f<G, false>(nan ? 1.f : 0.f);
+          if (f > 0.f) r = bits_f32(0x7FC00000u);
+        }
       }
+      if (li == 0 && row_ok) store_outputs(r, row, cand, outf);
     }
+  }
+}
+
+// ---- rowreduce_fast: the streaming path for the common shapes -----------------------------------
+// Preconditions (checked by the launcher): the row phase h = (row*S)&3 is the same for every row a
+// lane ever touches, i.e. S % 4 == 0 (ALIGNED: h = 0, a row is a whole number of 16-byte pieces) or
+// 64/G % 4 == 0 with one piece per lane (h = (g*S)&3).  Then
+//   * the lane's byte offset inside a task and its four element masks are loop invariant,
+//   * the task base is wave-uniform, so every load is `global_load_dwordx4 v, v_off, s[base]`,
+//   * ALIGNED rows need no element masks at all: lanes past the row's last piece re-read that piece
+//     (max is idempotent; for sums the piece is masked as a whole).
+// VALU per 16-byte piece: 2 v_max3 + 4 v_add (+ 4 v_cndmask when rows are unaligned); per row one DPP
+// max-reduction.  hipcc's own fmaxf lowering (canonicalising v_max pairs, unfused DPP moves) cost ~3x
+// that and capped the kernel near 3.6 TB/s, hence the few single-instruction asm helpers below.
+__device__ inline float v_max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ inline float v_max2(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// r = op(a, dpp(a)); the s_nop covers the VALU-write -> DPP-read hazard (2 wait states), which the
+// compiler does not pad inside an asm statement.
+#define SL_DPP_OP(name, insn, ctrl)                                                           \
+  __device__ inline float name(float a) {                                                     \
+    float r;                                                                                  \
+    asm("s_nop 1\n\t" insn " %0, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(a)); \
+    return r;                                                                                 \
+  }
+SL_DPP_OP(max_qp1, "v_max_f32_dpp", "quad_perm:[1,0,3,2]")
+SL_DPP_OP(max_qp2, "v_max_f32_dpp", "quad_perm:[2,3,0,1]")
+SL_DPP_OP(max_hmir, "v_max_f32_dpp", "row_half_mirror")
+SL_DPP_OP(max_mir, "v_max_f32_dpp", "row_mirror")
+SL_DPP_OP(add_qp1, "v_add_f32_dpp", "quad_perm:[1,0,3,2]")
+SL_DPP_OP(add_qp2, "v_add_f32_dpp", "quad_perm:[2,3,0,1]")
+SL_DPP_OP(add_hmir, "v_add_f32_dpp", "row_half_mirror")
+SL_DPP_OP(add_mir, "v_add_f32_dpp", "row_mirror")
+#undef SL_DPP_OP
+
+template <int G, bool SUMOP>
+__device__ inline float group_allreduce_asm(float v) {
+  if constexpr (SUMOP) {
+    if constexpr (G >= 2) v = add_qp1(v);
+    if constexpr (G >= 4) v = add_qp2(v);
+    if constexpr (G >= 8) v = add_hmir(v);
+    if constexpr (G >= 16) v = add_mir(v);
+    if constexpr (G >= 32) v += __shfl_xor(v, 16, 64);
+    if constexpr (G >= 64) v += __shfl_xor(v, 32, 64);
+  } else {
+    if constexpr (G >= 2) v = max_qp1(v);
+    if constexpr (G >= 4) v = max_qp2(v);
+    if constexpr (G >= 8) v = max_hmir(v);
+    if constexpr (G >= 16) v = max_mir(v);
+    if constexpr (G >= 32) v = v_max2(v, __shfl_xor(v, 16, 64));
+    if constexpr (G >= 64) v = v_max2(v, __shfl_xor(v, 32, 64));
+  }
+  return v;
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#ifndef SL_LOAD_AUX
+#define SL_LOAD_AUX 0  // cache-policy bits of the streaming loads (2 = nt); set by the build for A/B runs
+#endif
+
+template <int G, int U, int OP, bool ALIGNED>
+__global__ __launch_bounds__(256) void rowreduce_fast_kernel(const float* __restrict__ x, int64_t R, int S,
+                                                              uint16_t* __restrict__ cand,
+                                                              float* __restrict__ outf) {
+  constexpr int RPT = kWave / G;
+  constexpr bool SUMOP = (OP == OP_SUM || OP == OP_ABSSUM);
+  constexpr bool ABS = (OP == OP_ABSMAX || OP == OP_ABSSUM);
+  const float fill = SUMOP ? 0.f : -__builtin_huge_valf();
+  const int lane = threadIdx.x & 63;
+  const int li = lane & (G - 1);
+  const int g = lane / G;
+  const int64_t ntask = R / RPT;  // launcher guarantees R % RPT == 0 and total % 4 == 0
+  const int64_t nbatch = (ntask + U - 1) / U;
+  const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const int npieces = ALIGNED ? S / 4 : (S + 6) / 4;     // pieces of one row window
+  const int nsteps = ALIGNED ? (npieces + G - 1) / G : 1;  // unaligned rows: one piece per lane
+  const int h = ALIGNED ? 0 : ((g * S) & 3);
+  const uint32_t row_byte0 = (uint32_t)(((g * S) >> 2) * 16);  // lane-group's row start inside the task
+  const uint32_t task_bytes = (uint32_t)(RPT * S) * 4u;        // multiple of 16
+  // element masks of this lane's piece (unaligned rows only; loop invariant)
+  const int pos0 = li * 4 - h;
+  const bool k0 = (unsigned)(pos0 + 0) < (unsigned)S, k1 = (unsigned)(pos0 + 1) < (unsigned)S;
+  const bool k2 = (unsigned)(pos0 + 2) < (unsigned)S, k3 = (unsigned)(pos0 + 3) < (unsigned)S;
+
+  for (int64_t tb = wave0; tb < nbatch; tb += nwaves) {
+    const int64_t task0 = tb * U;
+    int nu = U;  // tasks that exist in this batch (wave-uniform)
+    if (task0 + U > ntask) nu = (int)(ntask - task0);
+    // Buffer descriptor over this batch's bytes, built from provably wave-uniform halves of the base
+    // pointer so every load is `buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen` (no 64-bit VALU
+    // address math, no waterfall loop); the hardware range check makes out-of-batch reads return 0.
+    const uint64_t bptr = (uint64_t)(reinterpret_cast<const char*>(x) + task0 * (int64_t)task_bytes);
+    const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bptr);
+    const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bptr >> 32));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(((uint64_t)bhi << 32) | blo), 0, (int)((uint32_t)nu * task_bytes), 0x00020000);
+    float m[U], sum[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      constexpr bool SUM = (OP == OP_SUM || OP == OP_ABSSUM);
-      float r = group_allreduce<G, SUM>(acc[u].lane_value());
-      if (li == 0 && e0[u] >= 0) {
-        r = finish<OP>(r, (float)S);
-        store_outputs(r, (tb * U + u) * RPT + g, cand, outf);
+      m[u] = fill;
+      sum[u] = 0.f;
+    }
+    for (int step = 0; step < nsteps; ++step) {
+      const int q = step * G + li;
+      uint32_t off;
+      bool piece_ok = true;
+      if constexpr (ALIGNED) {
+        piece_ok = q < npieces;
+        off = row_byte0 + (uint32_t)(piece_ok ? q : npieces - 1) * 16u;  // past the row: re-read its last piece
+      } else {
+        // past the row's window (li >= npieces): clamp onto the window's last piece; all masks are false there
+        off = row_byte0 + (uint32_t)(li < npieces ? li : npieces - 1) * 16u;
       }
+      float4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, (int)((uint32_t)u * task_bytes), SL_LOAD_AUX);
+        v[u] = make_float4(bits_f32(w[0]), bits_f32(w[1]), bits_f32(w[2]), bits_f32(w[3]));
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float e0 = v[u].x, e1 = v[u].y, e2 = v[u].z, e3 = v[u].w;
+        if constexpr (ABS) {
+          e0 = __builtin_fabsf(e0); e1 = __builtin_fabsf(e1); e2 = __builtin_fabsf(e2); e3 = __builtin_fabsf(e3);
+        }
+        if constexpr (!ALIGNED) {
+          e0 = k0 ? e0 : fill; e1 = k1 ? e1 : fill; e2 = k2 ? e2 : fill; e3 = k3 ? e3 : fill;
+        }
+        if constexpr (SUMOP) {
+          float ps = (e0 + e1) + (e2 + e3);
+          if constexpr (ALIGNED) ps = piece_ok ? ps : 0.f;
+          sum[u] += ps;
+        } else {
+          m[u] = v_max3(v_max3(m[u], e0, e1), e2, e3);
+          sum[u] += (e0 + e1) + (e2 + e3);  // NaN detector only
+        }
+      }
+    }
+    float r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if constexpr (SUMOP) {
+        r[u] = group_allreduce_asm<G, true>(sum[u]) / (float)S;  // torch: sum / n
+      } else {
+        r[u] = group_allreduce_asm<G, false>(m[u]);
+        // any lane of the wave saw a NaN sum (a NaN, or +inf and -inf)?  Rare: re-scan those rows exactly.
+        const bool row_ok = u < nu;
+        if (__builtin_expect(__any(row_ok && sum[u] != sum[u]), 0)) {
+          const float sred = group_allreduce_f<G, true>(sum[u]);
+          bool nan = false;
+          if (row_ok && sred != sred) {
+            const float* rowp = x + ((task0 + u) * RPT + g) * (int64_t)S;
+            for (int i = li; i < S; i += G) nan |= (rowp[i] != rowp[i]);
+          }
+          const float f = group_allreduce_f<G, false>(nan ? 1.f : 0.f);
+          if (f > 0.f) r[u] = bits_f32(0x7FC00000u);
+        }
+      }
+    }
+    // After the all-reduce every lane of a group holds its row's result for each u.  Lane li of group g
+    // keeps r[p + li] and stores it: one masked store instruction per G tasks instead of one per task.
+#pragma unroll
+    for (int p = 0; p < U; p += G) {
+      float sel = r[p];
+#pragma unroll
+      for (int u = p + 1; u < U && u < p + G; ++u) sel = (li == u - p) ? r[u] : sel;
+      const int uu = p + li;
+      if (li < G && uu < nu) store_outputs(sel, (task0 + uu) * RPT + g, cand, outf);
     }
   }
 }
@@ -275,13 +525,44 @@ void launch_rowreduce(const float* x, int64_t R, int S, uint16_t* cand, float* o
   const int64_t cap = (int64_t)num_cus() * 8;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((rowreduce_kernel<G, U, OP>), dim3((unsigned)blocks), dim3(256), 0, st, x, R, S, cand, outf);
+  if ((R * (int64_t)S) % 4 == 0)
+    hipLaunchKernelGGL((rowreduce_kernel<G, U, OP, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, R, S, cand, outf);
+  else
+    hipLaunchKernelGGL((rowreduce_kernel<G, U, OP, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, R, S, cand, outf);
+}
+
+template <int G, int U, int OP, bool ALIGNED>
+void launch_rowreduce_fast(const float* x, int64_t R, int S, uint16_t* cand, float* outf, hipStream_t st) {
+  constexpr int RPT = kWave / G;
+  const int64_t nbatch = (R / RPT + U - 1) / U;
+  int64_t blocks = (nbatch + 3) / 4;
+  const int64_t cap = (int64_t)num_cus() * 8;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL((rowreduce_fast_kernel<G, U, OP, ALIGNED>), dim3((unsigned)blocks), dim3(256), 0, st, x, R, S, cand,
+                     outf);
 }
 
 template <int OP>
 void dispatch_rowreduce(const float* x, int64_t R, int S, uint16_t* cand, float* outf, hipStream_t st) {
   // pieces needed for a row window: up to (S + 6) / 4
   const int need = (S + 6) / 4;
+  // fast path A: rows are whole 16-byte pieces
+  if (S % 4 == 0 && S >= 16 && (int64_t)S * 64 * 4 * 8 < (1ll << 31)) {
+    const int np = S / 4;
+    if (np <= 4 && R % 16 == 0) return launch_rowreduce_fast<4, 8, OP, true>(x, R, S, cand, outf, st);
+    if (np <= 8 && R % 8 == 0) return launch_rowreduce_fast<8, 8, OP, true>(x, R, S, cand, outf, st);
+    if (np <= 16 && R % 4 == 0) return launch_rowreduce_fast<16, 8, OP, true>(x, R, S, cand, outf, st);
+    if (np <= 32 && R % 2 == 0) return launch_rowreduce_fast<32, 8, OP, true>(x, R, S, cand, outf, st);
+    if (np <= 64) return launch_rowreduce_fast<64, 8, OP, true>(x, R, S, cand, outf, st);
+    return launch_rowreduce_fast<64, 4, OP, true>(x, R, S, cand, outf, st);
+  }
+  // fast path B: short unaligned rows (e.g. 7x7 = 49 floats), >= 4 rows per wave-load
+  if (S % 4 != 0 && need <= 16) {
+    if (need <= 4 && R % 16 == 0) return launch_rowreduce_fast<4, 8, OP, false>(x, R, S, cand, outf, st);
+    if (need <= 8 && R % 8 == 0) return launch_rowreduce_fast<8, 8, OP, false>(x, R, S, cand, outf, st);
+    if (R % 4 == 0) return launch_rowreduce_fast<16, 8, OP, false>(x, R, S, cand, outf, st);
+  }
   if (need <= 4) launch_rowreduce<4, 8, OP>(x, R, S, cand, outf, st);
   else if (need <= 8) launch_rowreduce<8, 8, OP>(x, R, S, cand, outf, st);
   else if (need <= 16) launch_rowreduce<16, 8, OP>(x, R, S, cand, outf, st);

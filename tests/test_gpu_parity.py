@@ -190,6 +190,49 @@ def test_conv_reduce_layouts_and_dtypes():
         assert np.array_equal(bits(cand), oracle.f32_to_bf16(oracle.agg_conv(xh.float().cpu().numpy(), "max")))
 
 
+@pytest.mark.parametrize("shape", [(3, 4, 7, 7), (7, 12, 14, 14), (5, 8, 28, 28), (9, 8, 7, 7), (33, 64, 7, 7), (6, 10, 4, 4),
+                                   (3, 16, 2, 2), (2, 6, 12, 12), (128, 512, 7, 7), (8, 100, 14, 14)])
+def test_conv_reduce_special_values_and_partial_batches(shape):
+    """NaN / +-inf anywhere (incl. +inf and -inf in one row: the sum-based NaN detector's false positive),
+    rows of all -inf, and row counts that leave the last wave batch partly empty."""
+    rng = np.random.RandomState(sum(shape))
+    x = rng.randn(*shape).astype(np.float32)
+    flat = x.reshape(shape[0] * shape[1], -1)
+    R, S = flat.shape
+    for r in rng.choice(R, size=min(R, 12), replace=False):
+        kind = rng.randint(6)
+        c = rng.randint(S)
+        if kind == 0:
+            flat[r, c] = np.nan
+        elif kind == 1:
+            flat[r, c] = np.inf
+            flat[r, (c + 1) % S] = -np.inf  # sum is NaN, max is +inf
+        elif kind == 2:
+            flat[r, :] = -np.inf
+        elif kind == 3:
+            flat[r, S - 1] = np.nan  # last element of the row
+        elif kind == 4:
+            flat[r, 0] = -np.nan  # negative-signed NaN in the first element
+        else:
+            flat[r, c] = -np.inf
+    xd = torch.from_numpy(x).to(DEV)
+    B, C = shape[:2]
+    for name, code in (("max", N.SL_CONV_MAX), ("mean", N.SL_CONV_MEAN)):
+        cand = torch.empty((B, C), dtype=torch.bfloat16, device=DEV)
+        out = torch.empty((B, C), dtype=torch.float32, device=DEV)
+        N.reduce_conv(xd, code, cand, out)
+        want = oracle.agg_conv(x, name)
+        got = out.cpu().numpy()
+        if name == "max":
+            assert feq(got, want), shape
+            assert np.array_equal(bits(cand), oracle.f32_to_bf16(want)), shape
+        else:
+            assert np.array_equal(np.isnan(got), np.isnan(want)), shape
+            fin = np.isfinite(want)
+            np.testing.assert_allclose(got[fin], want[fin], rtol=3e-6, atol=1e-6)
+            assert np.array_equal(got[~fin & ~np.isnan(want)], want[~fin & ~np.isnan(want)])
+
+
 TOKEN_SHAPES = [(2, 10, 16), (3, 197, 24), (2, 5, 7), (4, 50, 768), (2, 197, 260), (1, 1, 4), (3, 33, 1000)]
 
 
