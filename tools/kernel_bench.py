@@ -107,7 +107,7 @@ def main():
             print(json.dumps(out[-1]), flush=True)
     out.append(("merge_cold", bench_merge(2048, 20, 256, "total", steady=False)))
     print(json.dumps(out[-1]), flush=True)
-    for q, c, d in ((10000, 768, 1152), (10000, 9216, 1152), (4096, 4096, 512)):
+    for q, c, d in ((10000, 768, 1152), (10000, 9216, 1152), (4096, 2048, 512)):
         out.append(("gemm", bench_gemm(q, c, d)))
         print(json.dumps(out[-1]), flush=True)
 
