@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--cpu-images", type=int, default=192, help="bounded sample for the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probing", action="store_true")
+    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (exhaustive MIOpen search)")
     return ap.parse_args()
 
 
@@ -189,7 +190,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.backends.cudnn.benchmark = True
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
 
     B, K, W = args.batch, args.steps, args.warmup
     n_local = K * B

@@ -229,14 +229,14 @@ SL_API int sl_actmax_merge(uint16_t* d_vals, int64_t* d_ids, int64_t C, int64_t 
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof(SL_PROF_MERGE, st, bytes + (double)C * k * 10);
   const unsigned blocks = (unsigned)((C + kWavesPerBlock - 1) / kWavesPerBlock);
-  hipLaunchKernelGGL(actmax_merge_kernel, dim3(blocks), dim3(256), row_smem_bytes(k), st, d_vals, d_ids, C, (int)k,
-                     d_cand, sa, (const int64_t*)nullptr);
+  SL_LAUNCH(prof, actmax_merge_kernel, dim3(blocks), dim3(256), row_smem_bytes(k), st, d_vals, d_ids, C, (int)k, d_cand, sa,
+            (const int64_t*)nullptr);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
 namespace sl {
-int actmax_update_aten(uint16_t* d_vals, int64_t* d_ids, int64_t C, int64_t k, const uint16_t* d_cand,
+int actmax_update_aten(ProfScope& prof, uint16_t* d_vals, int64_t* d_ids, int64_t C, int64_t k, const uint16_t* d_cand,
                        const int64_t* d_sample_ids, int64_t id_base, int64_t B, void* d_ws, size_t ws_bytes,
                        hipStream_t st);
 }
@@ -252,15 +252,15 @@ SL_API int sl_actmax_update(uint16_t* d_vals, int64_t* d_ids, int64_t C, int64_t
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof(SL_PROF_MERGE, st, (double)B * C * 2 + (double)C * k * 10);
   if (ties == SL_TIES_ATEN)
-    return actmax_update_aten(d_vals, d_ids, C, k, d_cand, d_sample_ids, id_base, B, d_ws, ws_bytes, st);
+    return actmax_update_aten(prof, d_vals, d_ids, C, k, d_cand, d_sample_ids, id_base, B, d_ws, ws_bytes, st);
   SlotArgs sa;
   sa.nslots = 1;
   sa.stride = 0;
   sa.id_base[0] = id_base;
   sa.rows[0] = B;
   const unsigned blocks = (unsigned)((C + kWavesPerBlock - 1) / kWavesPerBlock);
-  hipLaunchKernelGGL(actmax_merge_kernel, dim3(blocks), dim3(256), row_smem_bytes(k), st, d_vals, d_ids, C, (int)k,
-                     d_cand, sa, d_sample_ids);
+  SL_LAUNCH(prof, actmax_merge_kernel, dim3(blocks), dim3(256), row_smem_bytes(k), st, d_vals, d_ids, C, (int)k, d_cand, sa,
+            d_sample_ids);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -274,8 +274,8 @@ SL_API int sl_actmax_merge_states(uint16_t* d_vals, int64_t* d_ids, int64_t C, i
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof(SL_PROF_MERGE, st, (double)(R + 1) * C * k * 10);
   const unsigned blocks = (unsigned)((C + kWavesPerBlock - 1) / kWavesPerBlock);
-  hipLaunchKernelGGL(actmax_merge_states_kernel, dim3(blocks), dim3(256), row_smem_bytes(k), st, d_vals, d_ids, C,
-                     (int)k, d_other_vals, d_other_ids, R);
+  SL_LAUNCH(prof, actmax_merge_states_kernel, dim3(blocks), dim3(256), row_smem_bytes(k), st, d_vals, d_ids, C, (int)k,
+            d_other_vals, d_other_ids, R);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -61,7 +61,7 @@ constexpr size_t kLdsBudget = 64 * 1024;
 
 }  // namespace
 
-int actmax_update_aten(uint16_t* d_vals, int64_t* d_ids, int64_t C, int64_t k, const uint16_t* d_cand,
+int actmax_update_aten(ProfScope& prof, uint16_t* d_vals, int64_t* d_ids, int64_t C, int64_t k, const uint16_t* d_cand,
                        const int64_t* d_sample_ids, int64_t id_base, int64_t B, void* d_ws, size_t ws_bytes,
                        hipStream_t st) {
   const int64_t n = k + B;
@@ -77,8 +77,8 @@ int actmax_update_aten(uint16_t* d_vals, int64_t* d_ids, int64_t C, int64_t k, c
   const unsigned blocks = (unsigned)((C + rpb - 1) / rpb);
   int64_t* ws_ids = reinterpret_cast<int64_t*>(d_ws);
   uint16_t* ws_vals = reinterpret_cast<uint16_t*>(ws_ids + C * k);
-  hipLaunchKernelGGL(actmax_update_aten_kernel, dim3(blocks), dim3(64), (size_t)n * rpb * 4, st, d_vals, d_ids, C,
-                     (int)k, d_cand, d_sample_ids, id_base, (int)B, rpb, ws_ids, ws_vals);
+  SL_LAUNCH(prof, actmax_update_aten_kernel, dim3(blocks), dim3(64), (size_t)n * rpb * 4, st, d_vals, d_ids, C, (int)k,
+            d_cand, d_sample_ids, id_base, (int)B, rpb, ws_ids, ws_vals);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
 }

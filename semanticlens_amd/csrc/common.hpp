@@ -1,5 +1,6 @@
 // Shared host/device helpers for libsemanticlens_hip.so (gfx950 only).
 #pragma once
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -32,14 +33,22 @@ int hip_fail(hipError_t e, const char* what);
     }                                \
   } while (0)
 
-// ---- event-bracketed launches (measurement, include/semanticlens_amd.h sl_prof_*) -------
+// ---- per-dispatch timing (measurement, include/semanticlens_amd.h sl_prof_*) -------------
+// When profiling is on, a ProfScope owns one (start, stop) event pair and SL_LAUNCH hands it to
+// hipExtLaunchKernelGGL, which stamps the events with the dispatch's own begin/end times (the same
+// timestamps rocprofv3's kernel trace reports) instead of bracketing the launch with stream events.
 struct ProfScope {
   ProfScope(int family, hipStream_t s, double work);
-  ~ProfScope();
-  int fam;
-  hipStream_t stream;
-  void* rec;
+  hipEvent_t start, stop;  // nullptr when profiling is off
 };
+
+#define SL_LAUNCH(prof, kernel, grid, block, shmem, stream, ...)                                             \
+  do {                                                                                                       \
+    if ((prof).start)                                                                                        \
+      hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, (prof).start, (prof).stop, 0, __VA_ARGS__);  \
+    else                                                                                                     \
+      hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                   \
+  } while (0)
 
 inline int num_cus() {
   static int n = [] {

@@ -227,11 +227,11 @@ int cosine_matrix_nt(const float* A, int64_t M, const float* B, int64_t N, int64
   ProfScope prof(SL_PROF_GEMM, st, 2.0 * (double)M * (double)N * (double)K);
   const bool vec = (K % 4 == 0) && (((uintptr_t)A | (uintptr_t)B) & 15) == 0;
   if (vec)
-    hipLaunchKernelGGL(cosine_gemm_nt_kernel<true>, dim3((unsigned)(tm * tn)), dim3(256), 0, st, A, B, ra, rb, M, N, K,
-                       out, (int)tn);
+    SL_LAUNCH(prof, cosine_gemm_nt_kernel<true>, dim3((unsigned)(tm * tn)), dim3(256), 0, st, A, B, ra, rb, M, N, K, out,
+              (int)tn);
   else
-    hipLaunchKernelGGL(cosine_gemm_nt_kernel<false>, dim3((unsigned)(tm * tn)), dim3(256), 0, st, A, B, ra, rb, M, N,
-                       K, out, (int)tn);
+    SL_LAUNCH(prof, cosine_gemm_nt_kernel<false>, dim3((unsigned)(tm * tn)), dim3(256), 0, st, A, B, ra, rb, M, N, K, out,
+              (int)tn);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -46,11 +46,11 @@ int launch_gather(const float* d_emb, int64_t n_local, int64_t D, const int64_t*
   const int64_t cap = (int64_t)num_cus() * 16;
   if (blocks > cap) blocks = cap;
   if (vec)
-    hipLaunchKernelGGL(gather_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, d_emb, n_local, D, d_ids,
-                       n_ids, row_offset, n_total, d_out, d_err_flag);
+    SL_LAUNCH(prof, gather_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, d_emb, n_local, D, d_ids, n_ids,
+              row_offset, n_total, d_out, d_err_flag);
   else
-    hipLaunchKernelGGL(gather_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, d_emb, n_local, D, d_ids,
-                       n_ids, row_offset, n_total, d_out, d_err_flag);
+    SL_LAUNCH(prof, gather_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, d_emb, n_local, D, d_ids, n_ids,
+              row_offset, n_total, d_out, d_err_flag);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256) void generic_reduce_kernel(const void* __restr
 }
 
 template <int G, int U, int OP>
-void launch_rowreduce(const float* x, int64_t R, int S, uint16_t* cand, float* outf, hipStream_t st) {
+void launch_rowreduce(ProfScope& prof, const float* x, int64_t R, int S, uint16_t* cand, float* outf, hipStream_t st) {
   constexpr int RPT = kWave / G;
   const int64_t ntasks = (R + RPT - 1) / RPT;
   const int64_t nbatch = (ntasks + U - 1) / U;
@@ -526,95 +526,94 @@ void launch_rowreduce(const float* x, int64_t R, int S, uint16_t* cand, float* o
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   if ((R * (int64_t)S) % 4 == 0)
-    hipLaunchKernelGGL((rowreduce_kernel<G, U, OP, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, R, S, cand, outf);
+    SL_LAUNCH(prof, (rowreduce_kernel<G, U, OP, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, R, S, cand, outf);
   else
-    hipLaunchKernelGGL((rowreduce_kernel<G, U, OP, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, R, S, cand, outf);
+    SL_LAUNCH(prof, (rowreduce_kernel<G, U, OP, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, R, S, cand, outf);
 }
 
 template <int G, int U, int OP, bool ALIGNED>
-void launch_rowreduce_fast(const float* x, int64_t R, int S, uint16_t* cand, float* outf, hipStream_t st) {
+void launch_rowreduce_fast(ProfScope& prof, const float* x, int64_t R, int S, uint16_t* cand, float* outf, hipStream_t st) {
   constexpr int RPT = kWave / G;
   const int64_t nbatch = (R / RPT + U - 1) / U;
   int64_t blocks = (nbatch + 3) / 4;
   const int64_t cap = (int64_t)num_cus() * 8;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((rowreduce_fast_kernel<G, U, OP, ALIGNED>), dim3((unsigned)blocks), dim3(256), 0, st, x, R, S, cand,
-                     outf);
+  SL_LAUNCH(prof, (rowreduce_fast_kernel<G, U, OP, ALIGNED>), dim3((unsigned)blocks), dim3(256), 0, st, x, R, S, cand, outf);
 }
 
 template <int OP>
-void dispatch_rowreduce(const float* x, int64_t R, int S, uint16_t* cand, float* outf, hipStream_t st) {
+void dispatch_rowreduce(ProfScope& prof, const float* x, int64_t R, int S, uint16_t* cand, float* outf, hipStream_t st) {
   // pieces needed for a row window: up to (S + 6) / 4
   const int need = (S + 6) / 4;
   // fast path A: rows are whole 16-byte pieces
   if (S % 4 == 0 && S >= 16 && (int64_t)S * 64 * 4 * 8 < (1ll << 31)) {
     const int np = S / 4;
-    if (np <= 4 && R % 16 == 0) return launch_rowreduce_fast<4, 8, OP, true>(x, R, S, cand, outf, st);
-    if (np <= 8 && R % 8 == 0) return launch_rowreduce_fast<8, 8, OP, true>(x, R, S, cand, outf, st);
-    if (np <= 16 && R % 4 == 0) return launch_rowreduce_fast<16, 8, OP, true>(x, R, S, cand, outf, st);
-    if (np <= 32 && R % 2 == 0) return launch_rowreduce_fast<32, 8, OP, true>(x, R, S, cand, outf, st);
-    if (np <= 64) return launch_rowreduce_fast<64, 8, OP, true>(x, R, S, cand, outf, st);
-    return launch_rowreduce_fast<64, 4, OP, true>(x, R, S, cand, outf, st);
+    if (np <= 4 && R % 16 == 0) return launch_rowreduce_fast<4, 8, OP, true>(prof, x, R, S, cand, outf, st);
+    if (np <= 8 && R % 8 == 0) return launch_rowreduce_fast<8, 8, OP, true>(prof, x, R, S, cand, outf, st);
+    if (np <= 16 && R % 4 == 0) return launch_rowreduce_fast<16, 8, OP, true>(prof, x, R, S, cand, outf, st);
+    if (np <= 32 && R % 2 == 0) return launch_rowreduce_fast<32, 8, OP, true>(prof, x, R, S, cand, outf, st);
+    if (np <= 64) return launch_rowreduce_fast<64, 8, OP, true>(prof, x, R, S, cand, outf, st);
+    return launch_rowreduce_fast<64, 4, OP, true>(prof, x, R, S, cand, outf, st);
   }
   // fast path B: short unaligned rows (e.g. 7x7 = 49 floats), >= 4 rows per wave-load
   if (S % 4 != 0 && need <= 16) {
-    if (need <= 4 && R % 16 == 0) return launch_rowreduce_fast<4, 8, OP, false>(x, R, S, cand, outf, st);
-    if (need <= 8 && R % 8 == 0) return launch_rowreduce_fast<8, 8, OP, false>(x, R, S, cand, outf, st);
-    if (R % 4 == 0) return launch_rowreduce_fast<16, 8, OP, false>(x, R, S, cand, outf, st);
+    if (need <= 4 && R % 16 == 0) return launch_rowreduce_fast<4, 8, OP, false>(prof, x, R, S, cand, outf, st);
+    if (need <= 8 && R % 8 == 0) return launch_rowreduce_fast<8, 8, OP, false>(prof, x, R, S, cand, outf, st);
+    if (R % 4 == 0) return launch_rowreduce_fast<16, 8, OP, false>(prof, x, R, S, cand, outf, st);
   }
-  if (need <= 4) launch_rowreduce<4, 8, OP>(x, R, S, cand, outf, st);
-  else if (need <= 8) launch_rowreduce<8, 8, OP>(x, R, S, cand, outf, st);
-  else if (need <= 16) launch_rowreduce<16, 8, OP>(x, R, S, cand, outf, st);
-  else if (need <= 32) launch_rowreduce<32, 8, OP>(x, R, S, cand, outf, st);
-  else if (need <= 64) launch_rowreduce<64, 8, OP>(x, R, S, cand, outf, st);
-  else launch_rowreduce<64, 4, OP>(x, R, S, cand, outf, st);
+  if (need <= 4) launch_rowreduce<4, 8, OP>(prof, x, R, S, cand, outf, st);
+  else if (need <= 8) launch_rowreduce<8, 8, OP>(prof, x, R, S, cand, outf, st);
+  else if (need <= 16) launch_rowreduce<16, 8, OP>(prof, x, R, S, cand, outf, st);
+  else if (need <= 32) launch_rowreduce<32, 8, OP>(prof, x, R, S, cand, outf, st);
+  else if (need <= 64) launch_rowreduce<64, 8, OP>(prof, x, R, S, cand, outf, st);
+  else launch_rowreduce<64, 4, OP>(prof, x, R, S, cand, outf, st);
 }
 
 template <int OP>
-void launch_colreduce(const float* x, int64_t B, int T, int64_t F, int64_t sb, int64_t st_, int t0, int t1,
+void launch_colreduce(ProfScope& prof, const float* x, int64_t B, int T, int64_t F, int64_t sb, int64_t st_, int t0, int t1,
                       float denom, uint16_t* cand, float* outf, hipStream_t st) {
   int64_t blocks = B * ((F + 255) / 256);
   const int64_t cap = (int64_t)num_cus() * 8;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((colreduce_kernel<OP>), dim3((unsigned)blocks), dim3(256), 0, st, x, B, T, F, sb, st_, t0, t1,
-                     denom, cand, outf);
+  SL_LAUNCH(prof, (colreduce_kernel<OP>), dim3((unsigned)blocks), dim3(256), 0, st, x, B, T, F, sb, st_, t0, t1, denom, cand,
+            outf);
 }
 
 template <typename T, int OP>
-void launch_generic(const void* x, int64_t B, int64_t C, int64_t S, int64_t sb, int64_t sc, int64_t ss, int64_t s0,
+void launch_generic(ProfScope& prof, const void* x, int64_t B, int64_t C, int64_t S, int64_t sb, int64_t sc, int64_t ss, int64_t s0,
                     int64_t s1, float denom, uint16_t* cand, float* outf, hipStream_t st) {
   int64_t blocks = (B * C + 255) / 256;
   const int64_t cap = (int64_t)num_cus() * 16;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL((generic_reduce_kernel<T, OP>), dim3((unsigned)blocks), dim3(256), 0, st, x, B, C, S, sb, sc, ss,
-                     s0, s1, denom, cand, outf);
+  SL_LAUNCH(prof, (generic_reduce_kernel<T, OP>), dim3((unsigned)blocks), dim3(256), 0, st, x, B, C, S, sb, sc, ss, s0, s1,
+            denom, cand, outf);
 }
 
 template <int OP>
-void dispatch_generic(const void* x, int dtype, int64_t B, int64_t C, int64_t S, int64_t sb, int64_t sc, int64_t ss,
+void dispatch_generic(ProfScope& prof, const void* x, int dtype, int64_t B, int64_t C, int64_t S, int64_t sb, int64_t sc, int64_t ss,
                       int64_t s0, int64_t s1, float denom, uint16_t* cand, float* outf, hipStream_t st) {
-  if (dtype == SL_F32) launch_generic<float, OP>(x, B, C, S, sb, sc, ss, s0, s1, denom, cand, outf, st);
-  else if (dtype == SL_F16) launch_generic<_Float16, OP>(x, B, C, S, sb, sc, ss, s0, s1, denom, cand, outf, st);
-  else launch_generic<uint16_t, OP>(x, B, C, S, sb, sc, ss, s0, s1, denom, cand, outf, st);
+  if (dtype == SL_F32) launch_generic<float, OP>(prof, x, B, C, S, sb, sc, ss, s0, s1, denom, cand, outf, st);
+  else if (dtype == SL_F16) launch_generic<_Float16, OP>(prof, x, B, C, S, sb, sc, ss, s0, s1, denom, cand, outf, st);
+  else launch_generic<uint16_t, OP>(prof, x, B, C, S, sb, sc, ss, s0, s1, denom, cand, outf, st);
 }
 
 // (B, C, S) with strides -> (B, C): reduce over s in [s0, s1).  Picks the fastest legal path.
 template <int OP>
-int reduce_dispatch(const void* x, int dtype, int64_t B, int64_t C, int64_t S, int64_t sb, int64_t sc, int64_t ss,
+int reduce_dispatch(ProfScope& prof, const void* x, int dtype, int64_t B, int64_t C, int64_t S, int64_t sb, int64_t sc, int64_t ss,
                     int64_t s0, int64_t s1, uint16_t* cand, float* outf, hipStream_t st) {
   const float denom = (float)(s1 - s0);
   const bool aligned = ((uintptr_t)x & 15) == 0;
   const bool full = (s0 == 0 && s1 == S);
   if (dtype == SL_F32 && aligned && full && ss == 1 && sc == S && sb == C * S && S < (1 << 28)) {
-    dispatch_rowreduce<OP>((const float*)x, B * C, (int)S, cand, outf, st);
+    dispatch_rowreduce<OP>(prof, (const float*)x, B * C, (int)S, cand, outf, st);
   } else if (dtype == SL_F32 && aligned && sc == 1 && (C % 4) == 0 && (ss % 4) == 0 && (sb % 4) == 0 &&
              S < (1 << 30)) {
-    launch_colreduce<OP>((const float*)x, B, (int)S, C, sb, ss, (int)s0, (int)s1, denom, cand, outf, st);
+    launch_colreduce<OP>(prof, (const float*)x, B, (int)S, C, sb, ss, (int)s0, (int)s1, denom, cand, outf, st);
   } else {
-    dispatch_generic<OP>(x, dtype, B, C, S, sb, sc, ss, s0, s1, denom, cand, outf, st);
+    dispatch_generic<OP>(prof, x, dtype, B, C, S, sb, sc, ss, s0, s1, denom, cand, outf, st);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "reduce kernel launch");
@@ -638,8 +637,8 @@ SL_API int sl_reduce_conv(const void* d_act, int dtype, int64_t B, int64_t C, in
   if (B * C == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof(SL_PROF_REDUCE, st, (double)B * C * S * dtype_size(dtype));
-  if (agg == SL_CONV_MAX) return reduce_dispatch<OP_MAX>(d_act, dtype, B, C, S, sb, sc, ss, 0, S, d_cand_bf16, d_out_f32, st);
-  return reduce_dispatch<OP_SUM>(d_act, dtype, B, C, S, sb, sc, ss, 0, S, d_cand_bf16, d_out_f32, st);
+  if (agg == SL_CONV_MAX) return reduce_dispatch<OP_MAX>(prof, d_act, dtype, B, C, S, sb, sc, ss, 0, S, d_cand_bf16, d_out_f32, st);
+  return reduce_dispatch<OP_SUM>(prof, d_act, dtype, B, C, S, sb, sc, ss, 0, S, d_cand_bf16, d_out_f32, st);
 }
 
 SL_API int sl_reduce_tokens(const void* d_act, int dtype, int64_t B, int64_t T, int64_t F, int64_t sb, int64_t st_,
@@ -664,12 +663,12 @@ SL_API int sl_reduce_tokens(const void* d_act, int dtype, int64_t B, int64_t T, 
   ProfScope prof(SL_PROF_REDUCE, st, (double)B * (t1 - t0) * F * dtype_size(dtype));
   switch (agg) {
     case SL_TOK_MEAN:
-      return reduce_dispatch<OP_SUM>(d_act, dtype, B, F, T, sb, sf, st_, t0, t1, d_cand_bf16, d_out_f32, st);
+      return reduce_dispatch<OP_SUM>(prof, d_act, dtype, B, F, T, sb, sf, st_, t0, t1, d_cand_bf16, d_out_f32, st);
     case SL_TOK_ABSMEAN:
-      return reduce_dispatch<OP_ABSSUM>(d_act, dtype, B, F, T, sb, sf, st_, t0, t1, d_cand_bf16, d_out_f32, st);
+      return reduce_dispatch<OP_ABSSUM>(prof, d_act, dtype, B, F, T, sb, sf, st_, t0, t1, d_cand_bf16, d_out_f32, st);
     case SL_TOK_ABSMAX:
-      return reduce_dispatch<OP_ABSMAX>(d_act, dtype, B, F, T, sb, sf, st_, t0, t1, d_cand_bf16, d_out_f32, st);
+      return reduce_dispatch<OP_ABSMAX>(prof, d_act, dtype, B, F, T, sb, sf, st_, t0, t1, d_cand_bf16, d_out_f32, st);
     default:  // max, and the single-token pick (max over one element is the element itself)
-      return reduce_dispatch<OP_MAX>(d_act, dtype, B, F, T, sb, sf, st_, t0, t1, d_cand_bf16, d_out_f32, st);
+      return reduce_dispatch<OP_MAX>(prof, d_act, dtype, B, F, T, sb, sf, st_, t0, t1, d_cand_bf16, d_out_f32, st);
   }
 }

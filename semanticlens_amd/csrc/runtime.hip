@@ -31,7 +31,8 @@ static bool g_prof_on = false;
 static std::vector<ProfRec> g_recs;       // live records
 static std::vector<ProfRec> g_free_recs;  // events to reuse
 
-ProfScope::ProfScope(int family, hipStream_t s, double work) : fam(family), stream(s), rec(nullptr) {
+ProfScope::ProfScope(int family, hipStream_t s, double work) : start(nullptr), stop(nullptr) {
+  (void)s;
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfRec r;
@@ -43,16 +44,9 @@ ProfScope::ProfScope(int family, hipStream_t s, double work) : fam(family), stre
   }
   r.fam = family;
   r.work = work;
-  (void)hipEventRecord(r.start, s);
   g_recs.push_back(r);
-  rec = (void*)(uintptr_t)g_recs.size();  // 1-based index
-}
-
-ProfScope::~ProfScope() {
-  if (!rec) return;
-  std::lock_guard<std::mutex> lk(g_prof_mu);
-  size_t idx = (size_t)(uintptr_t)rec - 1;
-  if (idx < g_recs.size()) (void)hipEventRecord(g_recs[idx].stop, stream);
+  start = r.start;
+  stop = r.stop;
 }
 
 }  // namespace sl

@@ -108,8 +108,7 @@ SL_API int sl_clarity(const float* d_V, int64_t C, int64_t n, int64_t D, float* 
   int64_t blocks = C;
   const int64_t cap = (int64_t)num_cus() * 8;
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(clarity_kernel, dim3((unsigned)blocks), dim3(256), (size_t)(n + 4) * 4, st, d_V, C, (int)n, D,
-                     d_out);
+  SL_LAUNCH(prof, clarity_kernel, dim3((unsigned)blocks), dim3(256), (size_t)(n + 4) * 4, st, d_V, C, (int)n, D, d_out);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
 }
