@@ -193,9 +193,12 @@ def polysemanticity(V, random_state: int = 123, n_clusters: int = 2) -> np.ndarr
 
     V = _f32(V)
     C, n, D = V.shape
-    fits = [KMeans(n_clusters=n_clusters, n_init=10, random_state=random_state).fit(e) for e in V]
-    centers = np.stack([f.cluster_centers_ for f in fits], 0).astype(np.float32)
-    poly = 1.0 - clarity(centers).astype(np.float64)
+    # The reference hands sklearn a torch tensor (scores.py:167); torch dtypes have no `.kind`, so
+    # sklearn's check_array falls back to its first accepted dtype and clusters in FLOAT64.
+    fits = [KMeans(n_clusters=n_clusters, n_init=10, random_state=random_state).fit(e.astype(np.float64)) for e in V]
+    centers = np.stack([f.cluster_centers_ for f in fits], 0)  # float64, like the reference's c_centers
+    cn = centers / np.maximum(np.linalg.norm(centers, axis=-1, keepdims=True), 1e-12)
+    poly = 1.0 - ((cn.mean(-2) ** 2).sum(-1) - 1.0 / n_clusters) / (n_clusters - 1) * n_clusters  # clarity_score in f64
     counts = []
     for f in fits:
         cnt = np.unique(f.labels_, return_counts=True)[1]

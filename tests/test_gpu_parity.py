@@ -452,3 +452,34 @@ def test_text_probes_golden(golden):
             for bs in (0, 2):
                 emb = _embed_text_probes(fm, queries[:nq], templates[:nt] or None, bs or None)
                 assert np.array_equal(emb.cpu().numpy(), g[f"q{nq}_t{nt}_bs{bs}"]), (nq, nt, bs)
+
+
+# ---------------------------------------------------------------------------------------------- K9
+def test_polysemanticity_goldens(golden):
+    """scores.py:131-185 incl. the fallback rows (one cluster / a cluster of one sample)."""
+    g = golden("scores")
+    for key in ("P", "P10"):
+        got = scores.polysemanticity_score(torch.from_numpy(g[key]).to(DEV))
+        assert got.dtype == torch.float64 and got.shape == (g[key].shape[0],)
+        np.testing.assert_allclose(got.cpu().numpy(), g[f"{key}_poly"], rtol=0, atol=1e-5)
+    assert scores.polysemanticity_score(torch.from_numpy(g["P10"])).device.type == "cpu"
+
+
+@pytest.mark.parametrize("C,n,D,kind", [(256, 20, 512, "random"), (256, 20, 512, "blobs"), (128, 10, 64, "random"),
+                                        (64, 33, 100, "blobs"), (64, 100, 32, "random"), (96, 20, 1152, "blobs3")])
+def test_polysemanticity_vs_sklearn_oracle(C, n, D, kind):
+    """The Gram-space restatement of sklearn's KMeans picks the same clustering as sklearn itself
+    (oracle.polysemanticity calls scikit-learn): per-component agreement within 1e-5 must be >= 98 %
+    (fp64 Gram arithmetic vs sklearn's coordinate arithmetic can flip numerical near-ties only)."""
+    rng = np.random.RandomState(C + n + D)
+    V = rng.randn(C, n, D).astype(np.float32)
+    if kind.startswith("blobs"):
+        nb = 3 if kind == "blobs3" else 2
+        centers = rng.randn(C, nb, D).astype(np.float32) * 2
+        assign = rng.randint(0, nb, size=(C, n))
+        V = centers[np.arange(C)[:, None], assign] + 0.5 * V
+    want = oracle.polysemanticity(V)
+    got = scores.polysemanticity_score(torch.from_numpy(V).to(DEV)).cpu().numpy()
+    agree = np.abs(got - want) <= 1e-5
+    assert agree.mean() >= 0.98, (kind, agree.mean(), np.abs(got - want).max())
+    assert np.all(got >= -1e-6) and np.all(got <= 2 + 1e-6)
