@@ -125,6 +125,14 @@ def cpu_baseline(args, model_cpu, fm_cpu):
     for n_ in LAYERS:
         grabbed[n_] = 0
     embeds = []
+    with torch.no_grad():  # one untimed batch: thread pools, oneDNN primitive caches
+        u8 = synth.synth_images_u8(torch.arange(10**7, 10**7 + B))
+        model_cpu(synth.normalize_u8(u8, synth.IMAGENET_MEAN, synth.IMAGENET_STD))
+        fm_cpu.encode_image(fm_cpu.preprocess(u8))
+    states.clear()
+    for n_ in LAYERS:
+        grabbed[n_] = 0
+    agg_s[0] = 0.0
     t0 = time.perf_counter()
     with torch.no_grad():
         for s in range(0, n, B):
