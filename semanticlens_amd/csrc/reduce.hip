@@ -17,6 +17,8 @@
 //                   channels_last conv): lanes along F with 16-byte loads, the 4 waves of a
 //                   workgroup split T and combine through LDS.
 //   generic       — any strides / fp16 / bf16: one lane per output element.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace sl {
@@ -311,7 +313,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int G, int U, int OP, bool ALIGNED>
 __global__ __launch_bounds__(256) void rowreduce_fast_kernel(const float* __restrict__ x, int64_t R, int S,
                                                               uint16_t* __restrict__ cand,
-                                                              float* __restrict__ outf) {
+                                                              float* __restrict__ outf, int reverse) {
   constexpr int RPT = kWave / G;
   constexpr bool SUMOP = (OP == OP_SUM || OP == OP_ABSSUM);
   constexpr bool ABS = (OP == OP_ABSMAX || OP == OP_ABSSUM);
@@ -334,7 +336,10 @@ __global__ __launch_bounds__(256) void rowreduce_fast_kernel(const float* __rest
   const bool k0 = (unsigned)(pos0 + 0) < (unsigned)S, k1 = (unsigned)(pos0 + 1) < (unsigned)S;
   const bool k2 = (unsigned)(pos0 + 2) < (unsigned)S, k3 = (unsigned)(pos0 + 3) < (unsigned)S;
 
-  for (int64_t tb = wave0; tb < nbatch; tb += nwaves) {
+  for (int64_t tbi = wave0; tbi < nbatch; tbi += nwaves) {
+    // reverse: walk the tensor from its end, i.e. most-recently-written first when the producer kernel
+    // has just finished and its tail is still in the L2 / Infinity Cache
+    const int64_t tb = reverse ? nbatch - 1 - tbi : tbi;
     const int64_t task0 = tb * U;
     int nu = U;  // tasks that exist in this batch (wave-uniform)
     if (task0 + U > ntask) nu = (int)(ntask - task0);
@@ -539,7 +544,12 @@ void launch_rowreduce_fast(ProfScope& prof, const float* x, int64_t R, int S, ui
   const int64_t cap = (int64_t)num_cus() * 8;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  SL_LAUNCH(prof, (rowreduce_fast_kernel<G, U, OP, ALIGNED>), dim3((unsigned)blocks), dim3(256), 0, st, x, R, S, cand, outf);
+  static const int reverse = [] {
+    const char* e = getenv("SL_REDUCE_REVERSE");
+    return e ? atoi(e) : 0;
+  }();
+  SL_LAUNCH(prof, (rowreduce_fast_kernel<G, U, OP, ALIGNED>), dim3((unsigned)blocks), dim3(256), 0, st, x, R, S, cand, outf,
+            reverse);
 }
 
 template <int OP>

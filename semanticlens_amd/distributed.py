@@ -55,13 +55,24 @@ def unpack_states(buf: torch.Tensor, shapes: list[tuple[int, int]]):
     return list(zip(out_vals, out_ids))
 
 
+def _host_staged(group) -> bool:
+    """gloo cannot move device tensors in every collective: stage through the host (tests / debugging only;
+    the production backend is "nccl" = RCCL, which works on device memory directly)."""
+    return dist.get_backend(group) == "gloo"
+
+
 def all_gather_states(states, group=None):
     """All-gather every rank's packed states.  Returns ``[per-layer (vals (R,C,k), ids (R,C,k))]``."""
     world = dist.get_world_size(group)
     shapes = [tuple(v.shape) for v, _ in states]
     mine = pack_states(states)
-    gathered = torch.empty((world, mine.numel()), dtype=torch.uint8, device=mine.device)
-    dist.all_gather_into_tensor(gathered.reshape(-1), mine, group=group)
+    if _host_staged(group) and mine.is_cuda:
+        host = torch.empty((world, mine.numel()), dtype=torch.uint8)
+        dist.all_gather_into_tensor(host.reshape(-1), mine.cpu(), group=group)
+        gathered = host.to(mine.device)
+    else:
+        gathered = torch.empty((world, mine.numel()), dtype=torch.uint8, device=mine.device)
+        dist.all_gather_into_tensor(gathered.reshape(-1), mine, group=group)
     per_rank = [unpack_states(gathered[r], shapes) for r in range(world)]
     out = []
     for li in range(len(shapes)):
@@ -103,6 +114,10 @@ def gather_concept_db_sharded(embeds_local: torch.Tensor, shard_start: int, n_to
     owns (zeros elsewhere, K5 sharded form) and one all-reduce sums the disjoint pieces.  Exchanges
     ``C*k*D*4`` bytes per layer instead of the whole ``(N, D)`` table."""
     part = N.gather_rows_shard(embeds_local, ids, shard_start, n_total)
+    if _host_staged(group) and part.is_cuda:
+        host = part.cpu()
+        dist.all_reduce(host, group=group)
+        return host.to(part.device)
     dist.all_reduce(part, group=group)
     return part
 
