@@ -25,6 +25,10 @@ namespace {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BN = 128, BK = 32, LDS_LD = BK + 4;
+#ifndef SL_GEMM_XCD_REMAP
+#define SL_GEMM_XCD_REMAP 0  // A/B measured: no gain (the GEMM is MFMA-issue bound, not L2-miss bound)
+#endif
+constexpr bool XCD_REMAP = SL_GEMM_XCD_REMAP != 0;
 
 // one wave per row: 1 / max(||row||, eps)
 __global__ __launch_bounds__(256) void row_inv_norm_kernel(const float* __restrict__ x, int64_t rows, int64_t cols,
@@ -135,8 +139,17 @@ __global__ __launch_bounds__(256) void cosine_gemm_nt_kernel(const float* __rest
   const int w = tid >> 6;
   const int wm = w >> 1, wn = w & 1;  // wave position in the 2x2 grid
   const int li = lane & 31, lh = lane >> 5;
-  const int64_t m0 = (int64_t)(blockIdx.x / tiles_n) * BM;
-  const int64_t n0 = (int64_t)(blockIdx.x % tiles_n) * BN;
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch, speed only), and each XCD has
+  // its own L2.  Give every XCD a contiguous run of tiles so the tiles_n tiles that share one 128-row
+  // panel of A hit it in the same L2 (bijective for any grid size).
+  int tile = blockIdx.x;
+  if (XCD_REMAP) {
+    const int nblk = gridDim.x, xcd = tile & 7, j = tile >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int64_t m0 = (int64_t)(tile / tiles_n) * BM;
+  const int64_t n0 = (int64_t)(tile % tiles_n) * BN;
 
   floatx16 acc[2][2];
 #pragma unroll
@@ -146,20 +159,43 @@ __global__ __launch_bounds__(256) void cosine_gemm_nt_kernel(const float* __rest
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // Per-thread source pointers of its 4 + 4 pieces of a tile, computed once: rows past the matrix edge are
+  // clamped onto the last row (their products land in output rows/cols that are never stored), so a full
+  // K tile needs no bounds checks and no exec-masked branches between the MFMA blocks.
+  const float* pa[4];
+  const float* pb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = tid + i * 256;
+    const int row = piece >> 3, c4 = piece & 7;
+    const int64_t ar = m0 + row < M ? m0 + row : M - 1;
+    const int64_t br = n0 + row < N ? n0 + row : N - 1;
+    pa[i] = A + ar * K + c4 * 4;
+    pb[i] = B + br * K + c4 * 4;
+  }
   float4 ra_[4], rb_[4];
-  load_tile_regs<VEC>(A, M, K, m0, 0, tid, ra_);
-  load_tile_regs<VEC>(B, N, K, n0, 0, tid, rb_);
-  store_tile_lds(sA[0], tid, ra_);
-  store_tile_lds(sB[0], tid, rb_);
-  __syncthreads();
-
-  const int nk = (int)((K + BK - 1) / BK);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {  // next tile's global loads fly during this tile's MFMAs
-      load_tile_regs<VEC>(A, M, K, m0, (int64_t)(kt + 1) * BK, tid, ra_);
-      load_tile_regs<VEC>(B, N, K, n0, (int64_t)(kt + 1) * BK, tid, rb_);
+  // full tile: unconditional 16-byte loads (VEC) — nothing between the MFMA blocks but these 8 loads
+  auto load_full = [&](int64_t k0) {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ra_[i] = *reinterpret_cast<const float4*>(pa[i] + k0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rb_[i] = *reinterpret_cast<const float4*>(pb[i] + k0);
+    } else {
+      load_tile_regs<false>(A, M, K, m0, k0, tid, ra_);
+      load_tile_regs<false>(B, N, K, n0, k0, tid, rb_);
     }
+  };
+  // last, partial tile of K: element-wise and zero filled
+  auto load_tail = [&](int64_t k0) {
+    load_tile_regs<false>(A, M, K, m0, k0, tid, ra_);
+    load_tile_regs<false>(B, N, K, n0, k0, tid, rb_);
+  };
+  auto stage = [&](int buf) {
+    store_tile_lds(sA[buf], tid, ra_);
+    store_tile_lds(sB[buf], tid, rb_);
+  };
+  auto compute = [&](int cur) {
     const float* a_base = sA[cur] + (wm * 64 + li) * LDS_LD + lh * 16;
     const float* b_base = sB[cur] + (wn * 64 + li) * LDS_LD + lh * 16;
 #pragma unroll
@@ -178,11 +214,34 @@ __global__ __launch_bounds__(256) void cosine_gemm_nt_kernel(const float* __rest
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv1[e], acc[1][1], 0, 0, 0);
       }
     }
-    if (kt + 1 < nk) {
-      store_tile_lds(sA[cur ^ 1], tid, ra_);
-      store_tile_lds(sB[cur ^ 1], tid, rb_);
-    }
+  };
+
+  const int nfull = (int)(K / BK);
+  const int ntiles = nfull + ((K % BK) ? 1 : 0);
+  if (ntiles > 0) {
+    if (nfull > 0) load_full(0);
+    else load_tail(0);
+    stage(0);
     __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nfull; ++kt) {  // steady state: tile kt+1 (full) flies in while tile kt is multiplied
+      load_full((int64_t)(kt + 1) * BK);
+      // hipcc otherwise sinks these loads to the end of the MFMA block (shorter live ranges), right in front of
+      // the LDS stores that need them, and the whole HBM/L2 latency is exposed once per tile
+      __builtin_amdgcn_sched_barrier(0);
+      compute(kt & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      stage((kt + 1) & 1);
+      __syncthreads();
+    }
+    if (kt + 1 < ntiles) {  // the partial K tile follows
+      load_tail((int64_t)(kt + 1) * BK);
+      compute(kt & 1);
+      stage((kt + 1) & 1);
+      __syncthreads();
+      ++kt;
+    }
+    compute(kt & 1);
   }
 
   // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
