@@ -337,3 +337,45 @@ def test_aten_order_restatement_matches_libstdcxx(tmp_path):
     res = subprocess.run([str(exe), "20000"], capture_output=True, text=True)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "mismatches=0" in res.stdout
+
+
+# ------------------------------------------------------------- cache files interchange with the reference
+@pytest.mark.skipif(not Path("/root/reference/semanticlens").exists(), reason="reference only exists in the build container")
+def test_cache_files_interchange_with_reference(tmp_path):
+    """a cache written by either package is accepted by the other (names, metadata, dtypes)."""
+    sys.path.insert(0, str(ROOT / "tests" / "golden"))
+    from ref_import import import_reference
+
+    import_reference()
+    from semanticlens.component_visualization import aggregators as ref_agg
+    from semanticlens.component_visualization.activation_caching import ActMaxCache as RefCache
+
+    ours = ActMaxCache(["layer4", "fc"], agg.aggregate_conv_max, 5)
+    for i, name in enumerate(("layer4", "fc")):
+        am = ActMax(5, 6)
+        am.activations = (torch.rand(6, 5) + i).to(torch.bfloat16)
+        am.sample_ids = torch.randint(-1, 1000, (6, 5))
+        ours.cache[name] = am
+    ours.store(tmp_path / "ours")
+    ref = RefCache(["layer4", "fc"], ref_agg.aggregate_conv_max, 5)
+    ref.load(tmp_path / "ours")
+    for name in ("layer4", "fc"):
+        assert torch.equal(ref.cache[name].activations, ours.cache[name].activations)
+        assert torch.equal(ref.cache[name].sample_ids, ours.cache[name].sample_ids)
+    ref.store(tmp_path / "theirs")
+    back = ActMaxCache(["layer4", "fc"], agg.aggregate_conv_max, 5)
+    back.load(tmp_path / "theirs")
+    assert torch.equal(back["fc"].activations, ours["fc"].activations)
+    assert sorted(p.name for p in (tmp_path / "ours").iterdir()) == sorted(p.name for p in (tmp_path / "theirs").iterdir())
+    import json
+    import struct
+
+    def parse(path):  # safetensors: u64 header length, JSON header, payload
+        raw = path.read_bytes()
+        (n,) = struct.unpack("<Q", raw[:8])
+        return json.loads(raw[8 : 8 + n]), raw[8 + n :]
+
+    for name in sorted(p.name for p in (tmp_path / "ours").iterdir()):
+        ho, po = parse(tmp_path / "ours" / name)
+        ht, pt = parse(tmp_path / "theirs" / name)
+        assert ho == ht and po == pt  # same header (metadata key order is unordered in safetensors) and same bytes
