@@ -427,6 +427,14 @@ __global__ __launch_bounds__(256) void rowreduce_fast_kernel(const float* __rest
   }
 }
 
+// streaming (read-once) 16-byte load with the nt cache policy, like the buffer loads of rowreduce_fast
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ inline float4 nt_load4(const float* p) {
+  const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+#define SL_NT_LOAD4(p) nt_load4(p)
+
 // ---- colreduce: out[b][f] = op_t x[b][t][f], f contiguous ------------------------------------
 // One workgroup (4 waves) per (b, 256-float chunk of F); waves split T; LDS combine.
 template <int OP>
@@ -453,14 +461,14 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
       for (; t + 28 < t_end; t += 32) {  // 8 loads in flight per lane
         float4 v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(base + (int64_t)(t + 4 * j) * st);
+        for (int j = 0; j < 8; ++j) v[j] = SL_NT_LOAD4(base + (int64_t)(t + 4 * j) * st);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           a0.add(v[j].x, true); a1.add(v[j].y, true); a2.add(v[j].z, true); a3.add(v[j].w, true);
         }
       }
       for (; t < t_end; t += 4) {
-        float4 v = *reinterpret_cast<const float4*>(base + (int64_t)t * st);
+        float4 v = SL_NT_LOAD4(base + (int64_t)t * st);
         a0.add(v.x, true); a1.add(v.y, true); a2.add(v.z, true); a3.add(v.w, true);
       }
     }
