@@ -306,11 +306,14 @@ __device__ inline float group_allreduce_asm(float v) {
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#ifndef SL_BIG_U
+#define SL_BIG_U 4
+#endif
 #ifndef SL_LOAD_AUX
 #define SL_LOAD_AUX 2  // cache-policy bits of the streaming loads: 2 = nt (read-once stream; +4..10 % over 0, A/B measured)
 #endif
 
-template <int G, int U, int OP, bool ALIGNED>
+template <int G, int U, int OP, bool ALIGNED, int AUX>
 __global__ __launch_bounds__(256) void rowreduce_fast_kernel(const float* __restrict__ x, int64_t R, int S,
                                                               uint16_t* __restrict__ cand,
                                                               float* __restrict__ outf, int reverse) {
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(256) void rowreduce_fast_kernel(const float* __rest
       float4 v[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, (int)((uint32_t)u * task_bytes), SL_LOAD_AUX);
+        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, (int)((uint32_t)u * task_bytes), AUX);
         v[u] = make_float4(bits_f32(w[0]), bits_f32(w[1]), bits_f32(w[2]), bits_f32(w[3]));
       }
 #pragma unroll
@@ -556,8 +559,20 @@ void launch_rowreduce_fast(ProfScope& prof, const float* x, int64_t R, int S, ui
     const char* e = getenv("SL_REDUCE_REVERSE");
     return e ? atoi(e) : 0;
   }();
-  SL_LAUNCH(prof, (rowreduce_fast_kernel<G, U, OP, ALIGNED>), dim3((unsigned)blocks), dim3(256), 0, st, x, R, S, cand, outf,
-            reverse);
+  // Cache policy of the streaming loads.  nt (read-once) is +4..10 % on inputs that come from HBM.  An input
+  // the producer kernel wrote a moment ago and that fits the 256 MiB Infinity Cache is better read with the
+  // default policy (measured 39.4 vs 41.6 us for 205 MB, 17.4 vs 17.9 us for 103 MB); above that size the
+  // producer's dirty lines are being evicted while we read and nt wins again (80 vs 100 us for 411 MB).
+  static const int64_t nt_min_bytes = [] {
+    const char* e = getenv("SL_NT_MIN_BYTES");
+    return e ? (int64_t)atoll(e) : (int64_t)256 << 20;
+  }();
+  if (R * (int64_t)S * 4 >= nt_min_bytes)
+    SL_LAUNCH(prof, (rowreduce_fast_kernel<G, U, OP, ALIGNED, SL_LOAD_AUX>), dim3((unsigned)blocks), dim3(256), 0, st, x, R, S,
+              cand, outf, reverse);
+  else
+    SL_LAUNCH(prof, (rowreduce_fast_kernel<G, U, OP, ALIGNED, 0>), dim3((unsigned)blocks), dim3(256), 0, st, x, R, S, cand,
+              outf, reverse);
 }
 
 template <int OP>
