@@ -162,6 +162,37 @@ size_t sl_poly2means_ws_bytes(int64_t C, int64_t n, int64_t D);
 int sl_template_mean(const float* d_E, const float* d_E0, int64_t Q, int64_t T, int64_t D, float* d_out,
                      void* stream);
 
+/* ---- K11: primitives of a native CLIP-family transformer tower ----------------
+ * The reference's OpenClip.encode_image / encode_text (foundation_models/clip.py:103-135) forward to
+ * the third-party open_clip model; these entry points run the same pre-LN transformer arithmetic in
+ * fp32 on the device (orchestrated by semanticlens_amd/foundation_models/native_clip.py). */
+#define SL_ACT_NONE 0
+#define SL_ACT_GELU 1      /* exact erf GELU (torch.nn.GELU()) */
+#define SL_ACT_QUICKGELU 2 /* x * sigmoid(1.702 x) (OpenAI CLIP checkpoints) */
+/* out = act(x W^T + bias) (+ residual): x (M,K), W (N,K) row-major (torch Linear.weight), bias (N) or
+ * NULL, residual (M,ldo) or NULL (may alias out), out row stride ldo >= N.  fp32-input MFMA GEMM.
+ * Row scatter (patch embedding): when rows_per_group > 0, row r is written to
+ *   (r / rows_per_group) * group_stride + row_offset + r % rows_per_group
+ * and d_rowadd[(row_offset + r % rows_per_group), :] of a (T,N) table (positional embedding) is added. */
+int sl_linear(const float* d_x, int64_t M, int64_t K, const float* d_w, int64_t N, const float* d_bias, int act,
+              const float* d_residual, float* d_out, int64_t ldo, int64_t rows_per_group, int64_t group_stride,
+              int64_t row_offset, const float* d_rowadd, void* stream);
+/* LayerNorm over the last dim (biased variance, like torch.nn.LayerNorm); row strides in elements. */
+int sl_layernorm(const float* d_x, int64_t rows, int64_t cols, int64_t x_row_stride, const float* d_gamma,
+                 const float* d_beta, float eps, float* d_out, int64_t out_row_stride, void* stream);
+/* softmax(q k^T / sqrt(head_dim)) v per (batch, head); d_qkv (B*T, 3*H*head_dim) rows [q | k | v]
+ * (torch MultiheadAttention in_proj layout), out (B*T, H*head_dim); causal != 0 masks keys j > i. */
+int sl_attention(const float* d_qkv, int64_t B, int64_t T, int64_t H, int64_t head_dim, int causal, float* d_out,
+                 void* stream);
+/* (B,C,Hi,Wi) image -> (B*(Hi/P)*(Wi/P), C*P*P) patch rows, k = c*P*P + py*P + px (Conv2d weight order). */
+int sl_patchify(const float* d_img, int64_t B, int64_t C, int64_t Hi, int64_t Wi, int64_t P, float* d_out, void* stream);
+/* out[g * group_stride_elems + c] = v[c] + add[c] for g < G (class-token row of every image). */
+int sl_broadcast_row(const float* d_v, const float* d_add, int64_t G, int64_t group_stride_elems, int64_t N, float* d_out,
+                     void* stream);
+/* out[b][t][:] = table[ids[b][t]][:] + pos[t][:]  (token + positional embedding of the text tower). */
+int sl_embed_tokens(const float* d_table, int64_t vocab, const int64_t* d_ids, int64_t B, int64_t T, int64_t W,
+                    const float* d_pos, float* d_out, void* stream);
+
 /* ---- measurement --------------------------------------------------------------------------
  * When enabled, every launch of a profiled kernel family is bracketed by HIP events on its
  * own stream.  sl_prof_read synchronises those events and returns the totals. */

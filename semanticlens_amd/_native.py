@@ -23,6 +23,7 @@ SL_TOK_MEAN, SL_TOK_ABSMEAN, SL_TOK_MAX, SL_TOK_ABSMAX, SL_TOK_TOKEN = 0, 1, 2, 
 SL_TIES_TOTAL, SL_TIES_ATEN = 0, 1
 SL_MAX_SLOTS = 16
 SL_PROF_REDUCE, SL_PROF_MERGE, SL_PROF_GEMM, SL_PROF_GATHER, SL_PROF_SCORES = 0, 1, 2, 3, 4
+SL_ACT_NONE, SL_ACT_GELU, SL_ACT_QUICKGELU = 0, 1, 2
 TIE_MODES = {"total": SL_TIES_TOTAL, "aten": SL_TIES_ATEN}
 
 _DTYPES = {torch.float32: SL_F32, torch.float16: SL_F16, torch.bfloat16: SL_BF16}
@@ -54,6 +55,12 @@ SIGNATURES = {
     "sl_template_mean": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "sl_poly2means": (_int, [_vp, _i64, _i64, _i64, _vp, _int, _vp, _int, _vp, _vp, _vp, _sz, _vp]),
     "sl_poly2means_ws_bytes": (_sz, [_i64, _i64, _i64]),
+    "sl_linear": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "sl_layernorm": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, ctypes.c_float, _vp, _i64, _vp]),
+    "sl_attention": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp]),
+    "sl_patchify": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "sl_broadcast_row": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "sl_embed_tokens": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "sl_prof_enable": (_int, [_int]),
     "sl_prof_reset": (_int, []),
     "sl_prof_read": (_int, [_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)]),
@@ -353,4 +360,70 @@ def poly2means(V: torch.Tensor, first_center, rand, replace_empty_clusters: bool
     if rc == -3:
         raise NotImplementedError(lib().sl_last_error().decode())
     _check(rc, "sl_poly2means")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# K11: native transformer-tower primitives (all on torch's current stream, fp32, contiguous)
+# ------------------------------------------------------------------------------------------------
+def linear(x, w, bias=None, act=SL_ACT_NONE, residual=None, out=None, scatter=None, rowadd=None):
+    """out = act(x @ w.T + bias) (+ residual).  x (M,K), w (N,K).  ``scatter=(rows_per_group, group_stride,
+    row_offset)`` writes row r to (r // rpg) * group_stride + row_offset + r % rpg of ``out`` (+ ``rowadd`` rows)."""
+    M, K = x.shape
+    Nn = w.shape[0]
+    if out is None:
+        out = torch.empty((M, Nn), dtype=torch.float32, device=x.device)
+    rpg, gs, ro = scatter if scatter is not None else (0, 0, 0)
+    with torch.cuda.device(x.device):
+        rc = lib().sl_linear(_ptr(x), M, K, _ptr(w), Nn, _ptr(bias), act, _ptr(residual), _ptr(out), out.stride(0) if out.ndim == 2 else Nn,
+                             rpg, gs, ro, _ptr(rowadd), _stream(x))
+    _check(rc, "sl_linear")
+    return out
+
+
+def layernorm(x, gamma, beta, eps, out=None, rows=None, x_row_stride=None):
+    cols = x.shape[-1]
+    rows = rows if rows is not None else x.numel() // cols
+    xs = x_row_stride if x_row_stride is not None else cols
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib().sl_layernorm(_ptr(x), rows, cols, xs, _ptr(gamma), _ptr(beta), float(eps), _ptr(out), cols, _stream(x))
+    _check(rc, "sl_layernorm")
+    return out
+
+
+def attention(qkv, B, T, H, head_dim, causal, out=None):
+    if out is None:
+        out = torch.empty((B * T, H * head_dim), dtype=torch.float32, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        rc = lib().sl_attention(_ptr(qkv), B, T, H, head_dim, 1 if causal else 0, _ptr(out), _stream(qkv))
+    _check(rc, "sl_attention")
+    return out
+
+
+def patchify(img, P, out=None):
+    B, C, Hi, Wi = img.shape
+    if out is None:
+        out = torch.empty((B * (Hi // P) * (Wi // P), C * P * P), dtype=torch.float32, device=img.device)
+    with torch.cuda.device(img.device):
+        rc = lib().sl_patchify(_ptr(img), B, C, Hi, Wi, P, _ptr(out), _stream(img))
+    _check(rc, "sl_patchify")
+    return out
+
+
+def broadcast_row(v, add, G, group_stride_elems, out):
+    with torch.cuda.device(out.device):
+        rc = lib().sl_broadcast_row(_ptr(v), _ptr(add), G, group_stride_elems, v.numel(), _ptr(out), _stream(out))
+    _check(rc, "sl_broadcast_row")
+
+
+def embed_tokens(table, ids, pos, out=None):
+    B, T = ids.shape
+    vocab, W = table.shape
+    if out is None:
+        out = torch.empty((B * T, W), dtype=torch.float32, device=table.device)
+    with torch.cuda.device(table.device):
+        rc = lib().sl_embed_tokens(_ptr(table), vocab, _ptr(ids), B, T, W, _ptr(pos), _ptr(out), _stream(table))
+    _check(rc, "sl_embed_tokens")
     return out

@@ -1,0 +1,290 @@
+// K11 — primitives of a native CLIP-family ViT tower.
+//
+// The reference's OpenClip.encode_image / encode_text (foundation_models/clip.py:103-135) only forward
+// to the third-party open_clip model; its arithmetic is a standard pre-LN transformer:
+//   tokens -> ln_pre -> L x [ x += out_proj(MHA(ln_1(x))) ; x += c_proj(gelu(c_fc(ln_2(x)))) ] -> ln_post -> proj
+// These kernels run that tower in fp32 on the device: every linear layer is the fp32-input MFMA GEMM of
+// gemm_f32.hpp with bias / GELU / residual (and, for the patch embedding, the token scatter + positional
+// add) fused into its epilogue; LayerNorm, attention and patch extraction are small bandwidth-bound kernels.
+// The orchestration (weights, layer loop) lives in semanticlens_amd/foundation_models/native_clip.py.
+#include "gemm_f32.hpp"
+
+namespace sl {
+namespace {
+
+// ---- linear: out = act(x W^T + b) (+ residual), optional row scatter for the patch embedding ----------
+template <int ACT, bool RES, bool REMAP>
+struct LinearEpi {
+  const float* bias;  // (N) or nullptr
+  const float* res;   // (M, ldo) or nullptr; may alias out (same element read then written by one lane)
+  float* out;
+  int64_t ldo;
+  int64_t rpg, gstride, roff;  // REMAP: out row = (r / rpg) * gstride + roff + r % rpg
+  const float* rowadd;         // REMAP: (roff + r % rpg, col) of this (T, N) table is added (positional embedding)
+  int64_t N;
+  __device__ inline float column(int64_t col) const { return bias ? bias[col] : 0.f; }
+  __device__ inline void store(int64_t row, int64_t col, float acc, float b) const {
+    float v = acc + b;
+    if constexpr (ACT == SL_ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    if constexpr (ACT == SL_ACT_QUICKGELU) v = v / (1.f + expf(-1.702f * v));
+    int64_t orow = row;
+    if constexpr (REMAP) {
+      const int64_t g = row / rpg, i = row % rpg;
+      orow = g * gstride + roff + i;
+      if (rowadd) v += rowadd[(roff + i) * N + col];
+    }
+    if constexpr (RES) v += res[orow * ldo + col];
+    out[orow * ldo + col] = v;
+  }
+};
+
+template <int ACT, bool RES, bool REMAP>
+int run_linear(ProfScope& prof, const float* x, int64_t M, int64_t K, const float* w, int64_t N, const float* bias,
+               const float* res, float* out, int64_t ldo, int64_t rpg, int64_t gstride, int64_t roff,
+               const float* rowadd, hipStream_t st) {
+  LinearEpi<ACT, RES, REMAP> epi{bias, res, out, ldo, rpg, gstride, roff, rowadd, N};
+  return gemm::launch_gemm_nt(prof, x, M, w, N, K, epi, st);
+}
+
+// ---- LayerNorm over the last dim: one wave per row, three passes over the (L1-resident) row ---------------
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t rows, int cols,
+                                                         int64_t xs, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps,
+                                                         float* __restrict__ out, int64_t os) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t r = wave; r < rows; r += nw) {
+    const float* p = x + r * xs;
+    float s = 0.f;
+    for (int i = lane; i < cols; i += 64) s += p[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float mean = s / (float)cols;
+    float v = 0.f;
+    for (int i = lane; i < cols; i += 64) {
+      const float d = p[i] - mean;
+      v += d * d;
+    }
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    const float rstd = 1.f / sqrtf(v / (float)cols + eps);
+    float* o = out + r * os;
+    for (int i = lane; i < cols; i += 64) o[i] = (p[i] - mean) * rstd * gamma[i] + beta[i];
+  }
+}
+
+// ---- multi-head attention, head_dim 64: one wave per (batch, head); lane = query row ----------------------
+// qkv: (B*T, 3*H*64) rows [q | k | v], head h at columns h*64.  softmax(q k^T / sqrt(64)) v, optional causal mask.
+constexpr int kDh = 64;
+__global__ __launch_bounds__(64) void attention_kernel(const float* __restrict__ qkv, int T, int H, int causal,
+                                                        float* __restrict__ out) {
+  extern __shared__ __align__(16) float smem[];
+  float* sK = smem;                       // T x 64
+  float* sV = smem + (size_t)T * kDh;     // T x 64
+  float* sP = smem + (size_t)2 * T * kDh; // T x 64 lanes (scores of the current 64-row block)
+  const int lane = threadIdx.x;
+  const int64_t b = blockIdx.x / H;
+  const int h = blockIdx.x % H;
+  const int64_t ld = 3ll * H * kDh;
+  const float* base = qkv + b * T * ld + h * kDh;
+  for (int e = lane; e < T * (kDh / 4); e += 64) {  // K and V of this head into LDS
+    const int t = e / (kDh / 4), c = e % (kDh / 4);
+    reinterpret_cast<float4*>(sK)[e] = *reinterpret_cast<const float4*>(base + t * ld + (int64_t)H * kDh + c * 4);
+    reinterpret_cast<float4*>(sV)[e] = *reinterpret_cast<const float4*>(base + t * ld + 2ll * H * kDh + c * 4);
+  }
+  __syncthreads();
+  for (int r0 = 0; r0 < T; r0 += 64) {
+    const int i = r0 + lane;
+    const bool active = i < T;
+    float q[kDh];
+#pragma unroll
+    for (int c = 0; c < kDh / 4; ++c) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (active) v = *reinterpret_cast<const float4*>(base + (int64_t)i * ld + c * 4);
+      q[4 * c + 0] = v.x * 0.125f; q[4 * c + 1] = v.y * 0.125f; q[4 * c + 2] = v.z * 0.125f; q[4 * c + 3] = v.w * 0.125f;
+    }
+    const int jmax = causal ? (r0 + 64 < T ? r0 + 64 : T) : T;  // keys any lane of this block may need
+    float m = -__builtin_huge_valf();
+    for (int j = 0; j < jmax; ++j) {
+      const float4* kj = reinterpret_cast<const float4*>(sK + (size_t)j * kDh);  // same address in all lanes: broadcast
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < kDh / 4; ++c) {
+        const float4 kv = kj[c];
+        s += q[4 * c] * kv.x + q[4 * c + 1] * kv.y + q[4 * c + 2] * kv.z + q[4 * c + 3] * kv.w;
+      }
+      if (causal && j > i) s = -__builtin_huge_valf();
+      sP[(size_t)j * 64 + lane] = s;
+      m = fmaxf(m, s);
+    }
+    float denom = 0.f;
+    float o[kDh];
+#pragma unroll
+    for (int d = 0; d < kDh; ++d) o[d] = 0.f;
+    for (int j = 0; j < jmax; ++j) {
+      const float p = expf(sP[(size_t)j * 64 + lane] - m);
+      denom += p;
+      const float4* vj = reinterpret_cast<const float4*>(sV + (size_t)j * kDh);
+#pragma unroll
+      for (int c = 0; c < kDh / 4; ++c) {
+        const float4 vv = vj[c];
+        o[4 * c] += p * vv.x; o[4 * c + 1] += p * vv.y; o[4 * c + 2] += p * vv.z; o[4 * c + 3] += p * vv.w;
+      }
+    }
+    if (active) {
+      const float inv = 1.f / denom;
+      float* op = out + (b * T + i) * (int64_t)H * kDh + h * kDh;
+#pragma unroll
+      for (int c = 0; c < kDh / 4; ++c)
+        *reinterpret_cast<float4*>(op + c * 4) = make_float4(o[4 * c] * inv, o[4 * c + 1] * inv, o[4 * c + 2] * inv, o[4 * c + 3] * inv);
+    }
+  }
+}
+
+// ---- patch extraction: (B, C, Hi, Wi) -> (B * gh * gw, C * P * P), k = c*P*P + py*P + px (conv weight order) --
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, int64_t B, int C, int Hi, int Wi,
+                                                        int P, float* __restrict__ out) {
+  const int gh = Hi / P, gw = Wi / P;
+  const int64_t kdim = (int64_t)C * P * P;
+  const int64_t total4 = B * gh * gw * kdim / 4;  // P % 4 == 0
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t idx = e * 4;
+    const int64_t row = idx / kdim;
+    const int k = (int)(idx % kdim);
+    const int c = k / (P * P), py = (k / P) % P, px = k % P;
+    const int64_t bb = row / (gh * gw);
+    const int pr = (int)(row % (gh * gw));
+    const int gy = pr / gw, gx = pr % gw;
+    const float* src = img + ((bb * C + c) * Hi + gy * P + py) * (int64_t)Wi + gx * P + px;
+    reinterpret_cast<float4*>(out)[e] = *reinterpret_cast<const float4*>(src);
+  }
+}
+
+// out[g * gstride + row] = v[:] (+ add[:]) for every group g: the class token row of every image
+__global__ __launch_bounds__(256) void broadcast_row_kernel(const float* __restrict__ v, const float* __restrict__ add,
+                                                             int64_t G, int64_t gstride_elems, int N,
+                                                             float* __restrict__ out) {
+  const int64_t total = G * N;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t g = e / N;
+    const int c = (int)(e % N);
+    out[g * gstride_elems + c] = v[c] + (add ? add[c] : 0.f);
+  }
+}
+
+// token embedding lookup + positional embedding: out[b][t][:] = table[ids[b][t]][:] + pos[t][:]
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const float* __restrict__ table, int64_t vocab,
+                                                            const int64_t* __restrict__ ids, int64_t B, int T, int W,
+                                                            const float* __restrict__ pos, float* __restrict__ out) {
+  const int64_t total = B * T * (int64_t)W;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e % W);
+    const int64_t bt = e / W;
+    const int t = (int)(bt % T);
+    int64_t id = ids[bt];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    out[e] = table[id * W + c] + pos[(int64_t)t * W + c];
+  }
+}
+
+int64_t grid_for(int64_t items) {
+  int64_t blocks = (items + 255) / 256;
+  const int64_t cap = (int64_t)num_cus() * 16;
+  if (blocks > cap) blocks = cap;
+  return blocks < 1 ? 1 : blocks;
+}
+
+}  // namespace
+}  // namespace sl
+
+using namespace sl;
+
+SL_API int sl_linear(const float* d_x, int64_t M, int64_t K, const float* d_w, int64_t N, const float* d_bias, int act,
+                     const float* d_residual, float* d_out, int64_t ldo, int64_t rows_per_group, int64_t group_stride,
+                     int64_t row_offset, const float* d_rowadd, void* stream) {
+  SL_REQUIRE(M >= 0 && K >= 0 && N >= 0 && ldo >= N, "sl_linear: bad shape");
+  SL_REQUIRE(act >= SL_ACT_NONE && act <= SL_ACT_QUICKGELU, "sl_linear: bad activation %d", act);
+  if (M * N == 0) return 0;
+  SL_REQUIRE(d_x && d_w && d_out, "sl_linear: null pointer");
+  const bool remap = rows_per_group > 0;
+  SL_REQUIRE(!(remap && (act != SL_ACT_NONE || d_residual)), "sl_linear: row scatter supports neither activation nor residual");
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope prof(SL_PROF_GEMM, st, 2.0 * (double)M * (double)N * (double)K);
+#define SL_RUN(A_, R_, P_) \
+  return run_linear<A_, R_, P_>(prof, d_x, M, K, d_w, N, d_bias, d_residual, d_out, ldo, rows_per_group, group_stride, row_offset, d_rowadd, st)
+  if (remap) SL_RUN(SL_ACT_NONE, false, true);
+  if (d_residual) {
+    if (act == SL_ACT_NONE) SL_RUN(SL_ACT_NONE, true, false);
+    if (act == SL_ACT_GELU) SL_RUN(SL_ACT_GELU, true, false);
+    SL_RUN(SL_ACT_QUICKGELU, true, false);
+  }
+  if (act == SL_ACT_NONE) SL_RUN(SL_ACT_NONE, false, false);
+  if (act == SL_ACT_GELU) SL_RUN(SL_ACT_GELU, false, false);
+  SL_RUN(SL_ACT_QUICKGELU, false, false);
+#undef SL_RUN
+}
+
+SL_API int sl_layernorm(const float* d_x, int64_t rows, int64_t cols, int64_t x_row_stride, const float* d_gamma,
+                        const float* d_beta, float eps, float* d_out, int64_t out_row_stride, void* stream) {
+  SL_REQUIRE(rows >= 0 && cols >= 1 && cols < (1 << 30), "sl_layernorm: bad shape");
+  if (rows == 0) return 0;
+  SL_REQUIRE(d_x && d_gamma && d_beta && d_out, "sl_layernorm: null pointer");
+  int64_t blocks = (rows + 3) / 4;
+  const int64_t cap = (int64_t)num_cus() * 8;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_x, rows, (int)cols,
+                     x_row_stride, d_gamma, d_beta, eps, d_out, out_row_stride);
+  SL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+SL_API int sl_attention(const float* d_qkv, int64_t B, int64_t T, int64_t H, int64_t head_dim, int causal, float* d_out,
+                        void* stream) {
+  SL_REQUIRE(B >= 0 && T >= 1 && H >= 1, "sl_attention: bad shape");
+  SL_REQUIRE(head_dim == kDh, "sl_attention: head_dim=%lld (only 64 is built)", (long long)head_dim);
+  SL_REQUIRE(T <= 256, "sl_attention: sequence length %lld exceeds 256", (long long)T);
+  if (B == 0) return 0;
+  SL_REQUIRE(d_qkv && d_out, "sl_attention: null pointer");
+  SL_REQUIRE(B * H < (1ll << 31), "sl_attention: too many heads");
+  const size_t smem = (size_t)T * kDh * 4 * 2 + (size_t)T * 64 * 4;
+  if (smem > 64 * 1024)
+    SL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(attention_kernel, dim3((unsigned)(B * H)), dim3(64), smem, (hipStream_t)stream, d_qkv, (int)T, (int)H,
+                     causal, d_out);
+  SL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+SL_API int sl_patchify(const float* d_img, int64_t B, int64_t C, int64_t Hi, int64_t Wi, int64_t P, float* d_out,
+                       void* stream) {
+  SL_REQUIRE(B >= 0 && C >= 1 && P >= 4 && P % 4 == 0 && Hi % P == 0 && Wi % P == 0, "sl_patchify: bad geometry");
+  if (B == 0) return 0;
+  SL_REQUIRE(d_img && d_out, "sl_patchify: null pointer");
+  SL_REQUIRE((((uintptr_t)d_img | (uintptr_t)d_out) & 15) == 0 && Wi % 4 == 0, "sl_patchify: needs 16-byte aligned rows");
+  const int64_t total4 = B * C * Hi * Wi / 4;
+  hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)grid_for(total4)), dim3(256), 0, (hipStream_t)stream, d_img, B, (int)C,
+                     (int)Hi, (int)Wi, (int)P, d_out);
+  SL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+SL_API int sl_broadcast_row(const float* d_v, const float* d_add, int64_t G, int64_t group_stride_elems, int64_t N,
+                            float* d_out, void* stream) {
+  SL_REQUIRE(G >= 0 && N >= 1, "sl_broadcast_row: bad shape");
+  if (G == 0) return 0;
+  SL_REQUIRE(d_v && d_out, "sl_broadcast_row: null pointer");
+  hipLaunchKernelGGL(broadcast_row_kernel, dim3((unsigned)grid_for(G * N)), dim3(256), 0, (hipStream_t)stream, d_v, d_add, G,
+                     group_stride_elems, (int)N, d_out);
+  SL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+SL_API int sl_embed_tokens(const float* d_table, int64_t vocab, const int64_t* d_ids, int64_t B, int64_t T, int64_t W,
+                           const float* d_pos, float* d_out, void* stream) {
+  SL_REQUIRE(B >= 0 && T >= 1 && W >= 1 && vocab >= 1, "sl_embed_tokens: bad shape");
+  if (B == 0) return 0;
+  SL_REQUIRE(d_table && d_ids && d_pos && d_out, "sl_embed_tokens: null pointer");
+  hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)grid_for(B * T * W)), dim3(256), 0, (hipStream_t)stream, d_table,
+                     vocab, d_ids, B, (int)T, (int)W, d_pos, d_out);
+  SL_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,207 @@
+"""NativeClip — a CLIP-family foundation model whose towers run on the package's own HIP kernels.
+
+The reference's ``OpenClip.encode_image`` / ``encode_text`` (foundation_models/clip.py:103-135) call straight
+into the third-party ``open_clip`` torch model.  ``NativeClip`` wraps any such ``AbstractVLM`` (tokenizer and
+preprocessing stay the wrapped object's), reads the weights out of its torch modules once, and runs the
+pre-LN transformer towers through the C ABI (K11: ``sl_linear`` = fp32-input MFMA GEMM with bias / GELU /
+residual / patch-scatter epilogues, ``sl_layernorm``, ``sl_attention``, ``sl_patchify``, ``sl_embed_tokens``).
+Everything is fp32, so features agree with the torch modules to ~1e-5 relative; it plugs into ``Lens`` and
+``ActivationComponentVisualizer`` like any other ``AbstractVLM``.
+
+Supported layout (probed by attribute, the names open_clip's ``VisionTransformer`` / ``TextTransformer`` and
+``synth.SyntheticClip`` use): ``conv1`` (patch embedding, no bias), ``class_embedding``, positional embedding,
+``ln_pre``, blocks with ``ln_1`` / ``attn`` (``torch.nn.MultiheadAttention``) / ``ln_2`` / ``mlp`` (Linear, GELU or
+QuickGELU, Linear), ``ln_post`` / ``ln_final``, projection matrices; head_dim 64.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from semanticlens_amd import _native as N
+from semanticlens_amd.foundation_models.base import AbstractVLM
+
+
+def _f32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def _first(obj, *names):
+    for n in names:
+        cur = obj
+        ok = True
+        for part in n.split("."):
+            if not hasattr(cur, part):
+                ok = False
+                break
+            cur = getattr(cur, part)
+        if ok and cur is not None:
+            return cur
+    raise AttributeError(f"none of {names} found on {type(obj).__name__}")
+
+
+class _Block:
+    """Weights of one pre-LN residual block, as flat fp32 device tensors."""
+
+    def __init__(self, blk: nn.Module, device):
+        attn: nn.MultiheadAttention = blk.attn
+        if not isinstance(attn, nn.MultiheadAttention) or attn.in_proj_weight is None:
+            raise TypeError("NativeClip expects torch.nn.MultiheadAttention blocks with a packed in_proj_weight")
+        self.heads = attn.num_heads
+        self.width = attn.embed_dim
+        if self.width // self.heads != 64:
+            raise ValueError(f"head_dim {self.width // self.heads} is not supported (64 only)")
+        self.ln1 = (_f32(blk.ln_1.weight, device), _f32(blk.ln_1.bias, device), blk.ln_1.eps)
+        self.ln2 = (_f32(blk.ln_2.weight, device), _f32(blk.ln_2.bias, device), blk.ln_2.eps)
+        self.w_qkv, self.b_qkv = _f32(attn.in_proj_weight, device), _f32(attn.in_proj_bias, device)
+        self.w_o, self.b_o = _f32(attn.out_proj.weight, device), _f32(attn.out_proj.bias, device)
+        linears = [m for m in blk.mlp.modules() if isinstance(m, nn.Linear)]
+        if len(linears) != 2:
+            raise TypeError("NativeClip expects an MLP of two Linear layers")
+        self.w_fc, self.b_fc = _f32(linears[0].weight, device), _f32(linears[0].bias, device)
+        self.w_pr, self.b_pr = _f32(linears[1].weight, device), _f32(linears[1].bias, device)
+        acts = [m for m in blk.mlp.modules() if not isinstance(m, (nn.Linear, nn.Sequential)) and m is not blk.mlp]
+        name = type(acts[0]).__name__.lower() if acts else "gelu"
+        self.act = N.SL_ACT_QUICKGELU if "quick" in name else N.SL_ACT_GELU
+
+
+class _Tower:
+    """L residual blocks over a (B*T, W) fp32 token matrix."""
+
+    def __init__(self, blocks, device):
+        self.blocks = [_Block(b, device) for b in blocks]
+        self.width = self.blocks[0].width
+        self.heads = self.blocks[0].heads
+
+    def forward(self, x: torch.Tensor, B: int, T: int, causal: bool) -> torch.Tensor:
+        M, W = x.shape
+        h = torch.empty_like(x)
+        qkv = torch.empty((M, 3 * W), dtype=torch.float32, device=x.device)
+        att = torch.empty_like(x)
+        hid = torch.empty((M, self.blocks[0].w_fc.shape[0]), dtype=torch.float32, device=x.device)
+        for blk in self.blocks:
+            N.layernorm(x, *blk.ln1, out=h)
+            N.linear(h, blk.w_qkv, blk.b_qkv, out=qkv)
+            N.attention(qkv, B, T, blk.heads, 64, causal, out=att)
+            N.linear(att, blk.w_o, blk.b_o, residual=x, out=x)  # x += out_proj(attn)
+            N.layernorm(x, *blk.ln2, out=h)
+            N.linear(h, blk.w_fc, blk.b_fc, act=blk.act, out=hid)
+            N.linear(hid, blk.w_pr, blk.b_pr, residual=x, out=x)  # x += c_proj(gelu(c_fc))
+        return x
+
+
+class NativeVisionTower:
+    def __init__(self, visual: nn.Module, blocks, device):
+        conv = visual.conv1
+        if conv.bias is not None or conv.kernel_size != conv.stride:
+            raise TypeError("NativeClip expects a bias-free patch embedding with stride == kernel size")
+        self.patch = conv.kernel_size[0]
+        self.width = conv.out_channels
+        self.w_patch = _f32(conv.weight.reshape(self.width, -1), device)  # (W, C*P*P)
+        self.cls = _f32(visual.class_embedding, device)
+        self.pos = _f32(_first(visual, "positional_embedding", "positional_embedding_v"), device)
+        ln_pre, ln_post = visual.ln_pre, visual.ln_post
+        self.ln_pre = (_f32(ln_pre.weight, device), _f32(ln_pre.bias, device), ln_pre.eps)
+        self.ln_post = (_f32(ln_post.weight, device), _f32(ln_post.bias, device), ln_post.eps)
+        proj = _first(visual, "proj", "proj_v")
+        self.w_proj = _f32(proj.t(), device)  # features = x @ proj  ->  Linear weight (D, W)
+        self.tower = _Tower(blocks, device)
+
+    @torch.no_grad()
+    def __call__(self, img: torch.Tensor) -> torch.Tensor:
+        img = N.to_device(img).to(torch.float32).contiguous()
+        B = img.shape[0]
+        n_patch = (img.shape[2] // self.patch) * (img.shape[3] // self.patch)
+        T = n_patch + 1
+        if T != self.pos.shape[0]:
+            raise ValueError(f"image gives {T} tokens, positional embedding has {self.pos.shape[0]}")
+        W = self.width
+        patches = N.patchify(img, self.patch)
+        x = torch.empty((B * T, W), dtype=torch.float32, device=img.device)
+        # patch embedding GEMM; its epilogue scatters row (b, p) to token row b*T + 1 + p and adds pos[1 + p]
+        N.linear(patches, self.w_patch, out=x, scatter=(n_patch, T, 1), rowadd=self.pos)
+        N.broadcast_row(self.cls, self.pos[0], B, T * W, x)  # token 0 = class embedding + pos[0]
+        h = N.layernorm(x, *self.ln_pre)
+        h = self.tower.forward(h, B, T, causal=False)
+        pooled = N.layernorm(h, *self.ln_post, rows=B, x_row_stride=T * W)  # class-token rows only
+        return N.linear(pooled, self.w_proj)
+
+
+class NativeTextTower:
+    def __init__(self, model: nn.Module, blocks, device):
+        self.table = _f32(model.token_embedding.weight, device)
+        self.pos = _f32(_first(model, "positional_embedding", "positional_embedding_t"), device)
+        ln = model.ln_final
+        self.ln_final = (_f32(ln.weight, device), _f32(ln.bias, device), ln.eps)
+        proj = _first(model, "text_projection", "proj_t")
+        self.w_proj = _f32(proj.t(), device)
+        self.tower = _Tower(blocks, device)
+
+    @torch.no_grad()
+    def __call__(self, tokens: torch.Tensor) -> torch.Tensor:
+        tokens = N.to_device(tokens).to(torch.int64).contiguous()
+        B, T = tokens.shape
+        x = N.embed_tokens(self.table, tokens, self.pos[:T].contiguous())
+        x = self.tower.forward(x, B, T, causal=True)
+        # features of the end-of-text token (highest id), as CLIP's text tower pools them
+        rows = torch.arange(B, device=tokens.device) * T + tokens.argmax(dim=-1)
+        picked = N.gather_rows(x, rows)
+        pooled = N.layernorm(picked, *self.ln_final)
+        return N.linear(pooled, self.w_proj)
+
+
+class NativeClip(AbstractVLM):
+    """``AbstractVLM`` running ``base``'s CLIP towers on HIP kernels; ``base`` keeps tokenizer + preprocessing."""
+
+    def __init__(self, base, device=None):
+        self.base = base
+        model = base.model
+        dev = torch.device(device) if device is not None else next(model.parameters()).device
+        if dev.type != "cuda":
+            dev = N.default_device()
+        self._device = dev
+        base.to(dev)
+        if hasattr(model, "visual") and hasattr(model.visual, "conv1"):  # open_clip: CLIP.visual is the whole image tower
+            visual, vblocks = model.visual, _first(model.visual, "transformer.resblocks")
+            tblocks = _first(model, "transformer.resblocks")
+        else:  # synth._ClipModel: embedding members on the model, block stacks in .visual / .text
+            visual, vblocks = _SynthVisual(model), model.visual.blocks
+            tblocks = model.text.blocks
+        self.vision = NativeVisionTower(visual, vblocks, dev)
+        try:
+            self.text = NativeTextTower(model, tblocks, dev)
+        except (AttributeError, TypeError, ValueError):
+            self.text = None  # text tower layout not recognised: encode_text stays on the wrapped torch model
+        self.name = "native-" + getattr(base, "name", type(base).__name__)
+
+    @property
+    def device(self):
+        return self._device
+
+    def to(self, device):
+        if torch.device(device).type != "cuda":
+            raise N.NativeLibraryError("NativeClip runs on a HIP device only")
+        return self
+
+    def encode_image(self, img):
+        return self.vision(img)
+
+    def encode_text(self, tokens):
+        if self.text is None:
+            return self.base.encode_text(tokens)
+        return self.text(tokens)
+
+    def preprocess(self, img):
+        return self.base.preprocess(img)
+
+    def tokenize(self, txt, *args, **kwargs):
+        return self.base.tokenize(txt, *args, **kwargs)
+
+
+class _SynthVisual:
+    """Adapter giving ``synth._ClipModel``'s image-tower members the names of open_clip's ``visual`` module."""
+
+    def __init__(self, m):
+        self.conv1, self.class_embedding = m.conv1, m.class_embedding
+        self.positional_embedding = m.positional_embedding_v
+        self.ln_pre, self.ln_post, self.proj = m.ln_pre, m.ln_post, m.proj_v

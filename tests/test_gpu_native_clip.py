@@ -1,0 +1,95 @@
+"""K11: the native transformer towers (HIP kernels through the C ABI) against the torch modules they were built
+from — the same `AbstractVLM` seam the reference's OpenClip sits behind (foundation_models/clip.py:103-135).
+open_clip itself is not installed, so the reference pins shapes only (tests/foundation_models/test_clip.py);
+here parity is torch-module (fp32, same weights) vs native, tolerance 1e-4 of the feature scale."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from semanticlens_amd import _native as N
+from semanticlens_amd.foundation_models.native_clip import NativeClip
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel_err(a, b):
+    return ((a - b).abs().max() / b.abs().max()).item()
+
+
+def test_primitives_against_torch():
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn(300, 200, device=DEV, generator=g)
+    w = torch.randn(130, 200, device=DEV, generator=g) * 0.1
+    b = torch.randn(130, device=DEV, generator=g)
+    r = torch.randn(300, 130, device=DEV, generator=g)
+    ref = x @ w.T + b
+    assert rel_err(N.linear(x, w, b), ref) < 1e-5
+    assert rel_err(N.linear(x, w, b, act=N.SL_ACT_GELU), torch.nn.functional.gelu(ref)) < 1e-5
+    assert rel_err(N.linear(x, w, b, act=N.SL_ACT_QUICKGELU), ref * torch.sigmoid(1.702 * ref)) < 1e-5
+    out = r.clone()
+    N.linear(x, w, b, residual=out, out=out)
+    assert rel_err(out, ref + r) < 1e-5
+    gam, bet = torch.randn(200, device=DEV, generator=g), torch.randn(200, device=DEV, generator=g)
+    assert rel_err(N.layernorm(x, gam, bet, 1e-5), torch.nn.functional.layer_norm(x, (200,), gam, bet, 1e-5)) < 1e-5
+    # attention vs torch.nn.MultiheadAttention (packed in_proj), plain and causal, T below and above one wave
+    for T, causal in ((50, False), (77, True), (130, True), (7, False)):
+        B, H = 3, 2
+        mha = torch.nn.MultiheadAttention(H * 64, H, batch_first=True).to(DEV)
+        xx = torch.randn(B, T, H * 64, device=DEV, generator=g)
+        mask = torch.full((T, T), float("-inf"), device=DEV).triu_(1) if causal else None
+        want = mha(xx, xx, xx, need_weights=False, attn_mask=mask)[0]
+        qkv = N.linear(xx.reshape(B * T, -1), mha.in_proj_weight.detach(), mha.in_proj_bias.detach())
+        att = N.attention(qkv, B, T, H, 64, causal)
+        got = N.linear(att, mha.out_proj.weight.detach(), mha.out_proj.bias.detach()).reshape(B, T, -1)
+        assert rel_err(got, want) < 1e-5, (T, causal)
+    img = torch.randn(2, 3, 32, 64, device=DEV, generator=g)
+    conv = torch.nn.Conv2d(3, 24, 16, 16, bias=False).to(DEV)
+    want = conv(img).flatten(2).transpose(1, 2).reshape(-1, 24)
+    assert rel_err(N.linear(N.patchify(img, 16), conv.weight.detach().reshape(24, -1)), want) < 1e-5
+
+
+@pytest.mark.parametrize("arch", [
+    dict(embed_dim=64, image_size=64, patch=16, v_width=128, v_layers=2, v_heads=2, ctx=16, vocab=49408, t_width=128, t_layers=2, t_heads=2),
+    dict(),  # CLIP ViT-B/32: 12 x 768 image tower (50 tokens), 12 x 512 text tower (77 tokens), 512-d joint space
+])
+def test_native_towers_match_torch_modules(arch):
+    fm = synth.SyntheticClip(device=DEV, seed=3, **arch)
+    nat = NativeClip(fm)
+    size = arch.get("image_size", 224)
+    u8 = synth.synth_images_u8(torch.arange(6, device=DEV), size=size)
+    x = fm.preprocess(u8)
+    want = fm.encode_image(x)
+    got = nat.encode_image(x)
+    assert got.shape == want.shape and got.dtype == torch.float32
+    assert rel_err(got, want) < 1e-4, rel_err(got, want)
+    toks = fm.tokenize(["a photo of a cat", "dog", "a very long prompt with many many words in it " * 3])
+    want_t = fm.encode_text(toks)
+    got_t = nat.encode_text(toks)
+    assert rel_err(got_t, want_t) < 1e-4, rel_err(got_t, want_t)
+    # cosine between the two implementations' features ~ 1
+    cos = torch.nn.functional.cosine_similarity(got, want, dim=-1)
+    assert (1 - cos).abs().max().item() < 1e-6
+
+
+def test_native_clip_drops_into_lens_pipeline():
+    """Same concept_db (within 1e-4 of the embedding scale) whether the AbstractVLM is the torch model or NativeClip."""
+    from semanticlens_amd import Lens
+    from semanticlens_amd.component_visualization import ActivationComponentVisualizer, aggregators
+
+    arch = dict(embed_dim=64, image_size=64, patch=16, v_width=128, v_layers=2, v_heads=2, ctx=16, vocab=49408, t_width=128, t_layers=2, t_heads=2)
+    fm = synth.SyntheticClip(device=DEV, seed=5, **arch)
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 16, 3, padding=1), torch.nn.ReLU()).to(DEV).eval()
+
+    def build():
+        ds_m = synth.SyntheticImageDataset(24, "model", size=64)
+        ds_f = synth.SyntheticImageDataset(24, "fm", size=64)
+        return ActivationComponentVisualizer(model, ds_m, ds_f, ["1"], num_samples=4, aggregate_fn=aggregators.aggregate_conv_max, tie_mode="aten")
+
+    db_torch = Lens(fm, device=DEV).compute_concept_db(build(), batch_size=8)
+    db_native = Lens(NativeClip(fm), device=DEV).compute_concept_db(build(), batch_size=8)
+    assert rel_err(db_native["1"], db_torch["1"]) < 1e-4
+    probe_t = Lens(fm, device=DEV).text_probing(["cat", "dog"], {"1": db_torch["1"].mean(1)})
+    probe_n = Lens(NativeClip(fm), device=DEV).text_probing(["cat", "dog"], {"1": db_native["1"].mean(1)})
+    np.testing.assert_allclose(probe_n["1"].cpu().numpy(), probe_t["1"].cpu().numpy(), rtol=0, atol=1e-4)
