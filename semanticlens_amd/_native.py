@@ -49,6 +49,8 @@ SIGNATURES = {
     "sl_gather_rows_shard": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "sl_similarity": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "sl_similarity_ws_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "sl_similarity_multi": (_int, [_vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _sz, _vp]),
+    "sl_similarity_multi_ws_bytes": (_sz, [_i64, _i64, _vp, _int]),
     "sl_clarity": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "sl_redundancy": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "sl_redundancy_ws_bytes": (_sz, [_i64, _i64, _i64]),
@@ -56,9 +58,11 @@ SIGNATURES = {
     "sl_poly2means": (_int, [_vp, _i64, _i64, _i64, _vp, _int, _vp, _int, _vp, _vp, _vp, _sz, _vp]),
     "sl_poly2means_ws_bytes": (_sz, [_i64, _i64, _i64]),
     "sl_linear": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
-    "sl_layernorm": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, ctypes.c_float, _vp, _i64, _vp]),
-    "sl_attention": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp]),
-    "sl_patchify": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "sl_layernorm": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _i64, _vp]),
+    "sl_attention": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp]),
+    "sl_patchify": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "sl_split_bf16": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "sl_linear_bf16x3": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _int, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "sl_broadcast_row": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "sl_embed_tokens": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "sl_prof_enable": (_int, [_int]),
@@ -280,6 +284,29 @@ def similarity(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def similarity_multi(x: torch.Tensor, ys: list[torch.Tensor]) -> list[torch.Tensor] | None:
+    """``[similarity(x, y) for y in ys]`` with the query normalised/split once.  Returns None when a layer would
+    take one of ``similarity_score``'s shape-quirk branches (the caller then goes layer by layer)."""
+    if x.ndim != 2 or any(y.ndim != 2 or y.shape[1] != x.shape[1] for y in ys):
+        return None
+    Q, K = x.shape
+    if any(y.shape[0] == Q or y.shape[0] == K for y in ys) or not ys:
+        return None
+    xd = _f32c(x)
+    yds = [_f32c(y, xd.device) for y in ys]
+    outs = [torch.empty((Q, y.shape[0]), dtype=torch.float32, device=xd.device) for y in yds]
+    L = len(yds)
+    cs = (_i64 * L)(*[y.shape[0] for y in yds])
+    yp = (_vp * L)(*[y.data_ptr() if y.numel() else None for y in yds])
+    op = (_vp * L)(*[o.data_ptr() if o.numel() else None for o in outs])
+    nbytes = int(lib().sl_similarity_multi_ws_bytes(Q, K, cs, L))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=xd.device)
+    with torch.cuda.device(xd.device):
+        rc = lib().sl_similarity_multi(_ptr(xd), Q, K, yp, cs, L, op, _ptr(ws), nbytes, _stream(xd))
+    _check(rc, "sl_similarity_multi")
+    return outs
+
+
 def clarity(V: torch.Tensor) -> torch.Tensor:
     Vd = _f32c(V)
     lead = Vd.shape[:-2]
@@ -381,35 +408,79 @@ def linear(x, w, bias=None, act=SL_ACT_NONE, residual=None, out=None, scatter=No
     return out
 
 
-def layernorm(x, gamma, beta, eps, out=None, rows=None, x_row_stride=None):
+class Split:
+    """An fp32 matrix carried as two bf16 matrices (hi = bf16(v), lo = bf16(v - hi)): operand of the bf16x3 GEMM."""
+
+    def __init__(self, rows: int, cols: int, device):
+        self.hi = torch.empty((rows, cols), dtype=torch.bfloat16, device=device)
+        self.lo = torch.empty((rows, cols), dtype=torch.bfloat16, device=device)
+        self.shape = (rows, cols)
+
+    @classmethod
+    def of(cls, x: torch.Tensor, row_scale: torch.Tensor | None = None) -> "Split":
+        x = x.contiguous()
+        out = cls(x.shape[0], x.shape[1], x.device)
+        with torch.cuda.device(x.device):
+            rc = lib().sl_split_bf16(_ptr(x), _ptr(row_scale), x.shape[0], x.shape[1], _ptr(out.hi), _ptr(out.lo), _stream(x))
+        _check(rc, "sl_split_bf16")
+        return out
+
+
+def _split_ptrs(sp):
+    return (_ptr(sp.hi), _ptr(sp.lo)) if sp is not None else (_vp(None), _vp(None))
+
+
+def linear3(x: Split, w: Split, bias=None, act=SL_ACT_NONE, residual=None, out=None, out_split: Split | None = None,
+            scatter=None, rowadd=None):
+    """bf16x3 version of :func:`linear`: x, w are :class:`Split` operands; the result is fp32 ``out`` (optionally
+    + residual, or scattered rows) or, with ``out_split``, split bf16 ready to feed the next GEMM."""
+    M, K = x.shape
+    Nn = w.shape[0]
+    dev = x.hi.device
+    if out is None and out_split is None:
+        out = torch.empty((M, Nn), dtype=torch.float32, device=dev)
+    ldo = out.stride(0) if out is not None else Nn
+    rpg, gs, ro = scatter if scatter is not None else (0, 0, 0)
+    oh, ol = _split_ptrs(out_split)
+    with torch.cuda.device(dev):
+        rc = lib().sl_linear_bf16x3(_ptr(x.hi), _ptr(x.lo), M, K, _ptr(w.hi), _ptr(w.lo), Nn, _ptr(bias), act, _ptr(residual),
+                                    _ptr(out), oh, ol, ldo, rpg, gs, ro, _ptr(rowadd), _stream(x.hi))
+    _check(rc, "sl_linear_bf16x3")
+    return out if out is not None else out_split
+
+
+def layernorm(x, gamma, beta, eps, out=None, rows=None, x_row_stride=None, out_split: Split | None = None):
     cols = x.shape[-1]
     rows = rows if rows is not None else x.numel() // cols
     xs = x_row_stride if x_row_stride is not None else cols
-    if out is None:
+    if out is None and out_split is None:
         out = torch.empty((rows, cols), dtype=torch.float32, device=x.device)
+    oh, ol = _split_ptrs(out_split)
     with torch.cuda.device(x.device):
-        rc = lib().sl_layernorm(_ptr(x), rows, cols, xs, _ptr(gamma), _ptr(beta), float(eps), _ptr(out), cols, _stream(x))
+        rc = lib().sl_layernorm(_ptr(x), rows, cols, xs, _ptr(gamma), _ptr(beta), float(eps), _ptr(out), oh, ol, cols, _stream(x))
     _check(rc, "sl_layernorm")
-    return out
+    return out if out is not None else out_split
 
 
-def attention(qkv, B, T, H, head_dim, causal, out=None):
-    if out is None:
+def attention(qkv, B, T, H, head_dim, causal, out=None, out_split: Split | None = None):
+    if out is None and out_split is None:
         out = torch.empty((B * T, H * head_dim), dtype=torch.float32, device=qkv.device)
+    oh, ol = _split_ptrs(out_split)
     with torch.cuda.device(qkv.device):
-        rc = lib().sl_attention(_ptr(qkv), B, T, H, head_dim, 1 if causal else 0, _ptr(out), _stream(qkv))
+        rc = lib().sl_attention(_ptr(qkv), B, T, H, head_dim, 1 if causal else 0, _ptr(out), oh, ol, _stream(qkv))
     _check(rc, "sl_attention")
-    return out
+    return out if out is not None else out_split
 
 
-def patchify(img, P, out=None):
+def patchify(img, P, out=None, out_split: Split | None = None):
     B, C, Hi, Wi = img.shape
-    if out is None:
+    if out is None and out_split is None:
         out = torch.empty((B * (Hi // P) * (Wi // P), C * P * P), dtype=torch.float32, device=img.device)
+    oh, ol = _split_ptrs(out_split)
     with torch.cuda.device(img.device):
-        rc = lib().sl_patchify(_ptr(img), B, C, Hi, Wi, P, _ptr(out), _stream(img))
+        rc = lib().sl_patchify(_ptr(img), B, C, Hi, Wi, P, _ptr(out), oh, ol, _stream(img))
     _check(rc, "sl_patchify")
-    return out
+    return out if out is not None else out_split
 
 
 def broadcast_row(v, add, G, group_stride_elems, out):

@@ -17,6 +17,10 @@
 // 16-lane group land in 16 distinct 16-byte slots of the 256-byte bank row (conflict-free).
 // In one MFMA the two lane halves (lane>>5) consume two different k of the tile; which two is
 // free as long as A and B agree, so half h owns k in [16h, 16h+16) and reads them as float4.
+#include <cstdlib>
+#include <cstring>
+
+#include "gemm_bf16x3.hpp"
 #include "gemm_f32.hpp"
 
 namespace sl {
@@ -31,6 +35,15 @@ struct CosineEpi {
   __device__ inline float column(int64_t col) const { return rb[col]; }
   __device__ inline void store(int64_t row, int64_t col, float acc, float cv) const { out[row * N + col] = acc * ra[row] * cv; }
 };
+// operands were normalised before the bf16 split: the accumulator is the cosine
+struct PlainEpi {
+  float* out;
+  int64_t N;
+  __device__ inline float column(int64_t) const { return 0.f; }
+  __device__ inline void store(int64_t row, int64_t col, float acc, float) const { out[row * N + col] = acc; }
+};
+
+size_t align256_(size_t n) { return (n + 255) & ~(size_t)255; }
 
 // one wave per row: 1 / max(||row||, eps)
 __global__ __launch_bounds__(256) void row_inv_norm_kernel(const float* __restrict__ x, int64_t rows, int64_t cols,
@@ -105,17 +118,83 @@ int launch_inv_norm(const float* x, int64_t rows, int64_t cols, float eps, float
 
 }  // namespace
 
-// out[M][N] = cos(A rows, B rows); ra/rb: scratch for the inverse norms.  Used by K6 and K8.
+// SL_GEMM_MODE=f32    : fp32-input MFMA (exact fp32 products)
+// SL_GEMM_MODE=bf16x3 : split-bf16 on the bf16 matrix cores (gemm_bf16x3.hpp), |error| ~1e-6 on cosines
+bool use_bf16x3() {
+  static const bool v = [] {
+    const char* e = getenv("SL_GEMM_MODE");
+    return !(e && strcmp(e, "f32") == 0);
+  }();
+  return v;
+}
+
+// bytes of split-bf16 scratch for an (R x K) operand: hi + lo
+size_t split_bytes(int64_t R, int64_t K) { return 2 * align256_((size_t)R * (size_t)K * 2); }
+
+// out[M][N] = cos(A rows, B rows).  ra/rb: scratch for the inverse norms; split: scratch of
+// split_bytes(M,K) + split_bytes(N,K) bytes (may be NULL -> fp32 path).  Used by K6 and K8.
 int cosine_matrix_nt(const float* A, int64_t M, const float* B, int64_t N, int64_t K, float* ra, float* rb, float* out,
-                     hipStream_t st) {
+                     void* split, hipStream_t st) {
   if (int rc = launch_inv_norm(A, M, K, 1e-12f, ra, st)) return rc;
-  if (B == A && N == M) {
+  const bool same = (B == A && N == M);
+  if (same) {
     rb = ra;
   } else if (int rc = launch_inv_norm(B, N, K, 1e-12f, rb, st)) {
     return rc;
   }
+  // below K = 64 too few products average the ~2^-16 split error down; those GEMMs are tiny anyway
+  if (split && use_bf16x3() && K % 8 == 0 && K >= 64) {
+    unsigned char* p = (unsigned char*)split;
+    uint16_t* ah = (uint16_t*)p;
+    uint16_t* al = (uint16_t*)(p + align256_((size_t)M * K * 2));
+    uint16_t* bh = ah;
+    uint16_t* bl = al;
+    if (int rc = gemm3::launch_split(A, ra, M, K, ah, al, st)) return rc;  // x_hat = x * rinv, then hi/lo
+    if (!same) {
+      bh = (uint16_t*)(p + split_bytes(M, K));
+      bl = (uint16_t*)(p + split_bytes(M, K) + align256_((size_t)N * K * 2));
+      if (int rc = gemm3::launch_split(B, rb, N, K, bh, bl, st)) return rc;
+    }
+    ProfScope prof(SL_PROF_GEMM, st, 2.0 * (double)M * (double)N * (double)K);
+    return gemm3::launch_gemm3_nt(prof, ah, al, M, bh, bl, N, K, PlainEpi{out, N}, st);
+  }
   ProfScope prof(SL_PROF_GEMM, st, 2.0 * (double)M * (double)N * (double)K);
   return gemm::launch_gemm_nt(prof, A, M, B, N, K, CosineEpi{ra, rb, out, N}, st);
+}
+
+size_t cosine_split_bytes(int64_t M, int64_t N, int64_t K) { return split_bytes(M, K) + split_bytes(N, K); }
+
+// One query matrix against L concept matrices (the per-layer loop of lens.py:206-214): the query is
+// normalised and split once, each layer then costs its own split + one GEMM.
+int cosine_matrix_multi(const float* X, int64_t Q, int64_t K, const float* const* Ys, const int64_t* Cs, int L,
+                        float* const* outs, unsigned char* ws, hipStream_t st) {
+  int64_t cmax = 0;
+  for (int l = 0; l < L; ++l) cmax = Cs[l] > cmax ? Cs[l] : cmax;
+  float* rx = (float*)ws;
+  float* ry = (float*)(ws + align256_((size_t)Q * 4));
+  unsigned char* sp = ws + align256_((size_t)Q * 4) + align256_((size_t)cmax * 4);
+  const bool fast = use_bf16x3() && K % 8 == 0 && K >= 64;
+  if (int rc = launch_inv_norm(X, Q, K, 1e-12f, rx, st)) return rc;
+  uint16_t* xh = (uint16_t*)sp;
+  uint16_t* xl = (uint16_t*)(sp + align256_((size_t)Q * K * 2));
+  uint16_t* yh = (uint16_t*)(sp + split_bytes(Q, K));
+  uint16_t* yl = (uint16_t*)(sp + split_bytes(Q, K) + align256_((size_t)cmax * K * 2));
+  if (fast)
+    if (int rc = gemm3::launch_split(X, rx, Q, K, xh, xl, st)) return rc;
+  for (int l = 0; l < L; ++l) {
+    if (Q * Cs[l] == 0) continue;
+    if (int rc = launch_inv_norm(Ys[l], Cs[l], K, 1e-12f, ry, st)) return rc;
+    ProfScope prof(SL_PROF_GEMM, st, 2.0 * (double)Q * (double)Cs[l] * (double)K);
+    int rc;
+    if (fast) {
+      if ((rc = gemm3::launch_split(Ys[l], ry, Cs[l], K, yh, yl, st))) return rc;
+      rc = gemm3::launch_gemm3_nt(prof, xh, xl, Q, yh, yl, Cs[l], K, PlainEpi{outs[l], Cs[l]}, st);
+    } else {
+      rc = gemm::launch_gemm_nt(prof, X, Q, Ys[l], Cs[l], K, CosineEpi{rx, ry, outs[l], Cs[l]}, st);
+    }
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 }  // namespace sl
@@ -127,6 +206,7 @@ static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 SL_API size_t sl_similarity_ws_bytes(int64_t xr, int64_t xc, int64_t yr, int64_t yc) {
   size_t b = align256((size_t)xr * 4) + align256((size_t)yr * 4);
   if (!(xr == yr && xc == yc) && xc == yr) b += align256((size_t)yr * (size_t)yc * 4);
+  else if (xc == yc) b += cosine_split_bytes(xr, yr, xc);
   return b + 256;
 }
 
@@ -173,6 +253,28 @@ SL_API int sl_similarity(const float* d_x, int64_t xr, int64_t xc, const float* 
   }
   // branch 2: normalize(x) @ normalize(y)^T — the probing GEMM
   if (xr * yr == 0) return 2;
-  if (int rc = cosine_matrix_nt(d_x, xr, d_y, yr, xc, rx, ry, d_out, st)) return rc;
+  void* split = ws + align256((size_t)xr * 4) + align256((size_t)yr * 4);
+  if (int rc = cosine_matrix_nt(d_x, xr, d_y, yr, xc, rx, ry, d_out, split, st)) return rc;
   return 2;
+}
+
+SL_API size_t sl_similarity_multi_ws_bytes(int64_t Q, int64_t K, const int64_t* h_Cs, int L) {
+  int64_t cmax = 0;
+  for (int l = 0; l < L; ++l) cmax = h_Cs[l] > cmax ? h_Cs[l] : cmax;
+  return align256((size_t)Q * 4) + align256((size_t)cmax * 4) + cosine_split_bytes(Q, cmax, K) + 512;
+}
+
+SL_API int sl_similarity_multi(const float* d_x, int64_t Q, int64_t K, const float* const* h_d_ys, const int64_t* h_Cs,
+                               int L, float* const* h_d_outs, void* d_ws, size_t ws_bytes, void* stream) {
+  SL_REQUIRE(Q >= 0 && K >= 0 && L >= 0, "sl_similarity_multi: negative shape");
+  if (L == 0 || Q == 0) return 0;
+  SL_REQUIRE(d_x && h_d_ys && h_Cs && h_d_outs, "sl_similarity_multi: null pointer");
+  for (int l = 0; l < L; ++l) {
+    SL_REQUIRE(h_Cs[l] >= 0 && (h_Cs[l] == 0 || (h_d_ys[l] && h_d_outs[l])), "sl_similarity_multi: bad layer %d", l);
+    // the shape quirks of scores.py:119-123 must not apply to any layer (the caller falls back to sl_similarity)
+    SL_REQUIRE(!(h_Cs[l] == Q) && !(K == h_Cs[l]), "sl_similarity_multi: layer %d hits a shape-quirk branch of similarity_score", l);
+  }
+  SL_REQUIRE(d_ws && ws_bytes >= sl_similarity_multi_ws_bytes(Q, K, h_Cs, L), "sl_similarity_multi: workspace too small");
+  unsigned char* ws = (unsigned char*)(((uintptr_t)d_ws + 255) & ~(uintptr_t)255);
+  return cosine_matrix_multi(d_x, Q, K, h_d_ys, h_Cs, L, h_d_outs, ws, (hipStream_t)stream);
 }

@@ -7,17 +7,27 @@
 // gemm_f32.hpp with bias / GELU / residual (and, for the patch embedding, the token scatter + positional
 // add) fused into its epilogue; LayerNorm, attention and patch extraction are small bandwidth-bound kernels.
 // The orchestration (weights, layer loop) lives in semanticlens_amd/foundation_models/native_clip.py.
+#include "gemm_bf16x3.hpp"
 #include "gemm_f32.hpp"
 
 namespace sl {
 namespace {
 
 // ---- linear: out = act(x W^T + b) (+ residual), optional row scatter for the patch embedding ----------
-template <int ACT, bool RES, bool REMAP>
+// write v as split bf16 (hi = bf16(v), lo = bf16(v - hi)): the operand format of the bf16x3 GEMM
+__device__ inline void store_split(float v, int64_t idx, uint16_t* hi, uint16_t* lo) {
+  const uint16_t h = f32_to_bf16_rne(v);
+  hi[idx] = h;
+  lo[idx] = f32_to_bf16_rne(v - bf16_to_f32(h));
+}
+
+template <int ACT, bool RES, bool REMAP, bool SPLIT = false>
 struct LinearEpi {
   const float* bias;  // (N) or nullptr
   const float* res;   // (M, ldo) or nullptr; may alias out (same element read then written by one lane)
   float* out;
+  uint16_t* out_hi;   // SPLIT: the result goes out as split bf16 instead of fp32
+  uint16_t* out_lo;
   int64_t ldo;
   int64_t rpg, gstride, roff;  // REMAP: out row = (r / rpg) * gstride + roff + r % rpg
   const float* rowadd;         // REMAP: (roff + r % rpg, col) of this (T, N) table is added (positional embedding)
@@ -34,7 +44,8 @@ struct LinearEpi {
       if (rowadd) v += rowadd[(roff + i) * N + col];
     }
     if constexpr (RES) v += res[orow * ldo + col];
-    out[orow * ldo + col] = v;
+    if constexpr (SPLIT) store_split(v, orow * ldo + col, out_hi, out_lo);
+    else out[orow * ldo + col] = v;
   }
 };
 
@@ -42,15 +53,24 @@ template <int ACT, bool RES, bool REMAP>
 int run_linear(ProfScope& prof, const float* x, int64_t M, int64_t K, const float* w, int64_t N, const float* bias,
                const float* res, float* out, int64_t ldo, int64_t rpg, int64_t gstride, int64_t roff,
                const float* rowadd, hipStream_t st) {
-  LinearEpi<ACT, RES, REMAP> epi{bias, res, out, ldo, rpg, gstride, roff, rowadd, N};
+  LinearEpi<ACT, RES, REMAP> epi{bias, res, out, nullptr, nullptr, ldo, rpg, gstride, roff, rowadd, N};
   return gemm::launch_gemm_nt(prof, x, M, w, N, K, epi, st);
+}
+
+template <int ACT, bool RES, bool REMAP, bool SPLIT>
+int run_linear3(ProfScope& prof, const uint16_t* xh, const uint16_t* xl, int64_t M, int64_t K, const uint16_t* wh,
+                const uint16_t* wl, int64_t N, const float* bias, const float* res, float* out, uint16_t* oh, uint16_t* ol,
+                int64_t ldo, int64_t rpg, int64_t gstride, int64_t roff, const float* rowadd, hipStream_t st) {
+  LinearEpi<ACT, RES, REMAP, SPLIT> epi{bias, res, out, oh, ol, ldo, rpg, gstride, roff, rowadd, N};
+  return gemm3::launch_gemm3_nt(prof, xh, xl, M, wh, wl, N, K, epi, st);
 }
 
 // ---- LayerNorm over the last dim: one wave per row, three passes over the (L1-resident) row ---------------
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t rows, int cols,
                                                          int64_t xs, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps,
-                                                         float* __restrict__ out, int64_t os) {
+                                                         float* __restrict__ out, int64_t os, uint16_t* __restrict__ oh,
+                                                         uint16_t* __restrict__ ol) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nw = (int64_t)gridDim.x * 4;
@@ -67,8 +87,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     const float rstd = 1.f / sqrtf(v / (float)cols + eps);
-    float* o = out + r * os;
-    for (int i = lane; i < cols; i += 64) o[i] = (p[i] - mean) * rstd * gamma[i] + beta[i];
+    for (int i = lane; i < cols; i += 64) {
+      const float y = (p[i] - mean) * rstd * gamma[i] + beta[i];
+      if (out) out[r * os + i] = y;
+      if (oh) store_split(y, r * os + i, oh, ol);
+    }
   }
 }
 
@@ -76,7 +99,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // qkv: (B*T, 3*H*64) rows [q | k | v], head h at columns h*64.  softmax(q k^T / sqrt(64)) v, optional causal mask.
 constexpr int kDh = 64;
 __global__ __launch_bounds__(64) void attention_kernel(const float* __restrict__ qkv, int T, int H, int causal,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, uint16_t* __restrict__ oh,
+                                                        uint16_t* __restrict__ ol) {
   extern __shared__ __align__(16) float smem[];
   float* sK = smem;                       // T x 64
   float* sV = smem + (size_t)T * kDh;     // T x 64
@@ -132,17 +156,24 @@ __global__ __launch_bounds__(64) void attention_kernel(const float* __restrict__
     }
     if (active) {
       const float inv = 1.f / denom;
-      float* op = out + (b * T + i) * (int64_t)H * kDh + h * kDh;
+      const int64_t o0 = (b * T + i) * (int64_t)H * kDh + h * kDh;
+      if (out) {
 #pragma unroll
-      for (int c = 0; c < kDh / 4; ++c)
-        *reinterpret_cast<float4*>(op + c * 4) = make_float4(o[4 * c] * inv, o[4 * c + 1] * inv, o[4 * c + 2] * inv, o[4 * c + 3] * inv);
+        for (int c = 0; c < kDh / 4; ++c)
+          *reinterpret_cast<float4*>(out + o0 + c * 4) = make_float4(o[4 * c] * inv, o[4 * c + 1] * inv, o[4 * c + 2] * inv, o[4 * c + 3] * inv);
+      }
+      if (oh) {
+#pragma unroll
+        for (int d = 0; d < kDh; ++d) store_split(o[d] * inv, o0 + d, oh, ol);
+      }
     }
   }
 }
 
 // ---- patch extraction: (B, C, Hi, Wi) -> (B * gh * gw, C * P * P), k = c*P*P + py*P + px (conv weight order) --
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, int64_t B, int C, int Hi, int Wi,
-                                                        int P, float* __restrict__ out) {
+                                                        int P, float* __restrict__ out, uint16_t* __restrict__ oh,
+                                                        uint16_t* __restrict__ ol) {
   const int gh = Hi / P, gw = Wi / P;
   const int64_t kdim = (int64_t)C * P * P;
   const int64_t total4 = B * gh * gw * kdim / 4;  // P % 4 == 0
@@ -155,7 +186,12 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     const int pr = (int)(row % (gh * gw));
     const int gy = pr / gw, gx = pr % gw;
     const float* src = img + ((bb * C + c) * Hi + gy * P + py) * (int64_t)Wi + gx * P + px;
-    reinterpret_cast<float4*>(out)[e] = *reinterpret_cast<const float4*>(src);
+    const float4 v = *reinterpret_cast<const float4*>(src);
+    if (out) reinterpret_cast<float4*>(out)[e] = v;
+    if (oh) {
+      store_split(v.x, idx + 0, oh, ol); store_split(v.y, idx + 1, oh, ol);
+      store_split(v.z, idx + 2, oh, ol); store_split(v.w, idx + 3, oh, ol);
+    }
   }
 }
 
@@ -224,45 +260,46 @@ SL_API int sl_linear(const float* d_x, int64_t M, int64_t K, const float* d_w, i
 }
 
 SL_API int sl_layernorm(const float* d_x, int64_t rows, int64_t cols, int64_t x_row_stride, const float* d_gamma,
-                        const float* d_beta, float eps, float* d_out, int64_t out_row_stride, void* stream) {
+                        const float* d_beta, float eps, float* d_out, uint16_t* d_out_hi, uint16_t* d_out_lo,
+                        int64_t out_row_stride, void* stream) {
   SL_REQUIRE(rows >= 0 && cols >= 1 && cols < (1 << 30), "sl_layernorm: bad shape");
   if (rows == 0) return 0;
-  SL_REQUIRE(d_x && d_gamma && d_beta && d_out, "sl_layernorm: null pointer");
+  SL_REQUIRE(d_x && d_gamma && d_beta && (d_out || (d_out_hi && d_out_lo)), "sl_layernorm: null pointer");
   int64_t blocks = (rows + 3) / 4;
   const int64_t cap = (int64_t)num_cus() * 8;
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_x, rows, (int)cols,
-                     x_row_stride, d_gamma, d_beta, eps, d_out, out_row_stride);
+                     x_row_stride, d_gamma, d_beta, eps, d_out, out_row_stride, d_out_hi, d_out_lo);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
 SL_API int sl_attention(const float* d_qkv, int64_t B, int64_t T, int64_t H, int64_t head_dim, int causal, float* d_out,
-                        void* stream) {
+                        uint16_t* d_out_hi, uint16_t* d_out_lo, void* stream) {
   SL_REQUIRE(B >= 0 && T >= 1 && H >= 1, "sl_attention: bad shape");
   SL_REQUIRE(head_dim == kDh, "sl_attention: head_dim=%lld (only 64 is built)", (long long)head_dim);
   SL_REQUIRE(T <= 256, "sl_attention: sequence length %lld exceeds 256", (long long)T);
   if (B == 0) return 0;
-  SL_REQUIRE(d_qkv && d_out, "sl_attention: null pointer");
+  SL_REQUIRE(d_qkv && (d_out || (d_out_hi && d_out_lo)), "sl_attention: null pointer");
   SL_REQUIRE(B * H < (1ll << 31), "sl_attention: too many heads");
   const size_t smem = (size_t)T * kDh * 4 * 2 + (size_t)T * 64 * 4;
   if (smem > 64 * 1024)
     SL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(attention_kernel, dim3((unsigned)(B * H)), dim3(64), smem, (hipStream_t)stream, d_qkv, (int)T, (int)H,
-                     causal, d_out);
+                     causal, d_out, d_out_hi, d_out_lo);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
 SL_API int sl_patchify(const float* d_img, int64_t B, int64_t C, int64_t Hi, int64_t Wi, int64_t P, float* d_out,
-                       void* stream) {
+                       uint16_t* d_out_hi, uint16_t* d_out_lo, void* stream) {
   SL_REQUIRE(B >= 0 && C >= 1 && P >= 4 && P % 4 == 0 && Hi % P == 0 && Wi % P == 0, "sl_patchify: bad geometry");
   if (B == 0) return 0;
-  SL_REQUIRE(d_img && d_out, "sl_patchify: null pointer");
+  SL_REQUIRE(d_img && (d_out || (d_out_hi && d_out_lo)), "sl_patchify: null pointer");
   SL_REQUIRE((((uintptr_t)d_img | (uintptr_t)d_out) & 15) == 0 && Wi % 4 == 0, "sl_patchify: needs 16-byte aligned rows");
   const int64_t total4 = B * C * Hi * Wi / 4;
   hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)grid_for(total4)), dim3(256), 0, (hipStream_t)stream, d_img, B, (int)C,
-                     (int)Hi, (int)Wi, (int)P, d_out);
+                     (int)Hi, (int)Wi, (int)P, d_out, d_out_hi, d_out_lo);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -287,4 +324,46 @@ SL_API int sl_embed_tokens(const float* d_table, int64_t vocab, const int64_t* d
                      vocab, d_ids, B, (int)T, (int)W, d_pos, d_out);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+SL_API int sl_split_bf16(const float* d_x, const float* d_row_scale, int64_t R, int64_t K, uint16_t* d_hi, uint16_t* d_lo,
+                         void* stream) {
+  SL_REQUIRE(R >= 0 && K >= 0, "sl_split_bf16: negative shape");
+  if (R * K == 0) return 0;
+  SL_REQUIRE(d_x && d_hi && d_lo, "sl_split_bf16: null pointer");
+  return gemm3::launch_split(d_x, d_row_scale, R, K, d_hi, d_lo, (hipStream_t)stream);
+}
+
+SL_API int sl_linear_bf16x3(const uint16_t* d_xh, const uint16_t* d_xl, int64_t M, int64_t K, const uint16_t* d_wh,
+                            const uint16_t* d_wl, int64_t N, const float* d_bias, int act, const float* d_residual,
+                            float* d_out, uint16_t* d_out_hi, uint16_t* d_out_lo, int64_t ldo, int64_t rows_per_group,
+                            int64_t group_stride, int64_t row_offset, const float* d_rowadd, void* stream) {
+  SL_REQUIRE(M >= 0 && K >= 0 && N >= 0 && ldo >= N, "sl_linear_bf16x3: bad shape");
+  SL_REQUIRE(K % 8 == 0, "sl_linear_bf16x3: K must be a multiple of 8");
+  SL_REQUIRE(act >= SL_ACT_NONE && act <= SL_ACT_QUICKGELU, "sl_linear_bf16x3: bad activation %d", act);
+  if (M * N == 0) return 0;
+  const bool split = d_out_hi && d_out_lo;
+  SL_REQUIRE(d_xh && d_xl && d_wh && d_wl && (d_out || split) && !(d_out && split), "sl_linear_bf16x3: null / ambiguous pointers");
+  const bool remap = rows_per_group > 0;
+  SL_REQUIRE(!(remap && (act != SL_ACT_NONE || d_residual || split)), "sl_linear_bf16x3: row scatter is plain fp32 only");
+  SL_REQUIRE(!(split && d_residual), "sl_linear_bf16x3: split output takes no residual");
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope prof(SL_PROF_GEMM, st, 2.0 * (double)M * (double)N * (double)K);
+#define SL_RUN3(A_, R_, P_, S_) \
+  return run_linear3<A_, R_, P_, S_>(prof, d_xh, d_xl, M, K, d_wh, d_wl, N, d_bias, d_residual, d_out, d_out_hi, d_out_lo, ldo, rows_per_group, group_stride, row_offset, d_rowadd, st)
+  if (remap) SL_RUN3(SL_ACT_NONE, false, true, false);
+  if (split) {
+    if (act == SL_ACT_NONE) SL_RUN3(SL_ACT_NONE, false, false, true);
+    if (act == SL_ACT_GELU) SL_RUN3(SL_ACT_GELU, false, false, true);
+    SL_RUN3(SL_ACT_QUICKGELU, false, false, true);
+  }
+  if (d_residual) {
+    if (act == SL_ACT_NONE) SL_RUN3(SL_ACT_NONE, true, false, false);
+    if (act == SL_ACT_GELU) SL_RUN3(SL_ACT_GELU, true, false, false);
+    SL_RUN3(SL_ACT_QUICKGELU, true, false, false);
+  }
+  if (act == SL_ACT_NONE) SL_RUN3(SL_ACT_NONE, false, false, false);
+  if (act == SL_ACT_GELU) SL_RUN3(SL_ACT_GELU, false, false, false);
+  SL_RUN3(SL_ACT_QUICKGELU, false, false, false);
+#undef SL_RUN3
 }

@@ -8,7 +8,8 @@
 namespace sl {
 
 int cosine_matrix_nt(const float* A, int64_t M, const float* B, int64_t N, int64_t K, float* ra, float* rb, float* out,
-                     hipStream_t st);
+                     void* split, hipStream_t st);
+size_t cosine_split_bytes(int64_t M, int64_t N, int64_t K);
 
 namespace {
 
@@ -116,7 +117,7 @@ SL_API int sl_clarity(const float* d_V, int64_t C, int64_t n, int64_t D, float* 
 SL_API size_t sl_redundancy_ws_bytes(int64_t Bt, int64_t C, int64_t D) {
   (void)Bt;
   (void)D;
-  return align256((size_t)C * 4) * 2 + align256((size_t)C * (size_t)C * 4) + 256;
+  return align256((size_t)C * 4) * 2 + align256((size_t)C * (size_t)C * 4) + cosine_split_bytes(C, C, D) + 256;
 }
 
 SL_API int sl_redundancy(const float* d_V, int64_t Bt, int64_t C, int64_t D, float* d_out, void* d_ws, size_t ws_bytes,
@@ -133,7 +134,8 @@ SL_API int sl_redundancy(const float* d_V, int64_t Bt, int64_t C, int64_t D, flo
   float* sims = (float*)(ws + 2 * align256((size_t)C * 4));
   for (int64_t b = 0; b < Bt; ++b) {
     const float* X = d_V + b * C * D;
-    if (int rc = cosine_matrix_nt(X, C, X, C, D, rinv, rinv, sims, st)) return rc;
+    void* split = ws + 2 * align256((size_t)C * 4) + align256((size_t)C * (size_t)C * 4);
+    if (int rc = cosine_matrix_nt(X, C, X, C, D, rinv, rinv, sims, split, st)) return rc;
     int64_t blocks = (C + 3) / 4;
     const int64_t cap = (int64_t)num_cus() * 8;
     if (blocks > cap) blocks = cap;

@@ -5,7 +5,10 @@ into the third-party ``open_clip`` torch model.  ``NativeClip`` wraps any such `
 preprocessing stay the wrapped object's), reads the weights out of its torch modules once, and runs the
 pre-LN transformer towers through the C ABI (K11: ``sl_linear`` = fp32-input MFMA GEMM with bias / GELU /
 residual / patch-scatter epilogues, ``sl_layernorm``, ``sl_attention``, ``sl_patchify``, ``sl_embed_tokens``).
-Everything is fp32, so features agree with the torch modules to ~1e-5 relative; it plugs into ``Lens`` and
+``gemm="bf16x3"`` (default) runs the linear layers as split-bf16 GEMMs on the bf16 matrix cores (three MFMAs per
+product, fp32 accumulate: fp32-class accuracy, ~2.4x the fp32-MFMA rate) with weights split once at construction and
+activations emitted in split form by the producing kernel; ``gemm="f32"`` uses the fp32-input MFMA GEMM.  Either
+way features agree with the torch modules to ~1e-5 relative, and the object plugs into ``Lens`` and
 ``ActivationComponentVisualizer`` like any other ``AbstractVLM``.
 
 Supported layout (probed by attribute, the names open_clip's ``VisionTransformer`` / ``TextTransformer`` and
@@ -43,7 +46,7 @@ def _first(obj, *names):
 class _Block:
     """Weights of one pre-LN residual block, as flat fp32 device tensors."""
 
-    def __init__(self, blk: nn.Module, device):
+    def __init__(self, blk: nn.Module, device, split: bool):
         attn: nn.MultiheadAttention = blk.attn
         if not isinstance(attn, nn.MultiheadAttention) or attn.in_proj_weight is None:
             raise TypeError("NativeClip expects torch.nn.MultiheadAttention blocks with a packed in_proj_weight")
@@ -63,35 +66,51 @@ class _Block:
         acts = [m for m in blk.mlp.modules() if not isinstance(m, (nn.Linear, nn.Sequential)) and m is not blk.mlp]
         name = type(acts[0]).__name__.lower() if acts else "gelu"
         self.act = N.SL_ACT_QUICKGELU if "quick" in name else N.SL_ACT_GELU
+        if split:
+            self.s_qkv, self.s_o = N.Split.of(self.w_qkv), N.Split.of(self.w_o)
+            self.s_fc, self.s_pr = N.Split.of(self.w_fc), N.Split.of(self.w_pr)
 
 
 class _Tower:
-    """L residual blocks over a (B*T, W) fp32 token matrix."""
+    """L residual blocks over a (B*T, W) fp32 token matrix (the residual stream stays fp32 in both modes)."""
 
-    def __init__(self, blocks, device):
-        self.blocks = [_Block(b, device) for b in blocks]
+    def __init__(self, blocks, device, split: bool):
+        self.split = split
+        self.blocks = [_Block(b, device, split) for b in blocks]
         self.width = self.blocks[0].width
         self.heads = self.blocks[0].heads
 
     def forward(self, x: torch.Tensor, B: int, T: int, causal: bool) -> torch.Tensor:
         M, W = x.shape
-        h = torch.empty_like(x)
+        F = self.blocks[0].w_fc.shape[0]
         qkv = torch.empty((M, 3 * W), dtype=torch.float32, device=x.device)
+        if self.split:
+            h, att, hid = N.Split(M, W, x.device), N.Split(M, W, x.device), N.Split(M, F, x.device)
+            for blk in self.blocks:
+                N.layernorm(x, *blk.ln1, out_split=h)
+                N.linear3(h, blk.s_qkv, blk.b_qkv, out=qkv)
+                N.attention(qkv, B, T, blk.heads, 64, causal, out_split=att)
+                N.linear3(att, blk.s_o, blk.b_o, residual=x, out=x)  # x += out_proj(attn)
+                N.layernorm(x, *blk.ln2, out_split=h)
+                N.linear3(h, blk.s_fc, blk.b_fc, act=blk.act, out_split=hid)  # GELU output leaves as split bf16
+                N.linear3(hid, blk.s_pr, blk.b_pr, residual=x, out=x)  # x += c_proj(gelu(c_fc))
+            return x
+        h = torch.empty_like(x)
         att = torch.empty_like(x)
-        hid = torch.empty((M, self.blocks[0].w_fc.shape[0]), dtype=torch.float32, device=x.device)
+        hid = torch.empty((M, F), dtype=torch.float32, device=x.device)
         for blk in self.blocks:
             N.layernorm(x, *blk.ln1, out=h)
             N.linear(h, blk.w_qkv, blk.b_qkv, out=qkv)
             N.attention(qkv, B, T, blk.heads, 64, causal, out=att)
-            N.linear(att, blk.w_o, blk.b_o, residual=x, out=x)  # x += out_proj(attn)
+            N.linear(att, blk.w_o, blk.b_o, residual=x, out=x)
             N.layernorm(x, *blk.ln2, out=h)
             N.linear(h, blk.w_fc, blk.b_fc, act=blk.act, out=hid)
-            N.linear(hid, blk.w_pr, blk.b_pr, residual=x, out=x)  # x += c_proj(gelu(c_fc))
+            N.linear(hid, blk.w_pr, blk.b_pr, residual=x, out=x)
         return x
 
 
 class NativeVisionTower:
-    def __init__(self, visual: nn.Module, blocks, device):
+    def __init__(self, visual: nn.Module, blocks, device, split: bool):
         conv = visual.conv1
         if conv.bias is not None or conv.kernel_size != conv.stride:
             raise TypeError("NativeClip expects a bias-free patch embedding with stride == kernel size")
@@ -105,7 +124,10 @@ class NativeVisionTower:
         self.ln_post = (_f32(ln_post.weight, device), _f32(ln_post.bias, device), ln_post.eps)
         proj = _first(visual, "proj", "proj_v")
         self.w_proj = _f32(proj.t(), device)  # features = x @ proj  ->  Linear weight (D, W)
-        self.tower = _Tower(blocks, device)
+        self.split = split
+        if split:
+            self.s_patch = N.Split.of(self.w_patch)
+        self.tower = _Tower(blocks, device, split)
 
     @torch.no_grad()
     def __call__(self, img: torch.Tensor) -> torch.Tensor:
@@ -116,10 +138,14 @@ class NativeVisionTower:
         if T != self.pos.shape[0]:
             raise ValueError(f"image gives {T} tokens, positional embedding has {self.pos.shape[0]}")
         W = self.width
-        patches = N.patchify(img, self.patch)
         x = torch.empty((B * T, W), dtype=torch.float32, device=img.device)
         # patch embedding GEMM; its epilogue scatters row (b, p) to token row b*T + 1 + p and adds pos[1 + p]
-        N.linear(patches, self.w_patch, out=x, scatter=(n_patch, T, 1), rowadd=self.pos)
+        if self.split:
+            patches = N.patchify(img, self.patch, out_split=N.Split(B * n_patch, self.w_patch.shape[1], img.device))
+            N.linear3(patches, self.s_patch, out=x, scatter=(n_patch, T, 1), rowadd=self.pos)
+        else:
+            patches = N.patchify(img, self.patch)
+            N.linear(patches, self.w_patch, out=x, scatter=(n_patch, T, 1), rowadd=self.pos)
         N.broadcast_row(self.cls, self.pos[0], B, T * W, x)  # token 0 = class embedding + pos[0]
         h = N.layernorm(x, *self.ln_pre)
         h = self.tower.forward(h, B, T, causal=False)
@@ -128,14 +154,14 @@ class NativeVisionTower:
 
 
 class NativeTextTower:
-    def __init__(self, model: nn.Module, blocks, device):
+    def __init__(self, model: nn.Module, blocks, device, split: bool):
         self.table = _f32(model.token_embedding.weight, device)
         self.pos = _f32(_first(model, "positional_embedding", "positional_embedding_t"), device)
         ln = model.ln_final
         self.ln_final = (_f32(ln.weight, device), _f32(ln.bias, device), ln.eps)
         proj = _first(model, "text_projection", "proj_t")
         self.w_proj = _f32(proj.t(), device)
-        self.tower = _Tower(blocks, device)
+        self.tower = _Tower(blocks, device, split)
 
     @torch.no_grad()
     def __call__(self, tokens: torch.Tensor) -> torch.Tensor:
@@ -153,7 +179,10 @@ class NativeTextTower:
 class NativeClip(AbstractVLM):
     """``AbstractVLM`` running ``base``'s CLIP towers on HIP kernels; ``base`` keeps tokenizer + preprocessing."""
 
-    def __init__(self, base, device=None):
+    def __init__(self, base, device=None, gemm: str = "bf16x3"):
+        if gemm not in ("bf16x3", "f32"):
+            raise ValueError("gemm must be 'bf16x3' or 'f32'")
+        split = gemm == "bf16x3"
         self.base = base
         model = base.model
         dev = torch.device(device) if device is not None else next(model.parameters()).device
@@ -167,12 +196,12 @@ class NativeClip(AbstractVLM):
         else:  # synth._ClipModel: embedding members on the model, block stacks in .visual / .text
             visual, vblocks = _SynthVisual(model), model.visual.blocks
             tblocks = model.text.blocks
-        self.vision = NativeVisionTower(visual, vblocks, dev)
+        self.vision = NativeVisionTower(visual, vblocks, dev, split)
         try:
-            self.text = NativeTextTower(model, tblocks, dev)
+            self.text = NativeTextTower(model, tblocks, dev, split)
         except (AttributeError, TypeError, ValueError):
             self.text = None  # text tower layout not recognised: encode_text stays on the wrapped torch model
-        self.name = "native-" + getattr(base, "name", type(base).__name__)
+        self.name = f"native-{gemm}-" + getattr(base, "name", type(base).__name__)
 
     @property
     def device(self):

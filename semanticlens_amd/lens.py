@@ -76,6 +76,13 @@ def _embed_text_probes(fm, query: list[str], templates: list[str] | None, batch_
 def _probe(query: torch.Tensor, aggregated_concept_db):
     if isinstance(aggregated_concept_db, torch.Tensor):
         return similarity_score(query.to(aggregated_concept_db.device), aggregated_concept_db)
+    keys = list(aggregated_concept_db)
+    values = [aggregated_concept_db[k] for k in keys]
+    # all layers in one native call (query normalised + split once) when none of them hits a shape quirk
+    if values and all(isinstance(v, torch.Tensor) for v in values) and len({v.device for v in values}) == 1:
+        outs = N.similarity_multi(query, values)
+        if outs is not None:
+            return {k: o.to(v.device) for k, o, v in zip(keys, outs, values)}
     return {key: similarity_score(query.to(value.device), value) for key, value in aggregated_concept_db.items()}
 
 

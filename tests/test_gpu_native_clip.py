@@ -48,15 +48,29 @@ def test_primitives_against_torch():
     conv = torch.nn.Conv2d(3, 24, 16, 16, bias=False).to(DEV)
     want = conv(img).flatten(2).transpose(1, 2).reshape(-1, 24)
     assert rel_err(N.linear(N.patchify(img, 16), conv.weight.detach().reshape(24, -1)), want) < 1e-5
+    # split-bf16 operands: hi + lo reconstructs the value to ~2^-17, and the bf16x3 GEMM matches fp32 results
+    sp = N.Split.of(x)
+    assert ((sp.hi.float() + sp.lo.float()) - x).abs().max().item() <= 2.0 ** -16 * x.abs().max().item()
+    ws = N.Split.of(w)
+    assert rel_err(N.linear3(sp, ws, b), ref) < 1e-5
+    assert rel_err(N.linear3(sp, ws, b, act=N.SL_ACT_GELU), torch.nn.functional.gelu(ref)) < 1e-5
+    out = r.clone()
+    N.linear3(sp, ws, b, residual=out, out=out)
+    assert rel_err(out, ref + r) < 1e-5
+    o2 = N.linear3(sp, ws, b, out_split=N.Split(300, 130, DEV))
+    assert rel_err(o2.hi.float() + o2.lo.float(), ref) < 1e-5
+    l2 = N.layernorm(x, gam, bet, 1e-5, out_split=N.Split(300, 200, DEV))
+    assert rel_err(l2.hi.float() + l2.lo.float(), torch.nn.functional.layer_norm(x, (200,), gam, bet, 1e-5)) < 1e-5
 
 
 @pytest.mark.parametrize("arch", [
     dict(embed_dim=64, image_size=64, patch=16, v_width=128, v_layers=2, v_heads=2, ctx=16, vocab=49408, t_width=128, t_layers=2, t_heads=2),
     dict(),  # CLIP ViT-B/32: 12 x 768 image tower (50 tokens), 12 x 512 text tower (77 tokens), 512-d joint space
 ])
-def test_native_towers_match_torch_modules(arch):
+@pytest.mark.parametrize("gemm", ["bf16x3", "f32"])
+def test_native_towers_match_torch_modules(arch, gemm):
     fm = synth.SyntheticClip(device=DEV, seed=3, **arch)
-    nat = NativeClip(fm)
+    nat = NativeClip(fm, gemm=gemm)
     size = arch.get("image_size", 224)
     u8 = synth.synth_images_u8(torch.arange(6, device=DEV), size=size)
     x = fm.preprocess(u8)

@@ -483,3 +483,23 @@ def test_polysemanticity_vs_sklearn_oracle(C, n, D, kind):
     agree = np.abs(got - want) <= 1e-5
     assert agree.mean() >= 0.98, (kind, agree.mean(), np.abs(got - want).max())
     assert np.all(got >= -1e-6) and np.all(got <= 2 + 1e-6)
+
+
+def test_probe_dict_uses_one_native_call_and_matches_per_layer():
+    from semanticlens_amd.lens import _probe
+
+    g = torch.Generator(device=DEV).manual_seed(11)
+    q = torch.randn(37, 256, device=DEV, generator=g)
+    db = {"a": torch.randn(50, 256, device=DEV, generator=g), "b": torch.randn(300, 256, device=DEV, generator=g),
+          "c": torch.randn(1, 256, device=DEV, generator=g)}
+    got = _probe(q, db)
+    for k, v in db.items():
+        assert got[k].shape == (37, v.shape[0]) and got[k].is_contiguous()
+        np.testing.assert_allclose(got[k].cpu().numpy(), oracle.similarity(q.cpu().numpy(), v.cpu().numpy()), rtol=0, atol=1e-5)
+    # a layer that hits a shape quirk (C == Q -> row-wise cosine) makes the whole dict go layer by layer
+    db["quirk"] = torch.randn(37, 256, device=DEV, generator=g)
+    got = _probe(q, db)
+    assert got["quirk"].shape == (37,) and got["b"].shape == (37, 300)
+    # host tensors in -> host tensors out
+    host = _probe(q.cpu(), {k: v.cpu() for k, v in db.items() if k != "quirk"})
+    assert all(t.device.type == "cpu" for t in host.values())

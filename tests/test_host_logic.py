@@ -259,7 +259,8 @@ def test_text_probing_host_flow_with_patched_kernels(mock_fm):
     # reference tests/test_lens.py:84-97: one encode_text call, (1, n_components) per layer
     mock_fm.encode_text.return_value = torch.randn(1, 128)
     lens = Lens(fm=mock_fm)
-    with mock.patch("semanticlens_amd.lens.similarity_score", side_effect=lambda q, d: torch.zeros(q.shape[0], d.shape[0])):
+    with mock.patch("semanticlens_amd.lens.similarity_score", side_effect=lambda q, d: torch.zeros(q.shape[0], d.shape[0])), \
+            mock.patch("semanticlens_amd.lens.N.similarity_multi", return_value=None):  # no device here: per-layer path
         res = lens.text_probing("a test query", {"layer1": torch.randn(10, 128)})
     mock_fm.encode_text.assert_called_once()
     assert res["layer1"].shape == (1, 10)
