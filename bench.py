@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--cpu-images", type=int, default=192, help="bounded sample for the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probing", action="store_true")
+    ap.add_argument("--fm", default="native", choices=["native", "native-f32", "torch"],
+                    help="CLIP ViT-B/32 encoder: package kernels (split-bf16 x3 or fp32 MFMA GEMMs) or the torch module")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (exhaustive MIOpen search)")
     return ap.parse_args()
 
@@ -236,6 +238,10 @@ def main():
     id_start = rank * n_local
     model = synth.resnet50().to(dev)
     fm = synth.SyntheticClip(device=dev)
+    if args.fm != "torch":
+        from semanticlens_amd.foundation_models.native_clip import NativeClip
+
+        fm = NativeClip(fm, gemm="bf16x3" if args.fm == "native" else "f32")
     Lens(fm, device=dev)
 
     # ---- warm-up on throw-away state (MIOpen kernel selection, allocator, lazy kernel loads) ----
@@ -303,6 +309,9 @@ def main():
                         "CLIP ViT-B/32 (random init) embed, aggregate_conv_max",
             "images_per_gpu": n_local, "batch": B, "num_samples_k": args.k, "tie_mode": args.tie_mode,
             "layers": LAYERS, "parallelism": f"shard{world}" if world > 1 else "single",
+            "clip_encoder": {"native": "NativeClip (HIP kernels, split-bf16 x3 GEMMs, fp32-class accuracy)",
+                             "native-f32": "NativeClip (HIP kernels, fp32-input MFMA GEMMs)",
+                             "torch": "torch module (hipBLASLt fp32)"}[args.fm],
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

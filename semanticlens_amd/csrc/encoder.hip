@@ -95,76 +95,87 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
-// ---- multi-head attention, head_dim 64: one wave per (batch, head); lane = query row ----------------------
+// ---- multi-head attention, head_dim 64 --------------------------------------------------------------------
 // qkv: (B*T, 3*H*64) rows [q | k | v], head h at columns h*64.  softmax(q k^T / sqrt(64)) v, optional causal mask.
+// One 256-thread workgroup per (batch, head): K and V of the head sit in LDS (T x 64 floats each); a query row is
+// owned by 4 adjacent lanes, each holding 16 of the 64 dims of q and of the output accumulator, so a wave covers 16
+// rows and the workgroup 64 rows per pass.  Scores are reduced over the 4 lanes with two quad DPP adds and fed
+// to an online softmax (running max / sum, accumulator rescaled per key), so no T x T score buffer exists and
+// ~6 waves per SIMD are resident (the first version, one wave per head with 64-float q and o arrays per lane
+// and a score buffer, ran at one wave per SIMD and took 39 % of the encoder's time).
 constexpr int kDh = 64;
-__global__ __launch_bounds__(64) void attention_kernel(const float* __restrict__ qkv, int T, int H, int causal,
-                                                        float* __restrict__ out, uint16_t* __restrict__ oh,
-                                                        uint16_t* __restrict__ ol) {
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, int T, int H, int causal,
+                                                         float* __restrict__ out, uint16_t* __restrict__ oh,
+                                                         uint16_t* __restrict__ ol) {
   extern __shared__ __align__(16) float smem[];
-  float* sK = smem;                       // T x 64
-  float* sV = smem + (size_t)T * kDh;     // T x 64
-  float* sP = smem + (size_t)2 * T * kDh; // T x 64 lanes (scores of the current 64-row block)
-  const int lane = threadIdx.x;
+  float* sK = smem;                    // T x 64
+  float* sV = smem + (size_t)T * kDh;  // T x 64
+  const int tid = threadIdx.x;
   const int64_t b = blockIdx.x / H;
   const int h = blockIdx.x % H;
   const int64_t ld = 3ll * H * kDh;
   const float* base = qkv + b * T * ld + h * kDh;
-  for (int e = lane; e < T * (kDh / 4); e += 64) {  // K and V of this head into LDS
+  for (int e = tid; e < T * (kDh / 4); e += 256) {
     const int t = e / (kDh / 4), c = e % (kDh / 4);
     reinterpret_cast<float4*>(sK)[e] = *reinterpret_cast<const float4*>(base + t * ld + (int64_t)H * kDh + c * 4);
     reinterpret_cast<float4*>(sV)[e] = *reinterpret_cast<const float4*>(base + t * ld + 2ll * H * kDh + c * 4);
   }
   __syncthreads();
+  const int part = tid & 3;  // which 16 dims of the head this lane owns
   for (int r0 = 0; r0 < T; r0 += 64) {
-    const int i = r0 + lane;
+    const int i = r0 + (tid >> 2);
     const bool active = i < T;
-    float q[kDh];
+    float q[16], o[16];
 #pragma unroll
-    for (int c = 0; c < kDh / 4; ++c) {
+    for (int c = 0; c < 4; ++c) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (active) v = *reinterpret_cast<const float4*>(base + (int64_t)i * ld + c * 4);
+      if (active) v = *reinterpret_cast<const float4*>(base + (int64_t)i * ld + part * 16 + c * 4);
       q[4 * c + 0] = v.x * 0.125f; q[4 * c + 1] = v.y * 0.125f; q[4 * c + 2] = v.z * 0.125f; q[4 * c + 3] = v.w * 0.125f;
+      o[4 * c + 0] = 0.f; o[4 * c + 1] = 0.f; o[4 * c + 2] = 0.f; o[4 * c + 3] = 0.f;
     }
-    const int jmax = causal ? (r0 + 64 < T ? r0 + 64 : T) : T;  // keys any lane of this block may need
-    float m = -__builtin_huge_valf();
+    // keys any row of this wave may need: rows of a wave are r0 + 16*w .. + 15
+    const int wave_last_row = r0 + (tid >> 6) * 16 + 15;
+    const int jmax = causal ? (wave_last_row + 1 < T ? wave_last_row + 1 : T) : T;
+    float m = -__builtin_huge_valf(), l = 0.f;
     for (int j = 0; j < jmax; ++j) {
-      const float4* kj = reinterpret_cast<const float4*>(sK + (size_t)j * kDh);  // same address in all lanes: broadcast
-      float s = 0.f;
+      const float4* kj = reinterpret_cast<const float4*>(sK + (size_t)j * kDh + part * 16);
+      float sp = 0.f;
 #pragma unroll
-      for (int c = 0; c < kDh / 4; ++c) {
+      for (int c = 0; c < 4; ++c) {
         const float4 kv = kj[c];
-        s += q[4 * c] * kv.x + q[4 * c + 1] * kv.y + q[4 * c + 2] * kv.z + q[4 * c + 3] * kv.w;
+        sp += q[4 * c] * kv.x + q[4 * c + 1] * kv.y + q[4 * c + 2] * kv.z + q[4 * c + 3] * kv.w;
       }
-      if (causal && j > i) s = -__builtin_huge_valf();
-      sP[(size_t)j * 64 + lane] = s;
-      m = fmaxf(m, s);
-    }
-    float denom = 0.f;
-    float o[kDh];
+      // sum over the 4 lanes of the row (quad_perm [1,0,3,2] then [2,3,0,1])
+      sp += bits_f32((uint32_t)__builtin_amdgcn_update_dpp(0, (int)f32_bits(sp), 0xB1, 0xF, 0xF, false));
+      sp += bits_f32((uint32_t)__builtin_amdgcn_update_dpp(0, (int)f32_bits(sp), 0x4E, 0xF, 0xF, false));
+      const bool masked = causal && j > i;
+      const float s = masked ? -__builtin_huge_valf() : sp;
+      const float mn = fmaxf(m, s);
+      const float alpha = expf(m - mn);          // first key: exp(-inf) = 0
+      const float pj = masked ? 0.f : expf(s - mn);
+      l = l * alpha + pj;
+      m = mn;
+      const float4* vj = reinterpret_cast<const float4*>(sV + (size_t)j * kDh + part * 16);
 #pragma unroll
-    for (int d = 0; d < kDh; ++d) o[d] = 0.f;
-    for (int j = 0; j < jmax; ++j) {
-      const float p = expf(sP[(size_t)j * 64 + lane] - m);
-      denom += p;
-      const float4* vj = reinterpret_cast<const float4*>(sV + (size_t)j * kDh);
-#pragma unroll
-      for (int c = 0; c < kDh / 4; ++c) {
+      for (int c = 0; c < 4; ++c) {
         const float4 vv = vj[c];
-        o[4 * c] += p * vv.x; o[4 * c + 1] += p * vv.y; o[4 * c + 2] += p * vv.z; o[4 * c + 3] += p * vv.w;
+        o[4 * c + 0] = o[4 * c + 0] * alpha + pj * vv.x;
+        o[4 * c + 1] = o[4 * c + 1] * alpha + pj * vv.y;
+        o[4 * c + 2] = o[4 * c + 2] * alpha + pj * vv.z;
+        o[4 * c + 3] = o[4 * c + 3] * alpha + pj * vv.w;
       }
     }
     if (active) {
-      const float inv = 1.f / denom;
-      const int64_t o0 = (b * T + i) * (int64_t)H * kDh + h * kDh;
+      const float inv = 1.f / l;
+      const int64_t o0 = (b * T + i) * (int64_t)H * kDh + h * kDh + part * 16;
       if (out) {
 #pragma unroll
-        for (int c = 0; c < kDh / 4; ++c)
+        for (int c = 0; c < 4; ++c)
           *reinterpret_cast<float4*>(out + o0 + c * 4) = make_float4(o[4 * c] * inv, o[4 * c + 1] * inv, o[4 * c + 2] * inv, o[4 * c + 3] * inv);
       }
       if (oh) {
 #pragma unroll
-        for (int d = 0; d < kDh; ++d) store_split(o[d] * inv, o0 + d, oh, ol);
+        for (int d = 0; d < 16; ++d) store_split(o[d] * inv, o0 + d, oh, ol);
       }
     }
   }
@@ -282,10 +293,10 @@ SL_API int sl_attention(const float* d_qkv, int64_t B, int64_t T, int64_t H, int
   if (B == 0) return 0;
   SL_REQUIRE(d_qkv && (d_out || (d_out_hi && d_out_lo)), "sl_attention: null pointer");
   SL_REQUIRE(B * H < (1ll << 31), "sl_attention: too many heads");
-  const size_t smem = (size_t)T * kDh * 4 * 2 + (size_t)T * 64 * 4;
+  const size_t smem = (size_t)T * kDh * 4 * 2;
   if (smem > 64 * 1024)
     SL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL(attention_kernel, dim3((unsigned)(B * H)), dim3(64), smem, (hipStream_t)stream, d_qkv, (int)T, (int)H,
+  hipLaunchKernelGGL(attention_kernel, dim3((unsigned)(B * H)), dim3(256), smem, (hipStream_t)stream, d_qkv, (int)T, (int)H,
                      causal, d_out, d_out_hi, d_out_lo);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
