@@ -1,0 +1,136 @@
+"""BASELINE.json configurations as parity cases (the bench line is configs[1]; the others are checked here).
+
+configs[0]: ResNet-18 (random init), 1k synthetic 224x224 images, layer4 only, CPU reference path — top-k indices and
+            the concept_db tensor are checked against the CPU restatement fed with the same layer4 activations.
+configs[3]: ViT-B/16-shaped probed model, encoder-block outputs (B,197,768), token aggregators.
+configs[4]: ConvNeXt-L stage shapes (192x56x56 ... 1536x7x7) through K1 + the full-db polysemanticity score.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import synth
+from semanticlens_amd import Lens, scores
+from semanticlens_amd import _native as N
+from semanticlens_amd.component_visualization import ActivationComponentVisualizer, aggregators
+from semanticlens_amd.component_visualization.activation_caching import ActMaxCache
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def bits(t):
+    return t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+class _DeviceImages(torch.utils.data.Dataset):
+    """synthetic images generated in one go (the per-item generator of synth.SyntheticImageDataset is slow for 1k)."""
+
+    def __init__(self, n, mode):
+        u8 = synth.synth_images_u8(torch.arange(n, device=DEV)).cpu()
+        self.mode, self.u8, self.name = mode, u8, f"synthetic-{n}"
+
+    def __len__(self):
+        return self.u8.shape[0]
+
+    def __getitem__(self, i):
+        if self.mode == "model":
+            return synth.normalize_u8(self.u8[i : i + 1], synth.IMAGENET_MEAN, synth.IMAGENET_STD)[0], 0
+        return self.u8[i]
+
+
+def test_config0_resnet18_1k_images_layer4_vs_cpu_path():
+    n, k, B = 1000, 20, 64
+    model = synth.resnet18().to(DEV)
+    fm = synth.SyntheticClip(device=DEV, embed_dim=1024, v_layers=2, t_layers=1)  # RN50-CLIP's joint width
+    cv = ActivationComponentVisualizer(model, _DeviceImages(n, "model"), _DeviceImages(n, "fm"), ["layer4"], num_samples=k,
+                                       aggregate_fn=aggregators.aggregate_conv_max, tie_mode="aten")
+    # CPU path fed with the very same layer4 activations (copied off the device as they are produced)
+    ref = oracle.ActMaxOracle(k, 512, oracle.MODE_ATEN)
+    seen = [0]
+
+    def tap(m, i, o):
+        a = o.detach().cpu().numpy()
+        ref.update(oracle.agg_conv(a, "max"), np.arange(seen[0], seen[0] + a.shape[0]))
+        seen[0] += a.shape[0]
+
+    h = model.layer4.register_forward_hook(tap)
+    db = Lens(fm, device=DEV).compute_concept_db(cv, batch_size=B)
+    h.remove()
+    # the embedding pass does not run the probed model, so the tap saw each image exactly once
+    assert seen[0] == n
+    am = cv.actmax_cache.cache["layer4"]
+    assert np.array_equal(bits(am.activations), ref.vals)
+    assert np.array_equal(am.sample_ids.numpy(), ref.ids)  # top-k indices, ties included
+    # concept_db tensor = embeds[ids] on the CPU path
+    u8 = cv.dataset_fm.u8
+    emb = torch.cat([fm.encode_image(fm.preprocess(u8[s : s + B])).cpu() for s in range(0, n, B)]).numpy()
+    assert db["layer4"].shape == (512, k, 1024)
+    assert np.array_equal(db["layer4"].numpy(), oracle.gather_rows(emb, ref.ids))
+    assert len(am.alive_latents) > 0
+
+
+def test_config3_vit_b16_block_outputs_token_aggregators():
+    """12 encoder blocks of width 768 over 197 tokens (ViT-B/16 geometry, 2 blocks here), max and CLS-token aggregation."""
+    torch.manual_seed(0)
+    blocks = torch.nn.ModuleList([synth._Block(768, 12) for _ in range(2)]).to(DEV).eval()
+
+    class Enc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.blocks = blocks
+
+        def forward(self, x):
+            for b in self.blocks:
+                x = b(x)
+            return x
+
+    model = Enc()
+    for fn, name, pos in ((aggregators.aggregate_transformer_max, "max", 0), (aggregators.get_aggregate_transformer_special_token(0), "token", 0)):
+        cache = ActMaxCache(["blocks.0", "blocks.1"], fn, n_collect=20, tie_mode="aten")
+        refs = {n: oracle.ActMaxOracle(20, 768, oracle.MODE_ATEN) for n in cache.layer_names}
+        count = {n: 0 for n in refs}
+
+        def tap(name_):
+            def f(m, i, o):
+                a = o.detach().cpu().numpy()
+                refs[name_].update(oracle.agg_tokens(a, name, pos), np.arange(count[name_], count[name_] + a.shape[0]))
+                count[name_] += a.shape[0]
+            return f
+
+        hs = [model.blocks[i].register_forward_hook(tap(f"blocks.{i}")) for i in range(2)]
+        g = torch.Generator(device=DEV).manual_seed(1)
+        with torch.no_grad(), cache.hook_context(model):
+            for _ in range(5):
+                model(torch.randn(48, 197, 768, device=DEV, generator=g))
+        for h in hs:
+            h.remove()
+        for n_ in refs:
+            assert np.array_equal(bits(cache.cache[n_].activations), refs[n_].vals), (name, n_)
+            assert np.array_equal(cache.cache[n_].sample_ids.numpy(), refs[n_].ids), (name, n_)
+
+
+@pytest.mark.parametrize("shape", [(32, 192, 56, 56), (32, 384, 28, 28), (32, 768, 14, 14), (32, 1536, 7, 7)])
+def test_config4_convnext_l_stage_shapes(shape):
+    g = torch.Generator(device=DEV).manual_seed(shape[1])
+    x = torch.randn(*shape, device=DEV, generator=g)
+    out = torch.empty(shape[:2], dtype=torch.float32, device=DEV)
+    cand = torch.empty(shape[:2], dtype=torch.bfloat16, device=DEV)
+    N.reduce_conv(x, N.SL_CONV_MAX, cand, out)
+    assert torch.equal(out, x.flatten(2).amax(-1))
+    assert np.array_equal(out[:4].cpu().numpy(), oracle.agg_conv(x[:4].cpu().numpy(), "max"))
+    assert torch.equal(cand, out.to(torch.bfloat16))
+
+
+def test_config4_polysemanticity_over_a_full_concept_db():
+    """eval_polysemanticity over every component of a ConvNeXt-L-sized layer (1536 components, k=20, D=512)."""
+    rng = np.random.RandomState(4)
+    V = rng.randn(1536, 20, 512).astype(np.float32)
+    V[::7, :9] += 2.0 * rng.randn(220, 1, 512).astype(np.float32)  # some clustered components
+    got = Lens(synth.SyntheticClip(device=DEV, v_layers=1, t_layers=1), device=DEV).eval_polysemanticity({"stage4": torch.from_numpy(V).to(DEV)})["stage4"]
+    assert got.shape == (1536,) and got.dtype == torch.float64
+    sub = np.arange(0, 1536, 24)
+    want = oracle.polysemanticity(V[sub])
+    agree = np.abs(got.cpu().numpy()[sub] - want) <= 1e-5
+    assert agree.mean() >= 0.97, agree.mean()
