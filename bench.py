@@ -175,39 +175,55 @@ def cpu_baseline(args, model_cpu, fm_cpu):
 
 @torch.no_grad()
 def probing_leg(dev):
-    """text_probing at BASELINE configs[3] shapes: Q=10,000 query embeddings (D=1152, SigLIP-so400m width)
-    against 12 layers x 768 components; the cosine GEMM (K6) is event-timed through sl_prof."""
+    """text_probing at BASELINE configs[3] shapes: Q=10,000 query embeddings (D=1152, SigLIP-so400m width) against
+    12 layers x 768 components, through `_probe` (lens.py:206-214).  The cosine GEMM (K6) is timed per dispatch
+    through sl_prof.  Measured in both arithmetic modes; the default (split-bf16 x3) is the headline."""
     g = torch.Generator(device=dev).manual_seed(2)
     Q, D, C, L = 10000, 1152, 768, 12
     q = torch.randn(Q, D, device=dev, generator=g)
     db = {f"block{i}": torch.randn(C, D, device=dev, generator=g) for i in range(L)}
     from semanticlens_amd.lens import _probe
 
-    _probe(q, db)  # warm-up
-    torch.cuda.synchronize()
-    N.prof_enable(True)
-    N.prof_reset()
-    t0 = time.perf_counter()
-    out = _probe(q, db)
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    ms, launches, flops = N.prof_read(N.SL_PROF_GEMM)
-    N.prof_enable(False)
+    def run(mode):
+        N.set_gemm_mode(mode)
+        _probe(q, db)  # warm-up
+        torch.cuda.synchronize()
+        N.prof_enable(True)
+        N.prof_reset()
+        t0 = time.perf_counter()
+        out = _probe(q, db)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        ms, launches, flops = N.prof_read(N.SL_PROF_GEMM)
+        N.prof_enable(False)
+        assert all(v.shape == (Q, C) for v in out.values())
+        return wall, ms, launches, flops, out
+
+    wall3, ms3, n3, fl3, out3 = run("bf16x3")
+    wall1, ms1, n1, fl1, out1 = run("f32")
+    N.set_gemm_mode(None)
+    max_diff = max((out3[k] - out1[k]).abs().max().item() for k in out3)
     sims = Q * C * L
-    assert all(v.shape == (Q, C) for v in out.values())
     return {
-        "metric": "Msimilarities/sec text_probing", "value": sims / wall / 1e6, "unit": "Msim/s",
+        "metric": "Msimilarities/sec text_probing", "value": sims / wall3 / 1e6, "unit": "Msim/s",
         "workload": f"Q={Q} x {L} layers x C={C}, D={D} (configs[3] shapes), query embeddings resident",
-        "wall_ms": wall * 1e3,
+        "wall_ms": wall3 * 1e3,
         # split-bf16 x3: three bf16 MFMAs per product.  `achieved` counts ALGORITHMIC flops (2*Q*C*D); the peak it is
         # priced against is the dense bf16 MFMA peak divided by the 3 products (2500 / 3); 3x achieved is what the
-        # matrix cores actually issue.  For reference also the ratio to the fp32-input MFMA peak (157.3).
-        "roofline": {"bound": "mfma", "achieved": flops / ms / 1e9 if ms else None, "peak": MFMA_BF16_PEAK_TFLOPS / 3,
-                     "unit": "TFLOP/s", "frac": (flops / ms / 1e9) / (MFMA_BF16_PEAK_TFLOPS / 3) if ms else None,
+        # matrix cores actually issue.
+        "roofline": {"bound": "mfma", "achieved": fl3 / ms3 / 1e9, "peak": MFMA_BF16_PEAK_TFLOPS / 3, "unit": "TFLOP/s",
+                     "frac": (fl3 / ms3 / 1e9) / (MFMA_BF16_PEAK_TFLOPS / 3),
                      "kernel": "gemm3_nt (split-bf16 x3 on v_mfma_f32_32x32x16_bf16, fp32-class accuracy)",
-                     "mfma_flops_issued_TFLOPs": 3 * flops / ms / 1e9 if ms else None,
-                     "ratio_to_fp32_mfma_peak": (flops / ms / 1e9) / MFMA_F32_PEAK_TFLOPS if ms else None,
-                     "launches": launches, "avg_ms": ms / max(launches, 1)},
+                     "mfma_flops_issued_TFLOPs": 3 * fl3 / ms3 / 1e9,
+                     "ratio_to_fp32_mfma_peak": (fl3 / ms3 / 1e9) / MFMA_F32_PEAK_TFLOPS,
+                     "launches": n3, "avg_ms": ms3 / max(n3, 1)},
+        # the same probe with the exact-fp32 kernel (SL_GEMM_MODE=f32)
+        "fp32_mfma_mode": {"value": sims / wall1 / 1e6, "unit": "Msim/s", "wall_ms": wall1 * 1e3,
+                           "roofline": {"bound": "mfma", "achieved": fl1 / ms1 / 1e9, "peak": MFMA_F32_PEAK_TFLOPS,
+                                        "unit": "TFLOP/s", "frac": (fl1 / ms1 / 1e9) / MFMA_F32_PEAK_TFLOPS,
+                                        "kernel": "gemm_nt (v_mfma_f32_32x32x2_f32)", "launches": n1,
+                                        "avg_ms": ms1 / max(n1, 1)}},
+        "max_abs_diff_between_modes": max_diff,
     }
 
 

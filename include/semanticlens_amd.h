@@ -135,6 +135,10 @@ int sl_similarity(const float* d_x, int64_t xr, int64_t xc, const float* d_y, in
                   void* d_ws, size_t ws_bytes, void* stream);
 size_t sl_similarity_ws_bytes(int64_t xr, int64_t xc, int64_t yr, int64_t yc);
 
+/* Arithmetic of the cosine GEMMs of sl_similarity(_multi) / sl_redundancy: 1 = split-bf16 x3 (default), 0 = fp32-input
+ * MFMA, -1 = as the SL_GEMM_MODE environment variable says.  Process-wide. */
+int sl_set_gemm_mode(int mode);
+
 /* One query matrix against L concept matrices — the per-layer loop of `_probe` (lens.py:206-214).  All
  * layers must take similarity_score's plain branch (Q != C_l and K != C_l; otherwise use sl_similarity).
  * h_d_ys / h_d_outs: host arrays of L device pointers ((C_l,K) inputs, (Q,C_l) outputs); h_Cs: host array. */

@@ -49,6 +49,7 @@ SIGNATURES = {
     "sl_gather_rows_shard": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "sl_similarity": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "sl_similarity_ws_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "sl_set_gemm_mode": (_int, [_int]),
     "sl_similarity_multi": (_int, [_vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _sz, _vp]),
     "sl_similarity_multi_ws_bytes": (_sz, [_i64, _i64, _vp, _int]),
     "sl_clarity": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
@@ -282,6 +283,11 @@ def similarity(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         rc = lib().sl_similarity(_ptr(xd), xr, xc, _ptr(yd), yr, yc, _ptr(out), _ptr(ws), nbytes, _stream(xd))
     _check(rc, "sl_similarity")
     return out
+
+
+def set_gemm_mode(mode: str | None):
+    """Arithmetic of the cosine GEMMs: "bf16x3" (default), "f32" (fp32-input MFMA) or None (environment)."""
+    _check(lib().sl_set_gemm_mode({None: -1, "f32": 0, "bf16x3": 1}[mode]), "sl_set_gemm_mode")
 
 
 def similarity_multi(x: torch.Tensor, ys: list[torch.Tensor]) -> list[torch.Tensor] | None:

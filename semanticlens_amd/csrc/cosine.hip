@@ -120,13 +120,16 @@ int launch_inv_norm(const float* x, int64_t rows, int64_t cols, float eps, float
 
 // SL_GEMM_MODE=f32    : fp32-input MFMA (exact fp32 products)
 // SL_GEMM_MODE=bf16x3 : split-bf16 on the bf16 matrix cores (gemm_bf16x3.hpp), |error| ~1e-6 on cosines
+static int g_gemm_mode = -1;  // -1: not set (environment decides), 0: f32, 1: bf16x3
 bool use_bf16x3() {
+  if (g_gemm_mode >= 0) return g_gemm_mode == 1;
   static const bool v = [] {
     const char* e = getenv("SL_GEMM_MODE");
     return !(e && strcmp(e, "f32") == 0);
   }();
   return v;
 }
+void set_gemm_mode(int m) { g_gemm_mode = m; }
 
 // bytes of split-bf16 scratch for an (R x K) operand: hi + lo
 size_t split_bytes(int64_t R, int64_t K) { return 2 * align256_((size_t)R * (size_t)K * 2); }
@@ -277,4 +280,10 @@ SL_API int sl_similarity_multi(const float* d_x, int64_t Q, int64_t K, const flo
   SL_REQUIRE(d_ws && ws_bytes >= sl_similarity_multi_ws_bytes(Q, K, h_Cs, L), "sl_similarity_multi: workspace too small");
   unsigned char* ws = (unsigned char*)(((uintptr_t)d_ws + 255) & ~(uintptr_t)255);
   return cosine_matrix_multi(d_x, Q, K, h_d_ys, h_Cs, L, h_d_outs, ws, (hipStream_t)stream);
+}
+
+SL_API int sl_set_gemm_mode(int mode) {
+  SL_REQUIRE(mode >= -1 && mode <= 1, "sl_set_gemm_mode: mode %d not in {-1 (environment), 0 (f32), 1 (bf16x3)}", mode);
+  set_gemm_mode(mode);
+  return 0;
 }
