@@ -57,6 +57,9 @@ __global__ __launch_bounds__(256, SL_G3_WAVES) void gemm3_nt_kernel(const uint16
   const int64_t m0 = (int64_t)(tile / tiles_n) * BM;
   const int64_t n0 = (int64_t)(tile % tiles_n) * BN;
 
+#ifdef SL_GEMM_CLOCKPROBE  // tools/native/clock_probe.hip: shader cycles vs the 100 MHz constant clock, per workgroup
+  const unsigned long long probe_c0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   floatx16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -171,6 +174,12 @@ __global__ __launch_bounds__(256, SL_G3_WAVES) void gemm3_nt_kernel(const uint16
       }
     }
   }
+#ifdef SL_GEMM_CLOCKPROBE
+  if (tid == 0) {
+    epi.probe[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - probe_c0;
+    epi.probe[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - probe_r0;
+  }
+#endif
 }
 
 inline int launch_split(const float* x, const float* scale, int64_t R, int64_t K, uint16_t* hi, uint16_t* lo, hipStream_t st) {

@@ -67,6 +67,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
   const int li = lane & 31, lh = lane >> 5;
   // (an XCD-aware tile order was A/B tested and is neutral: the kernel is MFMA-issue bound, not L2-miss bound)
   const int tile = blockIdx.x;
+#ifdef SL_GEMM_CLOCKPROBE  // tools/native/clock_probe.hip
+  const unsigned long long probe_c0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int64_t m0 = (int64_t)(tile / tiles_n) * BM;
   const int64_t n0 = (int64_t)(tile % tiles_n) * BN;
 
@@ -177,6 +180,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
       }
     }
   }
+#ifdef SL_GEMM_CLOCKPROBE
+  if (tid == 0) {
+    epi.probe[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - probe_c0;
+    epi.probe[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - probe_r0;
+  }
+#endif
 }
 
 template <class Epi>
