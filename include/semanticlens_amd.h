@@ -219,6 +219,33 @@ int sl_broadcast_row(const float* d_v, const float* d_add, int64_t G, int64_t gr
 int sl_embed_tokens(const float* d_table, int64_t vocab, const int64_t* d_ids, int64_t B, int64_t T, int64_t W,
                     const float* d_pos, float* d_out, void* stream);
 
+/* ---- K12: image preprocessing on the device -----------------------------------
+ * Replaces the per-sample host transform the reference applies before encode_image
+ * (foundation_models/clip.py:157-163 `self.preprocessor(image)`, i.e. open_clip's inference transform:
+ * Resize(S, BICUBIC) -> CenterCrop(S) -> ToTensor -> Normalize; "squash": Resize((S,S)) without crop).
+ * Bit-identical to Pillow's antialiased resize + torchvision's crop/normalise arithmetic.
+ *
+ * sl_preprocess_plan is a pure host function: h_hw (B,2) int32 heights/widths of the raw RGB images,
+ * h_pixel_offsets (B) byte offset of each image in the packed pixel buffer (NULL: tightly packed in order);
+ * writes h_plan (B, SL_PP_PLAN_STRIDE) int64 (upload it unchanged) and h_info[SL_PP_INFO_*].
+ * sl_preprocess: d_pixels packed (h,w,3) uint8 images, d_plan the uploaded plan, max_h / coef_bytes from h_info,
+ * h_mean/h_std 3 floats each (host); d_out (B,3,S,S) fp32 and/or d_out_u8 (B,S,S,3) resized+cropped bytes
+ * (either may be NULL); d_ws of h_info[SL_PP_INFO_WS_BYTES] bytes. */
+#define SL_PP_SHORTEST 0
+#define SL_PP_SQUASH 1
+#define SL_PP_BICUBIC 0
+#define SL_PP_BILINEAR 1
+#define SL_PP_PLAN_STRIDE 16
+#define SL_PP_INFO_WS_BYTES 0
+#define SL_PP_INFO_COEF_BYTES 1
+#define SL_PP_INFO_MAX_H 2
+#define SL_PP_INFO_PIXEL_BYTES 3
+int sl_preprocess_plan(const int32_t* h_hw, const int64_t* h_pixel_offsets, int64_t B, int S, int resize_mode,
+                       int interp, int64_t* h_plan, int64_t* h_info);
+int sl_preprocess(const uint8_t* d_pixels, const int64_t* d_plan, int64_t B, int S, int interp, int64_t max_h,
+                  int64_t coef_bytes, const float* h_mean, const float* h_std, float* d_out, uint8_t* d_out_u8,
+                  void* d_ws, size_t ws_bytes, void* stream);
+
 /* ---- measurement --------------------------------------------------------------------------
  * When enabled, every launch of a profiled kernel family is bracketed by HIP events on its
  * own stream.  sl_prof_read synchronises those events and returns the totals. */

@@ -29,8 +29,8 @@ MODE_TOTAL = 1
 
 def build(force: bool = False) -> Path:
     """Compile the oracle shared library with g++ (``make -C oracle``)."""
-    src = _HERE / "sl_oracle.cpp"
-    if force or not _LIB_PATH.exists() or _LIB_PATH.stat().st_mtime < src.stat().st_mtime:
+    newest = max((_HERE / f).stat().st_mtime for f in ("sl_oracle.cpp", "sl_oracle_preprocess.cpp"))
+    if force or not _LIB_PATH.exists() or _LIB_PATH.stat().st_mtime < newest:
         subprocess.run(["make", "-C", str(_HERE), "-B" if force else "-s"], check=True, capture_output=True)
     return _LIB_PATH
 
@@ -212,3 +212,33 @@ def polysemanticity(V, random_state: int = 123, n_clusters: int = 2) -> np.ndarr
             acc += clarity(np.stack([v_not.mean(1), v_not[:, i]], axis=1))
         poly[bad] = 1.0 - acc.astype(np.float64) / ns
     return poly
+
+
+RESIZE_MODE = {"shortest": 0, "squash": 1}
+INTERP = {"bicubic": 0, "bilinear": 1}
+
+
+def resized_size(h: int, w: int, size: int, resize_mode: str = "shortest") -> tuple[int, int]:
+    """torchvision ``Resize(size)`` output (h, w) — sl_oracle_preprocess.cpp::orc_resized_size."""
+    oh, ow = ctypes.c_int(), ctypes.c_int()
+    lib().orc_resized_size(int(h), int(w), int(size), RESIZE_MODE[resize_mode], ctypes.byref(oh), ctypes.byref(ow))
+    return oh.value, ow.value
+
+
+def center_crop_offset(size: int, crop: int) -> int:
+    return int(lib().orc_center_crop_offset(int(size), int(crop)))
+
+
+def preprocess(img, size: int, mean, std, resize_mode: str = "shortest", interp: str = "bicubic"):
+    """One (h, w, 3) uint8 image -> ((size, size, 3) uint8 resized+cropped, (3, size, size) fp32 normalised):
+    open_clip's inference transform (``clip.py:157-163`` calls it per sample) restated on the CPU."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    assert img.ndim == 3 and img.shape[2] == 3
+    u8 = np.empty((size, size, 3), np.uint8)
+    f = np.empty((3, size, size), np.float32)
+    m, s = _f32(mean), _f32(std)
+    rc = lib().orc_preprocess(_p(img), int(img.shape[0]), int(img.shape[1]), int(size), RESIZE_MODE[resize_mode],
+                              INTERP[interp], _p(m), _p(s), _p(u8), _p(f))
+    if rc != 0:
+        raise ValueError("resized image smaller than the crop")
+    return u8, f

@@ -25,6 +25,9 @@ SL_MAX_SLOTS = 16
 SL_PROF_REDUCE, SL_PROF_MERGE, SL_PROF_GEMM, SL_PROF_GATHER, SL_PROF_SCORES = 0, 1, 2, 3, 4
 SL_ACT_NONE, SL_ACT_GELU, SL_ACT_QUICKGELU = 0, 1, 2
 TIE_MODES = {"total": SL_TIES_TOTAL, "aten": SL_TIES_ATEN}
+SL_PP_PLAN_STRIDE = 16
+PP_RESIZE_MODES = {"shortest": 0, "squash": 1}
+PP_INTERP = {"bicubic": 0, "bilinear": 1}
 
 _DTYPES = {torch.float32: SL_F32, torch.float16: SL_F16, torch.bfloat16: SL_BF16}
 
@@ -66,6 +69,8 @@ SIGNATURES = {
     "sl_linear_bf16x3": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _int, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "sl_broadcast_row": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "sl_embed_tokens": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "sl_preprocess_plan": (_int, [_vp, _vp, _i64, _int, _int, _int, _vp, _vp]),
+    "sl_preprocess": (_int, [_vp, _vp, _i64, _int, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sl_prof_enable": (_int, [_int]),
     "sl_prof_reset": (_int, []),
     "sl_prof_read": (_int, [_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)]),
@@ -504,3 +509,42 @@ def embed_tokens(table, ids, pos, out=None):
         rc = lib().sl_embed_tokens(_ptr(table), vocab, _ptr(ids), B, T, W, _ptr(pos), _ptr(out), _stream(table))
     _check(rc, "sl_embed_tokens")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# K12: image preprocessing (foundation_models/clip.py:157-163 of the reference runs it per sample on the host)
+# ------------------------------------------------------------------------------------------------
+def preprocess_plan(hw, size: int, resize_mode: str = "shortest", interp: str = "bicubic", pixel_offsets=None):
+    """Host-side plan for a ragged batch: ``hw`` (B, 2) heights/widths -> (plan (B, 16) int64 CPU tensor, info dict).
+    Pure host arithmetic inside the library (no device needed)."""
+    hw_t = torch.as_tensor(hw, dtype=torch.int32).reshape(-1, 2).contiguous()
+    B = hw_t.shape[0]
+    plan = torch.zeros((B, SL_PP_PLAN_STRIDE), dtype=torch.int64)
+    info = (ctypes.c_int64 * 4)()
+    off = None if pixel_offsets is None else torch.as_tensor(pixel_offsets, dtype=torch.int64).contiguous()
+    if resize_mode not in PP_RESIZE_MODES or interp not in PP_INTERP:
+        raise ValueError(f"unknown resize_mode/interpolation {resize_mode!r}/{interp!r}")
+    _check(lib().sl_preprocess_plan(_vp(hw_t.data_ptr()) if B else _vp(None), _vp(off.data_ptr()) if off is not None and B else _vp(None),
+                                    B, int(size), PP_RESIZE_MODES[resize_mode], PP_INTERP[interp],
+                                    _vp(plan.data_ptr()) if B else _vp(None), ctypes.cast(info, _vp)), "sl_preprocess_plan")
+    return plan, {"ws_bytes": int(info[0]), "coef_bytes": int(info[1]), "max_h": int(info[2]), "pixel_bytes": int(info[3])}
+
+
+def preprocess(pixels: torch.Tensor, plan: torch.Tensor, info: dict, size: int, mean, std, interp: str = "bicubic",
+               want_u8: bool = False, want_f32: bool = True):
+    """Packed raw RGB bytes on the device + uploaded plan -> (B, 3, size, size) fp32 (and/or (B, size, size, 3) uint8)."""
+    if not pixels.is_cuda or pixels.dtype != torch.uint8:
+        raise TypeError("pixels must be a uint8 tensor on a HIP device")
+    dev = pixels.device
+    B = plan.shape[0]
+    plan_d = plan.to(dev, non_blocking=True) if not plan.is_cuda else plan
+    out = torch.empty((B, 3, size, size), dtype=torch.float32, device=dev) if want_f32 else None
+    out_u8 = torch.empty((B, size, size, 3), dtype=torch.uint8, device=dev) if want_u8 else None
+    ws = torch.empty((max(info["ws_bytes"], 16),), dtype=torch.uint8, device=dev)
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    sd = (ctypes.c_float * 3)(*[float(v) for v in std])
+    with torch.cuda.device(dev):
+        _check(lib().sl_preprocess(_ptr(pixels), _ptr(plan_d), B, int(size), PP_INTERP[interp], info["max_h"], info["coef_bytes"],
+                                   ctypes.cast(m, _vp), ctypes.cast(sd, _vp), _ptr(out), _ptr(out_u8), _ptr(ws),
+                                   info["ws_bytes"], _stream(pixels)), "sl_preprocess")
+    return out, out_u8

@@ -2,4 +2,6 @@
 from semanticlens_amd.foundation_models.base import AbstractVLM
 from semanticlens_amd.foundation_models.clip import ClipMobile, OpenClip, SigLipV2
 
-__all__ = ["AbstractVLM", "OpenClip", "ClipMobile", "SigLipV2"]
+from semanticlens_amd.foundation_models.preprocess import DevicePreprocess
+
+__all__ = ["AbstractVLM", "OpenClip", "ClipMobile", "SigLipV2", "DevicePreprocess"]

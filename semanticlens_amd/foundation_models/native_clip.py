@@ -179,7 +179,10 @@ class NativeTextTower:
 class NativeClip(AbstractVLM):
     """``AbstractVLM`` running ``base``'s CLIP towers on HIP kernels; ``base`` keeps tokenizer + preprocessing."""
 
-    def __init__(self, base, device=None, gemm: str = "bf16x3"):
+    def __init__(self, base, device=None, gemm: str = "bf16x3", preprocess=None):
+        """``preprocess``: ``None`` keeps ``base.preprocess`` (host transform, as upstream); a
+        ``DevicePreprocess`` (or ``"device"`` to derive one from ``base.preprocessor``) runs resize / crop /
+        normalise for the whole batch on the device (K12)."""
         if gemm not in ("bf16x3", "f32"):
             raise ValueError("gemm must be 'bf16x3' or 'f32'")
         split = gemm == "bf16x3"
@@ -202,6 +205,11 @@ class NativeClip(AbstractVLM):
         except (AttributeError, TypeError, ValueError):
             self.text = None  # text tower layout not recognised: encode_text stays on the wrapped torch model
         self.name = f"native-{gemm}-" + getattr(base, "name", type(base).__name__)
+        if preprocess == "device":
+            from semanticlens_amd.foundation_models.preprocess import DevicePreprocess
+
+            preprocess = DevicePreprocess.from_transform(base.preprocessor)
+        self._preprocess = preprocess.to(dev) if preprocess is not None else None
 
     @property
     def device(self):
@@ -221,6 +229,9 @@ class NativeClip(AbstractVLM):
         return self.text(tokens)
 
     def preprocess(self, img):
+        if self._preprocess is not None:
+            out = self._preprocess(img)
+            return out.unsqueeze(0) if out.ndim == 3 else out  # clip.py:160-162: a single image gets a batch axis
         return self.base.preprocess(img)
 
     def tokenize(self, txt, *args, **kwargs):

@@ -380,3 +380,45 @@ def test_cache_files_interchange_with_reference(tmp_path):
         ho, po = parse(tmp_path / "ours" / name)
         ht, pt = parse(tmp_path / "theirs" / name)
         assert ho == ht and po == pt  # same header (metadata key order is unordered in safetensors) and same bytes
+
+
+# ---- K12 host side: the launch plan (pure host function of the library) and batch packing -----------------------
+def test_preprocess_plan_matches_torchvision_size_rules():
+    hw = [(500, 375), (375, 500), (77, 50), (75, 50), (224, 224), (1, 9), (1000, 333)]
+    plan, info = N.preprocess_plan(hw, 224)
+    for (h, w), row in zip(hw, plan.tolist()):
+        short, long = (w, h) if w <= h else (h, w)
+        oh, ow = (int(224 * long / short), 224) if w <= h else (224, int(224 * long / short))
+        assert row[1:5] == [h, w, oh, ow]
+        assert row[5] == int(round((oh - 224) / 2.0)) and row[6] == int(round((ow - 224) / 2.0))
+    assert info["max_h"] == 1000 and info["pixel_bytes"] == sum(3 * h * w for h, w in hw)
+    assert plan[:, 0].tolist() == np.cumsum([0] + [3 * h * w for h, w in hw[:-1]]).tolist()
+    assert info["ws_bytes"] > info["coef_bytes"] > 0 and info["coef_bytes"] % 16 == 0
+    sq, _ = N.preprocess_plan(hw, 64, "squash", "bilinear")
+    assert sq[:, 3:7].tolist() == [[64, 64, 0, 0]] * len(hw)
+    with pytest.raises(ValueError):
+        N.preprocess_plan([(0, 5)], 32)
+    with pytest.raises(ValueError):
+        N.preprocess_plan([(8, 8)], 32, "longest")
+
+
+def test_device_preprocess_packs_ragged_batches_and_rejects_bad_input():
+    from semanticlens_amd.foundation_models import DevicePreprocess
+
+    pp = DevicePreprocess(size=32)
+    a = np.arange(5 * 7 * 3, dtype=np.uint8).reshape(5, 7, 3)
+    b = np.full((4, 3), 9, np.uint8)  # grey image -> replicated channels
+    buf, plan, info = pp.pack([a, torch.from_numpy(b)])
+    assert info["pixel_bytes"] == a.size + 3 * b.size
+    assert np.array_equal(buf.numpy()[: a.size], a.reshape(-1))
+    assert np.all(buf.numpy()[a.size : a.size + 3 * b.size] == 9)
+    assert plan[:, 1:3].tolist() == [[5, 7], [4, 3]]
+    with pytest.raises(TypeError):
+        pp.pack([a.astype(np.float32)])
+    with pytest.raises(ValueError):
+        pp.pack([np.zeros((4, 4, 4), np.uint8)])
+    with pytest.raises(ValueError):
+        DevicePreprocess(resize_mode="longest")
+    if not torch.cuda.is_available():
+        with pytest.raises(N.NativeLibraryError):  # no CPU fallback
+            pp([a])
