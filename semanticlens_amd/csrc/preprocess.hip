@@ -47,10 +47,13 @@ __device__ inline double tap_weight(double x, int interp) {
   return 0.0;
 }
 
+__host__ __device__ inline int pad4(int v) { return (v + 3) & ~3; }
+constexpr int kWideFlag = 1 << 30;  // in bounds[2 j + 1]: some tap of this row needs more than 24 signed bits
+
 // grid (2, B): blockIdx.x = axis (0 horizontal, 1 vertical).  Per kept output index j in [0, S): bounds (first
-// source index, tap count) and ksize int32 taps, written to the image's coefficient block:
-//   [bounds: S x 2 int32][taps: S x ksize int32]
-__global__ __launch_bounds__(64) void coeff_kernel(const int64_t* __restrict__ plan, int S, int interp,
+// source index, tap count) and the taps, written to the image's coefficient block (16-byte aligned rows, zero padded):
+//   [bounds: pad4(2 S) int32][taps: S x pad4(ksize) int32]
+__global__ __launch_bounds__(256) void coeff_kernel(const int64_t* __restrict__ plan, int S, int interp,
                                                    int32_t* __restrict__ ws_coef) {
 #pragma clang fp contract(off)
   const int64_t* p = plan + (int64_t)blockIdx.y * kPlanStride;
@@ -58,9 +61,9 @@ __global__ __launch_bounds__(64) void coeff_kernel(const int64_t* __restrict__ p
   const int in_size = (int)(axis == 0 ? p[P_W] : p[P_H]);
   const int out_size = (int)(axis == 0 ? p[P_OW] : p[P_OH]);
   const int crop0 = (int)(axis == 0 ? p[P_LEFT] : p[P_TOP]);
-  const int ksize = (int)(axis == 0 ? p[P_KH] : p[P_KV]);
+  const int ksize = pad4((int)(axis == 0 ? p[P_KH] : p[P_KV]));
   int32_t* bounds = ws_coef + (axis == 0 ? p[P_COEF_H] : p[P_COEF_V]);
-  int32_t* taps = bounds + 2 * S;
+  int32_t* taps = bounds + pad4(2 * S);
   const float in0 = 0.f, in1 = (float)in_size;
   double scale = (double)(in1 - in0) / out_size, filterscale = scale;
   if (filterscale < 1.0) filterscale = 1.0;
@@ -77,14 +80,17 @@ __global__ __launch_bounds__(64) void coeff_kernel(const int64_t* __restrict__ p
     double ww = 0.0;
     for (int x = 0; x < xmax; ++x) ww += tap_weight((x + xmin - center + 0.5) * ss, interp);
     int32_t* k = taps + (int64_t)j * ksize;
+    bool wide = false;  // a tap outside the signed 24-bit range: consumers take the 32-bit multiply path for this row
     for (int x = 0; x < xmax; ++x) {
       double v = tap_weight((x + xmin - center + 0.5) * ss, interp);
       if (ww != 0.0) v /= ww;
-      k[x] = v < 0 ? (int)(-0.5 + v * (1 << kPrecisionBits)) : (int)(0.5 + v * (1 << kPrecisionBits));
+      const int kv = v < 0 ? (int)(-0.5 + v * (1 << kPrecisionBits)) : (int)(0.5 + v * (1 << kPrecisionBits));
+      wide |= kv >= (1 << 23) || kv < -(1 << 23);
+      k[x] = kv;
     }
     for (int x = xmax < 0 ? 0 : xmax; x < ksize; ++x) k[x] = 0;
     bounds[2 * j] = xmin;
-    bounds[2 * j + 1] = xmax;
+    bounds[2 * j + 1] = (xmax < 0 ? 0 : xmax) | (wide ? kWideFlag : 0);
   }
 }
 
@@ -93,70 +99,196 @@ __device__ inline uint32_t clip8(int v) {
   return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
-// grid (ceil(max_h * S / 256), B): thread = (source row y, kept output column j)
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+
+// 12 contiguous bytes (4 RGB pixels) at any byte alignment (gfx950 runs with unaligned global access enabled)
+__device__ inline u32x3 load12(const uint8_t* p) {
+  u32x3 v;
+  __builtin_memcpy(&v, p, 12);
+  return v;
+}
+
+// byte * tap: taps fit 24 signed bits except in flagged rows, so the full-rate 24-bit multiply is exact (the 32-bit
+// integer multiply is a quarter-rate instruction and was the bottleneck of both passes)
+template <bool WIDE>
+__device__ inline int bmul(uint32_t byte, int k) {
+  if (WIDE) return (int)byte * k;
+  return __mul24((int)byte, k);
+}
+
+// acc[c] += sum over the 4 pixels in `px` of pixel[c] * k[tap]
+template <bool WIDE>
+__device__ inline void mac4(const u32x3 px, const int4 k, int& s0, int& s1, int& s2) {
+  s0 += bmul<WIDE>(px.x & 0xff, k.x) + bmul<WIDE>(px.x >> 24, k.y) + bmul<WIDE>((px.y >> 16) & 0xff, k.z) + bmul<WIDE>((px.z >> 8) & 0xff, k.w);
+  s1 += bmul<WIDE>((px.x >> 8) & 0xff, k.x) + bmul<WIDE>(px.y & 0xff, k.y) + bmul<WIDE>(px.y >> 24, k.z) + bmul<WIDE>((px.z >> 16) & 0xff, k.w);
+  s2 += bmul<WIDE>((px.x >> 16) & 0xff, k.x) + bmul<WIDE>((px.y >> 8) & 0xff, k.y) + bmul<WIDE>(px.z & 0xff, k.z) + bmul<WIDE>(px.z >> 24, k.w);
+}
+
+// the four-taps-at-a-time body of the horizontal pass for R rows
+template <bool WIDE, int R>
+__device__ inline void hpass(const uint8_t* const (&rows)[R], const int32_t* __restrict__ k, int xmax, int (&acc)[R][3]) {
+  int x = 0;
+  for (; x + 4 <= xmax; x += 4) {
+    const int4 kk = *reinterpret_cast<const int4*>(k + x);
+#pragma unroll
+    for (int r = 0; r < R; ++r) mac4<WIDE>(load12(rows[r] + 3 * x), kk, acc[r][0], acc[r][1], acc[r][2]);
+  }
+  if (x < xmax) {  // 1..3 taps left: window [xmax - 4, xmax), taps below x already done
+    const int xs = xmax - 4, done = x - xs;
+    int4 kk;
+    kk.x = 0;  // done >= 1
+    kk.y = done >= 2 ? 0 : k[xs + 1];
+    kk.z = done >= 3 ? 0 : k[xs + 2];
+    kk.w = k[xs + 3];
+#pragma unroll
+    for (int r = 0; r < R; ++r) mac4<WIDE>(load12(rows[r] + 3 * xs), kk, acc[r][0], acc[r][1], acc[r][2]);
+  }
+}
+
+constexpr int kRowsPerThread = 4;
+
+// grid (ceil(ceil(max_h / 4) * S / 256), B): thread = (four consecutive source rows, kept output column j); the
+// launch is latency bound (one short dependent chain per thread), so a thread keeps the taps of its column in
+// registers and applies them to four rows.  Taps are consumed four at a time (one 12-byte pixel load per row + one
+// 16-byte coefficient load); a last partial group re-reads the final four taps with the already consumed ones
+// masked, so nothing outside [xmin, xmin + xmax) is touched.
 __global__ __launch_bounds__(256) void horizontal_kernel(const uint8_t* __restrict__ pixels, const int64_t* __restrict__ plan,
                                                          int S, const int32_t* __restrict__ ws_coef,
                                                          uint8_t* __restrict__ ws_tmp) {
+  constexpr int R = kRowsPerThread;
   const int64_t* p = plan + (int64_t)blockIdx.y * kPlanStride;
   const int h = (int)p[P_H], w = (int)p[P_W];
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (int64_t)h * S) return;
-  const int y = (int)(t / S), j = (int)(t % S);
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;  // 32-bit index math: the launch is bounded to 2^31 threads
+  const uint32_t hb = (uint32_t)(h + R - 1) / R;
+  if (t >= hb * (uint32_t)S) return;
+  const int y0 = (int)(t / (uint32_t)S) * R, j = (int)(t % (uint32_t)S);
+  const int nrow = h - y0 < R ? h - y0 : R;
   const int32_t* bounds = ws_coef + p[P_COEF_H];
-  const int ksize = (int)p[P_KH];
-  const int32_t* k = bounds + 2 * S + (int64_t)j * ksize;
-  const int xmin = bounds[2 * j], xmax = bounds[2 * j + 1];
-  const uint8_t* src = pixels + p[P_OFF] + ((int64_t)y * w + xmin) * 3;
-  int s0 = 1 << (kPrecisionBits - 1), s1 = s0, s2 = s0;
-  for (int x = 0; x < xmax; ++x) {
-    const int kv = k[x];
-    s0 += (int)src[3 * x] * kv;
-    s1 += (int)src[3 * x + 1] * kv;
-    s2 += (int)src[3 * x + 2] * kv;
+  const int ksize = pad4((int)p[P_KH]);
+  const int32_t* k = bounds + pad4(2 * S) + (int64_t)j * ksize;
+  const int xmin = bounds[2 * j];
+  const int xflag = bounds[2 * j + 1];
+  const int xmax = xflag & ~kWideFlag;
+  const int64_t row_bytes = (int64_t)w * 3;
+  const uint8_t* src = pixels + p[P_OFF] + ((int64_t)y0 * w + xmin) * 3;
+  int acc[R][3];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 1 << (kPrecisionBits - 1);
+  // rows past the image reuse the last valid row (never stored)
+  const uint8_t* rows[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) rows[r] = src + (r < nrow ? r : nrow - 1) * row_bytes;
+  if (xmax >= 4) {
+    if (xflag & kWideFlag) hpass<true, R>(rows, k, xmax, acc);
+    else hpass<false, R>(rows, k, xmax, acc);
+  } else {
+    for (int x = 0; x < xmax; ++x) {
+      const int kv = k[x];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        acc[r][0] += (int)rows[r][3 * x] * kv;
+        acc[r][1] += (int)rows[r][3 * x + 1] * kv;
+        acc[r][2] += (int)rows[r][3 * x + 2] * kv;
+      }
+    }
   }
-  uint8_t* dst = ws_tmp + p[P_TMP] + t * 3;
-  dst[0] = (uint8_t)clip8(s0);
-  dst[1] = (uint8_t)clip8(s1);
-  dst[2] = (uint8_t)clip8(s2);
+  uint8_t* dst = ws_tmp + p[P_TMP] + ((int64_t)y0 * S + j) * 3;
+  if ((S & 3) == 0) {
+    // four adjacent columns (lanes 4m..4m+3, same rows because S % 4 == 0) hold 12 contiguous bytes: lanes 0..2 of
+    // the quad each assemble one aligned dword from their own 24 bits and the next lane's, lane 3 stores nothing
+    const int q = threadIdx.x & 3;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint32_t mine = clip8(acc[r][0]) | (clip8(acc[r][1]) << 8) | (clip8(acc[r][2]) << 16);
+      const uint32_t next = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xF9 /* quad_perm [1,2,3,3] */, 0xF, 0xF, true);
+      const uint32_t word = q == 0 ? (mine | (next << 24)) : q == 1 ? ((mine >> 8) | (next << 16)) : ((mine >> 16) | (next << 8));
+      if (r < nrow && q != 3)
+        *reinterpret_cast<uint32_t*>(dst + (int64_t)r * S * 3 - 3 * q + 4 * q) = word;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (r < nrow) {
+        dst[(int64_t)r * S * 3 + 0] = (uint8_t)clip8(acc[r][0]);
+        dst[(int64_t)r * S * 3 + 1] = (uint8_t)clip8(acc[r][1]);
+        dst[(int64_t)r * S * 3 + 2] = (uint8_t)clip8(acc[r][2]);
+      }
+    }
+  }
 }
 
-// grid (ceil(S * S / 256), B): thread = (kept output row i, kept output column j)
+// grid (ceil(S * ceil(S / 4) / 256), B): thread = (kept output row i, four adjacent kept output columns).  One 12-byte
+// load per tap row feeds 12 accumulators; the normalised result leaves as one 16-byte store per channel.
 __global__ __launch_bounds__(256) void vertical_kernel(const int64_t* __restrict__ plan, int S,
                                                        const int32_t* __restrict__ ws_coef,
                                                        const uint8_t* __restrict__ ws_tmp, Norm nm, float* __restrict__ out,
                                                        uint8_t* __restrict__ out_u8) {
   const int64_t b = blockIdx.y;
   const int64_t* p = plan + b * kPlanStride;
+  const int S4 = (S + 3) >> 2;
   const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= S * S) return;
-  const int i = t / S, j = t % S;
+  if (t >= S * S4) return;
+  const int i = t / S4, j = (t % S4) * 4;
+  const int ncol = S - j < 4 ? S - j : 4;
   const int32_t* bounds = ws_coef + p[P_COEF_V];
-  const int ksize = (int)p[P_KV];
-  const int32_t* k = bounds + 2 * S + (int64_t)i * ksize;
-  const int ymin = bounds[2 * i], ymax = bounds[2 * i + 1];
+  const int ksize = pad4((int)p[P_KV]);
+  const int32_t* k = bounds + pad4(2 * S) + (int64_t)i * ksize;
+  const int ymin = bounds[2 * i], yflag = bounds[2 * i + 1];
+  const int ymax = yflag & ~kWideFlag;
+  const bool wide = (yflag & kWideFlag) != 0;
   const uint8_t* src = ws_tmp + p[P_TMP] + ((int64_t)ymin * S + j) * 3;
-  int s0 = 1 << (kPrecisionBits - 1), s1 = s0, s2 = s0;
-  for (int y = 0; y < ymax; ++y) {
-    const int kv = k[y];
-    const uint8_t* q = src + (int64_t)y * S * 3;
-    s0 += (int)q[0] * kv;
-    s1 += (int)q[1] * kv;
-    s2 += (int)q[2] * kv;
+  int acc[12];
+#pragma unroll
+  for (int q = 0; q < 12; ++q) acc[q] = 1 << (kPrecisionBits - 1);
+  if (ncol == 4 && !wide) {
+#pragma unroll 4
+    for (int y = 0; y < ymax; ++y) {
+      const int kv = k[y];
+      const u32x3 v = load12(src + (int64_t)y * S * 3);
+      const uint32_t wd[3] = {v.x, v.y, v.z};
+#pragma unroll
+      for (int q = 0; q < 12; ++q) acc[q] += bmul<false>((wd[q >> 2] >> (8 * (q & 3))) & 0xff, kv);
+    }
+  } else {
+    for (int y = 0; y < ymax; ++y) {
+      const int kv = k[y];
+      const uint8_t* q8 = src + (int64_t)y * S * 3;
+#pragma unroll
+      for (int q = 0; q < 12; ++q)
+        if (q < 3 * ncol) acc[q] += (int)q8[q] * kv;
+    }
   }
-  const uint32_t u[3] = {clip8(s0), clip8(s1), clip8(s2)};
+  uint32_t u[12];
+#pragma unroll
+  for (int q = 0; q < 12; ++q) u[q] = clip8(acc[q]);  // q = 3 * column + channel
   if (out_u8) {
     uint8_t* d = out_u8 + ((b * S + i) * S + j) * 3;
-    d[0] = (uint8_t)u[0];
-    d[1] = (uint8_t)u[1];
-    d[2] = (uint8_t)u[2];
+    if (ncol == 4) {
+      u32x3 pk;
+      pk.x = u[0] | (u[1] << 8) | (u[2] << 16) | (u[3] << 24);
+      pk.y = u[4] | (u[5] << 8) | (u[6] << 16) | (u[7] << 24);
+      pk.z = u[8] | (u[9] << 8) | (u[10] << 16) | (u[11] << 24);
+      __builtin_memcpy(d, &pk, 12);
+    } else {
+      for (int q = 0; q < 3 * ncol; ++q) d[q] = (uint8_t)u[q];
+    }
   }
   if (out) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       // ToTensor (u / 255) then Normalize ((t - mean) / std): three correctly rounded fp32 operations
-      const float tt = __fdiv_rn((float)u[c], 255.0f);
-      const float dd = __fsub_rn(tt, nm.mean[c]);
-      out[((b * 3 + c) * S + i) * S + j] = __fdiv_rn(dd, nm.stdv[c]);
+      float r[4];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const float tt = __fdiv_rn((float)u[3 * cc + c], 255.0f);
+        r[cc] = __fdiv_rn(__fsub_rn(tt, nm.mean[c]), nm.stdv[c]);
+      }
+      float* o = out + ((b * 3 + c) * S + i) * S + j;
+      if (ncol == 4 && (S & 3) == 0) {
+        *reinterpret_cast<float4*>(o) = make_float4(r[0], r[1], r[2], r[3]);
+      } else {
+        for (int cc = 0; cc < ncol; ++cc) o[cc] = r[cc];
+      }
     }
   }
 }
@@ -205,9 +337,9 @@ SL_API int sl_preprocess_plan(const int32_t* h_hw, const int64_t* h_pixel_offset
     p[P_KH] = axis_ksize((int)w, (int)ow, interp);
     p[P_KV] = axis_ksize((int)h, (int)oh, interp);
     p[P_COEF_H] = coef;
-    coef += (int64_t)S * (2 + p[P_KH]);
+    coef += pad4(2 * S) + (int64_t)S * pad4((int)p[P_KH]);
     p[P_COEF_V] = coef;
-    coef += (int64_t)S * (2 + p[P_KV]);
+    coef += pad4(2 * S) + (int64_t)S * pad4((int)p[P_KV]);
     p[P_TMP] = (int64_t)tmp;
     tmp += align16((size_t)h * (size_t)S * 3);
     pix += h * w * 3;
@@ -239,15 +371,15 @@ SL_API int sl_preprocess(const uint8_t* d_pixels, const int64_t* d_plan, int64_t
     nm.mean[c] = h_mean ? h_mean[c] : 0.f;
     nm.stdv[c] = h_std ? h_std[c] : 1.f;
   }
-  hipLaunchKernelGGL(coeff_kernel, dim3(2, (unsigned)B), dim3(64), 0, st, d_plan, S, interp, coef);
+  hipLaunchKernelGGL(coeff_kernel, dim3(2, (unsigned)B), dim3(256), 0, st, d_plan, S, interp, coef);
   SL_CHECK_HIP(hipGetLastError());
-  const int64_t hb = (max_h * S + 255) / 256;
-  SL_REQUIRE(hb < (1ll << 31), "sl_preprocess: image too tall");
+  const int64_t hb = ((max_h + kRowsPerThread - 1) / kRowsPerThread * S + 255) / 256;
+  SL_REQUIRE(hb < (1ll << 23), "sl_preprocess: image too tall");
   if (hb > 0) {
     hipLaunchKernelGGL(horizontal_kernel, dim3((unsigned)hb, (unsigned)B), dim3(256), 0, st, d_pixels, d_plan, S, coef, tmp);
     SL_CHECK_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(vertical_kernel, dim3((unsigned)(((int64_t)S * S + 255) / 256), (unsigned)B), dim3(256), 0, st, d_plan,
+  hipLaunchKernelGGL(vertical_kernel, dim3((unsigned)(((int64_t)S * ((S + 3) / 4) + 255) / 256), (unsigned)B), dim3(256), 0, st, d_plan,
                      S, coef, tmp, nm, d_out, d_out_u8);
   SL_CHECK_HIP(hipGetLastError());
   return 0;

@@ -82,11 +82,41 @@ def bench_gemm(Q, C, D):
     return {"Q": Q, "C": C, "D": D, "ms": ms, "TFLOPs": 2.0 * Q * C * D / ms / 1e9, "Msim_per_s": Q * C / ms / 1e3}
 
 
+def bench_preprocess(B, h, w, S=224, cpu_images=16):
+    """K12 on a batch of (h, w) RGB images (resident on the device) vs the oracle (Pillow's algorithm) on one core."""
+    import numpy as np
+
+    px = torch.randint(0, 256, (B, h, w, 3), dtype=torch.uint8, device=DEV)
+    plan, info = N.preprocess_plan([(h, w)] * B, S)
+    plan_d = plan.to(DEV)
+    mean, std = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
+    flat = px.reshape(-1)
+    ms = timed(lambda: N.preprocess(flat, plan_d, info, S, mean, std), iters=10)
+    alg = B * (h * w * 3 + 3 * S * S * 4)
+    res = {"B": B, "hw": [h, w], "S": S, "ms": ms, "images_per_s": B / ms * 1e3, "GBps_algorithmic": alg / ms / 1e6}
+    try:
+        import oracle
+
+        imgs = px[:cpu_images].cpu().numpy()
+        t0 = time.perf_counter()
+        for i in range(cpu_images):
+            oracle.preprocess(imgs[i], S, mean, std)
+        res["cpu_oracle_images_per_s_1core"] = cpu_images / (time.perf_counter() - t0)
+    except Exception as e:  # the oracle is optional here
+        res["cpu_oracle"] = repr(e)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only", default=None, help="run one family: preprocess")
     args = ap.parse_args()
     out = []
+    if args.only == "preprocess":
+        for B, h, w in ((256, 500, 375), (256, 375, 500), (256, 224, 224), (64, 1200, 1600)):
+            print(json.dumps(("preprocess", bench_preprocess(B, h, w))), flush=True)
+        return
     shapes = [(256, 512, 28, 28), (256, 1024, 14, 14), (256, 2048, 7, 7), (64, 512, 28, 28), (64, 1024, 14, 14), (64, 2048, 7, 7)]
     if not args.quick:
         shapes += [(256, 192, 56, 56), (256, 1536, 7, 7), (32, 2048, 7, 7), (1024, 2048, 7, 7)]
@@ -110,6 +140,8 @@ def main():
     for q, c, d in ((10000, 768, 1152), (10000, 9216, 1152), (4096, 2048, 512)):
         out.append(("gemm", bench_gemm(q, c, d)))
         print(json.dumps(out[-1]), flush=True)
+    for B, h, w in ((256, 500, 375), (256, 224, 224)):
+        print(json.dumps(("preprocess", bench_preprocess(B, h, w))), flush=True)
 
 
 if __name__ == "__main__":
