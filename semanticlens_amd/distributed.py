@@ -11,6 +11,10 @@ associative and commutative, so the global state is the merge of the per-rank st
 
 No other collective is on the data path.  With ``tie_mode="total"`` the 1/2/4/8-GPU results are
 bit-identical to each other.
+
+Analysis stage (last bullet): the concept DB is small and replicated; ``text_probing_sharded`` shards
+the prompt list through the text tower and the query rows through the cosine GEMM, ``eval_sharded`` shards the
+component axis of clarity / polysemanticity.  Each ends in one all-gather of result rows.
 """
 from __future__ import annotations
 
@@ -148,3 +152,100 @@ def compute_concept_db_sharded(cv, fm, batch_size: int = 64, num_workers: int = 
         name: gather_concept_db_sharded(embeds, start, n_total, cv.get_max_reference(name), group)
         for name in cv.layer_names
     }
+
+
+# ------------------------------------------------------------------------------------------------
+# analysis stage: shard rows, replicate the (small) concept DB, one all-gather of results
+# ------------------------------------------------------------------------------------------------
+def all_gather_rows(part: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """Rank ``r`` holds rows ``shard_range(n_total, r, R)`` of an ``(n_total, ...)`` tensor; every rank gets all of it.
+    One ``all_gather_into_tensor`` of equal blocks of ``ceil(n_total / R)`` rows (short blocks zero padded)."""
+    world = dist.get_world_size(group)
+    per = -(-n_total // world) if n_total else 0
+    tail = tuple(part.shape[1:])
+    if part.shape[0] > per:
+        raise ValueError(f"local part has {part.shape[0]} rows, the shard size is {per}")
+    if per == 0:
+        return part.new_empty((0,) + tail)
+    block = part
+    if part.shape[0] < per:
+        block = part.new_zeros((per,) + tail)
+        block[: part.shape[0]] = part
+    block = block.contiguous()
+    if _host_staged(group) and block.is_cuda:
+        host = torch.empty((world * per,) + tail, dtype=block.dtype)
+        dist.all_gather_into_tensor(host, block.cpu(), group=group)
+        out = host.to(block.device)
+    else:
+        out = torch.empty((world * per,) + tail, dtype=block.dtype, device=block.device)
+        dist.all_gather_into_tensor(out, block, group=group)
+    return out[:n_total]
+
+
+@torch.no_grad()
+def encode_text_sharded(fm, texts: list[str], batch_size: int | None = None, group=None) -> torch.Tensor:
+    """``(len(texts), D)`` text embeddings on every rank; rank ``r`` runs the text tower on its slice only."""
+    from semanticlens_amd.lens import _encode_texts
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lo, hi = shard_range(len(texts), rank, world)
+    local = _encode_texts(fm, texts[lo:hi], batch_size) if hi > lo else None
+    dim = torch.tensor([local.shape[1] if local is not None else 0], dtype=torch.int64, device=fm.device)
+    dist.all_reduce(dim, op=dist.ReduceOp.MAX, group=group)
+    if local is None:
+        local = torch.empty((0, int(dim.item())), dtype=torch.float32, device=fm.device)
+    return all_gather_rows(local.to(torch.float32), len(texts), group)
+
+
+@torch.no_grad()
+def text_probing_sharded(fm, query, aggregated_concept_db, templates=None, batch_size=None, group=None):
+    """Multi-GPU ``Lens.text_probing`` (lens.py:331-362): same result on every rank, equal to the single-process one.
+
+    The (templated) prompt list is sharded through the text tower and all-gathered, the template mean (which mixes
+    prompts of different queries, SURVEY.md finding 4) runs on the full list, then query rows are sharded through the
+    cosine GEMM against the replicated DB and the similarity rows are all-gathered."""
+    from semanticlens_amd.lens import _embed_text_probes, _probe
+
+    queries = query if isinstance(query, list) else [query]
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    embeds = _embed_text_probes(fm, queries, templates, batch_size,
+                                encode=lambda texts, bs: encode_text_sharded(fm, texts, bs, group))
+    Q, D = embeds.shape
+    lo, hi = shard_range(Q, rank, world)
+
+    def quirky(y):  # similarity_score picks its branch from the shapes (scores.py:119-128): keep those layers whole
+        return y.ndim != 2 or y.shape[0] == Q or y.shape[0] == D or y.shape[1] != D
+
+    if isinstance(aggregated_concept_db, torch.Tensor):
+        if quirky(aggregated_concept_db):
+            return _probe(embeds, aggregated_concept_db)
+        return all_gather_rows(_probe(embeds[lo:hi], aggregated_concept_db), Q, group)
+    plain = {k: v for k, v in aggregated_concept_db.items() if not quirky(v)}
+    local = _probe(embeds[lo:hi], plain) if plain else {}
+    out = {}
+    for k, v in aggregated_concept_db.items():  # keep the caller's layer order
+        out[k] = all_gather_rows(local[k], Q, group) if k in local else _probe(embeds, {k: v})[k]
+    return out
+
+
+@torch.no_grad()
+def eval_sharded(score_fn, concept_db, group=None):
+    """Per-component scores (``clarity_score`` / ``polysemanticity_score``: every component is independent) with the
+    component axis sharded across ranks; ``concept_db``: ``(C, n, D)`` tensor or dict of them, replicated."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+
+    def one(V):
+        C = V.shape[0]
+        lo, hi = shard_range(C, rank, world)
+        if hi > lo:
+            part = score_fn(V[lo:hi])
+        else:
+            part = None
+        ref = score_fn(V[:1]) if part is None and C > 0 else part  # dtype/device of the result for an empty shard
+        if part is None:
+            part = ref[:0] if ref is not None else torch.empty(0)
+        return all_gather_rows(part, C, group)
+
+    if isinstance(concept_db, torch.Tensor):
+        return one(concept_db)
+    return {k: one(v) for k, v in concept_db.items()}

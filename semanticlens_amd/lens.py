@@ -44,31 +44,41 @@ def image_probing(fm, query, aggregated_concept_db):
     return _probe(query_embed, aggregated_concept_db)
 
 
+def _encode_texts(fm, texts: list[str], batch_size: int | None = None, progress: bool = False):
+    """``fm.encode_text(fm.tokenize(chunk))`` over ``texts`` in chunks of ``batch_size`` (lens.py:176-191)."""
+    batch_size = batch_size or len(texts)
+    chunks = []
+    for start in tqdm(
+        range(0, len(texts), batch_size), desc="text embedding ...", leave=False, disable=not progress or batch_size == len(texts)
+    ):
+        chunk = texts[start : start + batch_size]
+        chunks.append(fm.encode_text(fm.tokenize(chunk).to(fm.device)))
+    return chunks[0] if len(chunks) == 1 else torch.cat(chunks, dim=0)
+
+
 @torch.no_grad()
-def _embed_text_probes(fm, query: list[str], templates: list[str] | None, batch_size: int | None):
+def _embed_text_probes(fm, query: list[str], templates: list[str] | None, batch_size: int | None, encode=None):
     """Tokenise + encode the (templated) queries; with templates, subtract the empty-template
     embedding and average over templates (lens.py:165-203).
 
     The reference builds the templated list template-major (``for t in templates for q in query``,
     :174) but regroups it query-major (``"(q t) d -> q t d"``, :197).  That grouping is kept
     (SURVEY.md finding 4) so probing scores equal the reference's.
+
+    ``encode(texts, batch_size)`` replaces the local text tower (``distributed.text_probing_sharded`` shards the
+    prompt list across ranks there); each prompt's embedding does not depend on how the list is split.
     """
     if templates:
         query_templated = [t.format(q) for t in templates for q in query]
         empty_templates = [t.format("") for t in templates]
-        batch_size = batch_size or len(query_templated)
-        chunks = []
-        for start in tqdm(
-            range(0, len(query_templated), batch_size),
-            desc="text embedding ...",
-            leave=False,
-            disable=batch_size == len(query_templated),
-        ):
-            chunk = query_templated[start : start + batch_size]
-            chunks.append(fm.encode_text(fm.tokenize(chunk).to(fm.device)))
-        templated = torch.cat(chunks, dim=0)
+        if encode is None:
+            templated = _encode_texts(fm, query_templated, batch_size, progress=True)
+        else:
+            templated = encode(query_templated, batch_size)
         empty = fm.encode_text(fm.tokenize(empty_templates).to(fm.device))
         return N.template_mean(templated, empty, len(query))
+    if encode is not None:
+        return encode(query, None)
     return fm.encode_text(fm.tokenize(query).to(fm.device))
 
 

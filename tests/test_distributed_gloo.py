@@ -76,3 +76,67 @@ def test_sharded_merge_two_ranks_gloo(tmp_path):
             got = np.load(tmp_path / f"rank{r}.npz")
             assert np.array_equal(got[f"v_{name}"].view(np.uint16), ref.vals), (name, r)
             assert np.array_equal(got[f"i_{name}"], ref.ids), (name, r)
+
+
+# ---- analysis stage (text_probing_sharded / eval_sharded): row sharding + one all-gather of results ------------------
+def _analysis_worker(rank, world, port, out_dir):
+    import oracle
+    from helpers import FakeVLM
+    from semanticlens_amd import _native as N
+    from semanticlens_amd import distributed as sld
+    from semanticlens_amd import lens as sl_lens
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # uneven rows, an empty shard on the last rank (n_total=4, world=3 -> blocks of 2)
+        full = torch.arange(4 * 3, dtype=torch.float32).reshape(4, 3)
+        lo, hi = sld.shard_range(4, rank, world)
+        got = sld.all_gather_rows(full[lo:hi], 4)
+        assert torch.equal(got, full), (rank, got)
+        assert sld.all_gather_rows(full[:0], 0).shape == (0, 3)
+
+        # host stand-ins for the two kernels on this path (checker code in a test only)
+        N.template_mean = lambda E, E0, Q: torch.from_numpy(oracle.template_mean(E.numpy(), E0.numpy(), Q))
+        sl_lens._probe = lambda q, db: {k: torch.from_numpy(oracle.similarity(q.numpy(), v.numpy())) for k, v in db.items()}
+        fm = FakeVLM(dim=16)
+        rng = np.random.RandomState(3)
+        db = {"l1": torch.from_numpy(rng.randn(7, 16).astype(np.float32)), "l2": torch.from_numpy(rng.randn(5, 16).astype(np.float32))}
+        queries = ["cat", "dog", "striped zebra", "a", "wheel"]
+        templates = ["a photo of a {}", "an image of {}", "{}"]
+        for tpl in (None, templates):
+            out = sld.text_probing_sharded(fm, queries, db, templates=tpl, batch_size=4)
+            np.savez(os.path.join(out_dir, f"probe_{'tpl' if tpl else 'plain'}_rank{rank}.npz"), **{k: v.numpy() for k, v in out.items()})
+
+        V = torch.from_numpy(rng.randn(5, 6, 16).astype(np.float32))
+        score = lambda v: torch.from_numpy(oracle.clarity(v.numpy()))
+        sc = sld.eval_sharded(score, {"x": V})["x"]
+        np.save(os.path.join(out_dir, f"clarity_rank{rank}.npy"), sc.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_probing_and_scores_three_ranks_gloo(tmp_path):
+    import oracle
+    from helpers import FakeVLM
+    from semanticlens_amd import lens as sl_lens
+
+    world = 3
+    mp.spawn(_analysis_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    # single-process expectation with the same stand-ins
+    fm = FakeVLM(dim=16)
+    rng = np.random.RandomState(3)
+    db = {"l1": rng.randn(7, 16).astype(np.float32), "l2": rng.randn(5, 16).astype(np.float32)}
+    queries = ["cat", "dog", "striped zebra", "a", "wheel"]
+    templates = ["a photo of a {}", "an image of {}", "{}"]
+    enc = lambda texts: fm.encode_text(fm.tokenize(texts)).numpy()
+    plain = enc(queries)
+    templated = oracle.template_mean(enc([t.format(q) for t in templates for q in queries]), enc([t.format("") for t in templates]), len(queries))
+    for tag, emb in (("plain", plain), ("tpl", templated)):
+        for r in range(world):
+            got = np.load(tmp_path / f"probe_{tag}_rank{r}.npz")
+            for k, v in db.items():
+                assert np.array_equal(got[k], oracle.similarity(emb, v)), (tag, r, k)
+    V = rng.randn(5, 6, 16).astype(np.float32)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"clarity_rank{r}.npy"), oracle.clarity(V))
