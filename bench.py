@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--no-probing", action="store_true")
     ap.add_argument("--fm", default="native", choices=["native", "native-f32", "torch"],
                     help="CLIP ViT-B/32 encoder: package kernels (split-bf16 x3 or fp32 MFMA GEMMs) or the torch module")
+    ap.add_argument("--overlap", action="store_true",
+                    help="run the CLIP embed of each batch on a second HIP stream beside forward + collect (+5 %% images/s; "
+                         "K1 then shares HBM with the encoder, so its in-bench roofline fraction drops ~3 points)")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (exhaustive MIOpen search)")
     return ap.parse_args()
 
@@ -74,16 +77,30 @@ def make_cv(model, n_total, k, tie_mode):
     )
 
 
+OVERLAP = False  # --overlap: embed on a second HIP stream beside forward + collect
+
+
 @torch.no_grad()
 def run_steps(cv, fm, batches, id_start, n_local):
     """The timed inner loop: K steps over device-resident uint8 batches."""
     for name in LAYERS:
         cv.actmax_cache.sample_idx_counter[name] = id_start
     embeds, filled = None, 0
+    overlap = OVERLAP
+    main = torch.cuda.current_stream()
+    side = torch.cuda.Stream() if overlap else None
     with cv.actmax_cache.hook_context(cv.model):
         for u8 in batches:
-            cv.collect_batch(synth.normalize_u8(u8, synth.IMAGENET_MEAN, synth.IMAGENET_STD))
-            embeds, filled = cv.embed_batch(fm, u8, embeds, filled, n_local)
+            if overlap:  # hot loop 2 (embed) on a second HIP stream beside hot loop 1 (forward + collect)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    embeds, filled = cv.embed_batch(fm, u8, embeds, filled, n_local)
+                cv.collect_batch(synth.normalize_u8(u8, synth.IMAGENET_MEAN, synth.IMAGENET_STD))
+            else:
+                cv.collect_batch(synth.normalize_u8(u8, synth.IMAGENET_MEAN, synth.IMAGENET_STD))
+                embeds, filled = cv.embed_batch(fm, u8, embeds, filled, n_local)
+    if overlap:
+        main.wait_stream(side)
     return embeds
 
 
@@ -247,6 +264,8 @@ def main():
             dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
+    global OVERLAP
+    OVERLAP = bool(args.overlap)
 
     B, K, W = args.batch, args.steps, args.warmup
     n_local = K * B
@@ -324,7 +343,7 @@ def main():
             "workload": "BASELINE configs[1]: ResNet-50 (random init) layer2-4, synthetic 224x224 images, "
                         "CLIP ViT-B/32 (random init) embed, aggregate_conv_max",
             "images_per_gpu": n_local, "batch": B, "num_samples_k": args.k, "tie_mode": args.tie_mode,
-            "layers": LAYERS, "parallelism": f"shard{world}" if world > 1 else "single",
+            "streams": 2 if args.overlap else 1, "layers": LAYERS, "parallelism": f"shard{world}" if world > 1 else "single",
             "clip_encoder": {"native": "NativeClip (HIP kernels, split-bf16 x3 GEMMs, fp32-class accuracy)",
                              "native-f32": "NativeClip (HIP kernels, fp32-input MFMA GEMMs)",
                              "torch": "torch module (hipBLASLt fp32)"}[args.fm],
