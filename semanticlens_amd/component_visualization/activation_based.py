@@ -233,13 +233,77 @@ class ActivationComponentVisualizer(AbstractComponentVisualizer):
         self._check_layer_name(layer_name)
         return self.actmax_cache.cache[layer_name].sample_ids
 
-    def visualize_components(self, *args, **kwargs):
-        """Plotting of the reference (activation_based.py:453-543) is outside the concept-DB hot path."""
-        raise NotImplementedError(
-            "visualize_components (matplotlib grid rendering) is out of scope of semanticlens_amd; "
-            "use get_max_reference(layer) and plot the samples with the reference package."
-        )
+    def visualize_components(self, component_ids, layer_name: str, n_samples: int = 9, nrows: int = 3, fname=None,
+                             denormalization_fn=None):
+        """Plot the top activating samples of some components (reference: activation_based.py:453-543; host-side
+        matplotlib rendering, not part of the device path).  One tile per component: its first ``n_samples``
+        reference samples from ``self.dataset`` laid out ``nrows`` per row (the reference passes ``nrows`` as
+        ``make_grid``'s images-per-row), tiles arranged in a near-square figure; saved under
+        ``<storage_dir>/plots`` when caching is on."""
+        self._check_layer_name(layer_name)
+        import matplotlib.pyplot as plt
+
+        post = getattr(self.dataset, "denormalization_fn", None) or denormalization_fn or (lambda x: x)
+        ids_all = self.get_max_reference(layer_name=layer_name)
+        component_ids = torch.as_tensor(component_ids).reshape(-1)
+        tiles = []
+        for cid in component_ids.tolist():
+            imgs = [torch.as_tensor(post(self.dataset[int(i)][0])).detach().cpu() for i in ids_all[cid][:n_samples]]
+            tiles.append(_image_grid(imgs, per_row=nrows).permute(1, 2, 0).numpy())
+        n = len(tiles)
+        cols = max(1, int(n**0.5))
+        rows = (n + cols - 1) // cols
+        fig, axs = plt.subplots(rows, cols, figsize=(3 * cols, 3 * rows), squeeze=False)
+        flat = axs.reshape(-1)
+        for ax, tile, cid in zip(flat, tiles, component_ids.tolist()):
+            ax.imshow(tile)
+            ax.set_title(f"Neuron {cid}")
+            ax.set_xticks([])
+            ax.set_yticks([])
+        for ax in flat[n:]:
+            ax.axis("off")
+        model_name = str(getattr(self.model, "name", type(self.model).__name__))
+        plt.suptitle((f"{fname:.15} " if fname else "") + f"{model_name:>.10} {layer_name:<.15}", fontsize=16)
+        plt.tight_layout(rect=[0, 0, 1, 0.96])
+        plt.show()
+        if self.caching:
+            fdir = self.storage_dir / "plots"
+            fdir.mkdir(parents=True, exist_ok=True)
+            tag = "-".join(str(c) for c in component_ids.tolist())
+            fpath = fdir / ((fname + "_" if fname else "") + f"{layer_name}_{tag}.png")
+            plt.savefig(fpath)
+            plt.close(fig)
+            print(f"Saved visualization to {fpath}")
+        elif fname:
+            logger.warning(
+                "Failed to save visualization. Caching is not enabled in the ComponentVisualizer (`cv.caching: False`)"
+            )
+        return fig
 
     def _check_layer_name(self, layer_name):
         if layer_name not in self.layer_names:
             raise ValueError(f"Layer '{layer_name}' not found in model layers: {self.layer_names}")
+
+
+def _image_grid(images: list[torch.Tensor], per_row: int, padding: int = 2) -> torch.Tensor:
+    """``(3, H', W')`` mosaic of equally sized ``(C, H, W)`` images, ``per_row`` per row with a ``padding``-pixel black
+    frame around every cell — the layout ``torchvision.utils.make_grid`` produces (torchvision is not a dependency)."""
+    if not images:
+        raise ValueError("no images to arrange")
+    imgs = []
+    for im in images:
+        im = im.float()
+        if im.ndim == 2:
+            im = im[None]
+        if im.shape[0] == 1:
+            im = im.expand(3, -1, -1)
+        imgs.append(im)
+    C, H, W = imgs[0].shape
+    xm = min(per_row, len(imgs))
+    ym = (len(imgs) + xm - 1) // xm
+    grid = torch.zeros((C, ym * (H + padding) + padding, xm * (W + padding) + padding))
+    for idx, im in enumerate(imgs):
+        r, c = divmod(idx, xm)
+        y0, x0 = r * (H + padding) + padding, c * (W + padding) + padding
+        grid[:, y0 : y0 + H, x0 : x0 + W] = im
+    return grid

@@ -422,3 +422,30 @@ def test_device_preprocess_packs_ragged_batches_and_rejects_bad_input():
     if not torch.cuda.is_available():
         with pytest.raises(N.NativeLibraryError):  # no CPU fallback
             pp([a])
+
+
+def test_visualize_components_renders_and_saves(mock_model, mock_dataset, tmp_path):
+    """Host-side plotting (reference: activation_based.py:453-543): one tile per component from its top samples."""
+    import matplotlib
+
+    matplotlib.use("Agg")
+    from semanticlens_amd.component_visualization.activation_based import _image_grid
+
+    grid = _image_grid([torch.full((3, 4, 5), float(i)) for i in range(5)], per_row=3)
+    assert grid.shape == (3, 2 * 6 + 2, 3 * 7 + 2)  # 2 rows x 3 columns of (4+2) x (5+2) cells + the closing frame
+    assert grid[:, 2:6, 2:7].eq(0).all() and grid[:, 2:6, 9:14].eq(1).all() and grid[:, 8:12, 9:14].eq(4).all()
+    assert grid[:, :2].eq(0).all() and grid[:, :, :2].eq(0).all()
+    assert _image_grid([torch.ones(4, 5)], per_row=3).shape == (3, 8, 9)  # grey image -> 3 channels
+
+    cv = ActivationComponentVisualizer(mock_model, mock_dataset, mock_dataset, ["0"], num_samples=4,
+                                       aggregate_fn=agg.aggregate_conv_mean, cache_dir=tmp_path)
+    am = cv.actmax_cache.cache["0"]
+    am.n_latents, am.is_setup = 5, True
+    am.sample_ids = torch.arange(20).reshape(5, 4) % len(mock_dataset)
+    am.activations = torch.zeros(5, 4, dtype=torch.bfloat16)
+    fig = cv.visualize_components(torch.tensor([0, 3, 4]), "0", n_samples=4, nrows=2, fname="demo")
+    assert len(fig.axes) >= 3
+    saved = list((cv.storage_dir / "plots").glob("demo_0_0-3-4.png"))
+    assert len(saved) == 1 and saved[0].stat().st_size > 0
+    with pytest.raises(ValueError):
+        cv.visualize_components(torch.tensor([0]), "nope")
