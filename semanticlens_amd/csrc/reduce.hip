@@ -316,7 +316,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int G, int U, int OP, bool ALIGNED, int AUX>
 __global__ __launch_bounds__(256) void rowreduce_fast_kernel(const float* __restrict__ x, int64_t R, int S,
                                                               uint16_t* __restrict__ cand,
-                                                              float* __restrict__ outf, int reverse) {
+                                                              float* __restrict__ outf, int reverse, int64_t tail_from) {
   constexpr int RPT = kWave / G;
   constexpr bool SUMOP = (OP == OP_SUM || OP == OP_ABSSUM);
   constexpr bool ABS = (OP == OP_ABSMAX || OP == OP_ABSSUM);
@@ -372,10 +372,20 @@ __global__ __launch_bounds__(256) void rowreduce_fast_kernel(const float* __rest
         off = row_byte0 + (uint32_t)(li < npieces ? li : npieces - 1) * 16u;
       }
       float4 v[U];
+      // batches from `tail_from` on (the part of a just-produced input that is still in the Infinity Cache) are read
+      // with the default policy, the rest (already evicted to HBM) with the streaming one; wave-uniform choice
+      if (AUX != 0 && __builtin_amdgcn_readfirstlane((int)(tb >= tail_from))) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, (int)((uint32_t)u * task_bytes), AUX);
-        v[u] = make_float4(bits_f32(w[0]), bits_f32(w[1]), bits_f32(w[2]), bits_f32(w[3]));
+        for (int u = 0; u < U; ++u) {
+          const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, (int)((uint32_t)u * task_bytes), 0);
+          v[u] = make_float4(bits_f32(w[0]), bits_f32(w[1]), bits_f32(w[2]), bits_f32(w[3]));
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, (int)((uint32_t)u * task_bytes), AUX);
+          v[u] = make_float4(bits_f32(w[0]), bits_f32(w[1]), bits_f32(w[2]), bits_f32(w[3]));
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -567,12 +577,23 @@ void launch_rowreduce_fast(ProfScope& prof, const float* x, int64_t R, int S, ui
     const char* e = getenv("SL_NT_MIN_BYTES");
     return e ? (int64_t)atoll(e) : (int64_t)256 << 20;
   }();
-  if (R * (int64_t)S * 4 >= nt_min_bytes)
+  // Above the Infinity Cache size only the head of a just-produced input has been evicted to HBM; its last ~240 MB
+  // are still cached (dirty).  The head is streamed with nt, the tail read with the default policy (in-bench, 411 MB
+  // layer2 output: 78.7 -> ~70 us; a tail above 256 MB loses again, 288 MB is back to the all-nt time).
+  static const int64_t tail_bytes = [] {
+    const char* e = getenv("SL_REDUCE_TAIL_MB");
+    return (e ? (int64_t)atoll(e) : (int64_t)240) << 20;
+  }();
+  const int64_t bytes = R * (int64_t)S * 4;
+  if (bytes >= nt_min_bytes) {
+    const int64_t batch_bytes = (int64_t)U * RPT * S * 4;
+    const int64_t tail_from = tail_bytes > 0 ? (bytes > tail_bytes ? (bytes - tail_bytes) / batch_bytes : 0) : INT64_MAX;
     SL_LAUNCH(prof, (rowreduce_fast_kernel<G, U, OP, ALIGNED, SL_LOAD_AUX>), dim3((unsigned)blocks), dim3(256), 0, st, x, R, S,
-              cand, outf, reverse);
-  else
+              cand, outf, reverse, tail_from);
+  } else {
     SL_LAUNCH(prof, (rowreduce_fast_kernel<G, U, OP, ALIGNED, 0>), dim3((unsigned)blocks), dim3(256), 0, st, x, R, S, cand,
-              outf, reverse);
+              outf, reverse, (int64_t)INT64_MAX);
+  }
 }
 
 template <int OP>
