@@ -24,7 +24,8 @@ def main(fetch_csv, write_csv, out_json):
     fetch = load(fetch_csv, "FETCH_SIZE")
     write = load(write_csv, "WRITE_SIZE")
     # bench shapes (tools/pmc_target.py): ResNet-50 layer2/3/4 at B=256 fp32, in kernel-template order
-    algo = {"<64, 4, 0, true>": 256 * 512 * 784 * 4, "<64, 8, 0, true>": 256 * 1024 * 196 * 4, "<16, 8, 0, false>": 256 * 2048 * 49 * 4}
+    # (the template list continues with the cache-policy argument, hence prefix matches)
+    algo = {"<64, 4, 0, true,": 256 * 512 * 784 * 4, "<64, 8, 0, true,": 256 * 1024 * 196 * 4, "<16, 8, 0, false,": 256 * 2048 * 49 * 4}
     kernels = {}
     tot_traffic = tot_algo = 0.0
     for name, kib in fetch.items():
