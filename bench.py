@@ -230,7 +230,7 @@ def probing_leg(dev):
         # matrix cores actually issue.
         "roofline": {"bound": "mfma", "achieved": fl3 / ms3 / 1e9, "peak": MFMA_BF16_PEAK_TFLOPS / 3, "unit": "TFLOP/s",
                      "frac": (fl3 / ms3 / 1e9) / (MFMA_BF16_PEAK_TFLOPS / 3),
-                     "kernel": "gemm3_nt (split-bf16 x3 on v_mfma_f32_32x32x16_bf16, fp32-class accuracy)",
+                     "kernel": "gemm3_nt_dma256 (split-bf16 x3 on v_mfma_f32_32x32x16_bf16, 256x128 tiles staged by LDS-DMA, all 12 layers in one launch; fp32-class accuracy)",
                      "mfma_flops_issued_TFLOPs": 3 * fl3 / ms3 / 1e9,
                      "ratio_to_fp32_mfma_peak": (fl3 / ms3 / 1e9) / MFMA_F32_PEAK_TFLOPS,
                      "launches": n3, "avg_ms": ms3 / max(n3, 1)},

@@ -106,6 +106,25 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const float* __restrict__ 
   }
 }
 
+// Epilogue of the fused multi-layer probe: the B operand is the row-wise concatenation of L layers' concept
+// matrices; column `col` belongs to layer l with start[l] <= col < start[l + 1] and goes to outs[l] (Q x C_l).
+// column() runs once per output column and hands the layer index to store() through its float slot.
+constexpr int kMaxFusedLayers = 32;
+struct MultiEpi {
+  float* out[kMaxFusedLayers];
+  int64_t start[kMaxFusedLayers + 1];
+  int n;
+  __device__ float column(int64_t col) const {
+    int l = 0;
+    while (l + 1 < n && col >= start[l + 1]) ++l;
+    return __int_as_float(l);
+  }
+  __device__ void store(int64_t row, int64_t col, float acc, float cv) const {
+    const int l = __float_as_int(cv);
+    out[l][row * (start[l + 1] - start[l]) + (col - start[l])] = acc;
+  }
+};
+
 int launch_inv_norm(const float* x, int64_t rows, int64_t cols, float eps, float* out, hipStream_t st) {
   int64_t blocks = (rows + 3) / 4;
   const int64_t cap = (int64_t)num_cus() * 8;
@@ -171,19 +190,44 @@ size_t cosine_split_bytes(int64_t M, int64_t N, int64_t K) { return split_bytes(
 // normalised and split once, each layer then costs its own split + one GEMM.
 int cosine_matrix_multi(const float* X, int64_t Q, int64_t K, const float* const* Ys, const int64_t* Cs, int L,
                         float* const* outs, unsigned char* ws, hipStream_t st) {
-  int64_t cmax = 0;
-  for (int l = 0; l < L; ++l) cmax = Cs[l] > cmax ? Cs[l] : cmax;
+  int64_t cmax = 0, csum = 0;
+  for (int l = 0; l < L; ++l) {
+    cmax = Cs[l] > cmax ? Cs[l] : cmax;
+    csum += Cs[l];
+  }
+  const bool fast = use_bf16x3() && K % 8 == 0 && K >= 64;
+  const bool fused = fast && L <= kMaxFusedLayers;
+  const int64_t yrows = fused ? csum : cmax;  // rows of the y scratch (all layers, or one at a time)
   float* rx = (float*)ws;
   float* ry = (float*)(ws + align256_((size_t)Q * 4));
-  unsigned char* sp = ws + align256_((size_t)Q * 4) + align256_((size_t)cmax * 4);
-  const bool fast = use_bf16x3() && K % 8 == 0 && K >= 64;
+  unsigned char* sp = ws + align256_((size_t)Q * 4) + align256_((size_t)yrows * 4);
   if (int rc = launch_inv_norm(X, Q, K, 1e-12f, rx, st)) return rc;
   uint16_t* xh = (uint16_t*)sp;
   uint16_t* xl = (uint16_t*)(sp + align256_((size_t)Q * K * 2));
   uint16_t* yh = (uint16_t*)(sp + split_bytes(Q, K));
-  uint16_t* yl = (uint16_t*)(sp + split_bytes(Q, K) + align256_((size_t)cmax * K * 2));
+  uint16_t* yl = (uint16_t*)(sp + split_bytes(Q, K) + align256_((size_t)yrows * K * 2));
   if (fast)
     if (int rc = gemm3::launch_split(X, rx, Q, K, xh, xl, st)) return rc;
+  if (fused) {
+    // every layer is normalised + split into its rows of ONE (sum C, K) operand; a single GEMM launch then fills the
+    // chip (12 x 768 columns: 2880 tiles of 256 x 128 instead of 12 launches of 474 tiles of 128 x 128)
+    MultiEpi epi{};
+    epi.n = 0;
+    int64_t off = 0;
+    for (int l = 0; l < L; ++l) {
+      if (Cs[l] == 0) continue;
+      if (int rc = launch_inv_norm(Ys[l], Cs[l], K, 1e-12f, ry + off, st)) return rc;
+      if (int rc = gemm3::launch_split(Ys[l], ry + off, Cs[l], K, yh + off * K, yl + off * K, st)) return rc;
+      epi.out[epi.n] = outs[l];
+      epi.start[epi.n] = off;
+      ++epi.n;
+      off += Cs[l];
+    }
+    epi.start[epi.n] = off;
+    if (Q * off == 0) return 0;
+    ProfScope prof(SL_PROF_GEMM, st, 2.0 * (double)Q * (double)off * (double)K);
+    return gemm3::launch_gemm3_nt(prof, xh, xl, Q, yh, yl, off, K, epi, st);
+  }
   for (int l = 0; l < L; ++l) {
     if (Q * Cs[l] == 0) continue;
     if (int rc = launch_inv_norm(Ys[l], Cs[l], K, 1e-12f, ry, st)) return rc;
@@ -262,9 +306,9 @@ SL_API int sl_similarity(const float* d_x, int64_t xr, int64_t xc, const float* 
 }
 
 SL_API size_t sl_similarity_multi_ws_bytes(int64_t Q, int64_t K, const int64_t* h_Cs, int L) {
-  int64_t cmax = 0;
-  for (int l = 0; l < L; ++l) cmax = h_Cs[l] > cmax ? h_Cs[l] : cmax;
-  return align256((size_t)Q * 4) + align256((size_t)cmax * 4) + cosine_split_bytes(Q, cmax, K) + 512;
+  int64_t csum = 0;  // the fused path keeps every layer's normalised + split rows at once
+  for (int l = 0; l < L; ++l) csum += h_Cs[l] > 0 ? h_Cs[l] : 0;
+  return align256((size_t)Q * 4) + align256((size_t)csum * 4) + cosine_split_bytes(Q, csum, K) + 512;
 }
 
 SL_API int sl_similarity_multi(const float* d_x, int64_t Q, int64_t K, const float* const* h_d_ys, const int64_t* h_Cs,

@@ -14,6 +14,7 @@
 // on how the hardware orders k inside a fragment.
 #pragma once
 #include "common.hpp"
+#include <cstdlib>
 
 namespace sl {
 namespace gemm3 {
@@ -182,6 +183,154 @@ __global__ __launch_bounds__(256, SL_G3_WAVES) void gemm3_nt_kernel(const uint16
 #endif
 }
 
+// ---- variant 2: 256 x 128 block tile, wave tile 128 x 64, tiles staged by LDS-DMA, single buffer -------------------
+// The register-staged kernel above spends as many LDS cycles on its ds_write_b128 staging stores as on fragment
+// reads (PMC: LDS pipe ~87 % of the MFMA time) and 32 VGPRs on the in-flight tile.  Here each wave issues twelve
+// 1-KiB LDS-DMA loads (global_load_lds_dwordx4) per tile: no VGPR staging, no ds_write.  LDS-DMA writes lane L's 16
+// bytes at base + 16 L, so an image is unpadded rows of 64 bytes; fragment reads stay conflict-free through an XOR
+// swizzle of the 16-byte slot, slot = chunk ^ ((row >> 2) & 3), applied on the SOURCE address of the DMA and on the
+// ds_read address (for every ds_read_b128 lane group the 16 (row % 4, slot) pairs are distinct).  The wave tile is
+// 128 x 64: twice the MFMA work per barrier pair and per fragment read (12 ds_read_b128 feed 24 MFMAs per k-step
+// instead of 8 feeding 12); two workgroups per CU alternate between their DMA/wait phase and their 48-MFMA phase.
+// Accumulation order per output element is the same as in the kernel above: results are bit-identical
+// (tools/g3test.py).  Measured at 10000 x 9216 x 1152: 250 -> 272 TFLOP/s algorithmic including the normalise/split
+// passes; a 128 x 128 DMA variant with double buffering and one barrier per k-step was no faster than the
+// register-staged kernel (246 vs 239) and is not kept.  Used for grids of >= 8 tiles per CU; smaller problems fill
+// the chip better with 128 x 128 tiles.
+__device__ __attribute__((aligned(16))) const uint32_t g_zero16[4] = {0, 0, 0, 0};
+
+constexpr int BM3 = 256;
+constexpr int IMG3A_BYTES = BM3 * 64, IMG3B_BYTES = BN * 64;
+constexpr int BUF3_BYTES = 2 * IMG3A_BYTES + 2 * IMG3B_BYTES;  // A_hi | A_lo | B_hi | B_lo = 48 KB
+
+template <class Epi>
+__global__ __launch_bounds__(256, 2) void gemm3_nt_dma256_kernel(const uint16_t* __restrict__ Ah, const uint16_t* __restrict__ Al,
+                                                                 const uint16_t* __restrict__ Bh, const uint16_t* __restrict__ Bl,
+                                                                 int64_t M, int64_t N, int64_t K, int tiles_n, Epi epi) {
+  __shared__ __align__(1024) unsigned char smem[BUF3_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int tile = blockIdx.x;
+  const int64_t m0 = (int64_t)(tile / tiles_n) * BM3;
+  const int64_t n0 = (int64_t)(tile % tiles_n) * BN;
+
+  floatx16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // DMA: wave w stages A rows [64 w, 64 w + 64) (4 loads per image) and B rows [32 w, 32 w + 32) (2 loads per image)
+  const int lrow = lane >> 2;
+  int64_t a_src[4], b_src[2];  // element offsets of this lane's chunk inside the hi/lo matrices
+  int a_chunk[4], b_chunk[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = w * 64 + i * 16 + lrow;
+    a_chunk[i] = (lane & 3) ^ ((row >> 2) & 3);
+    const int64_t ar = m0 + row < M ? m0 + row : M - 1;
+    a_src[i] = ar * K + a_chunk[i] * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = w * 32 + i * 16 + lrow;
+    b_chunk[i] = (lane & 3) ^ ((row >> 2) & 3);
+    const int64_t br = n0 + row < N ? n0 + row : N - 1;
+    b_src[i] = br * K + b_chunk[i] * 8;
+  }
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  auto dma_tile = [&](int64_t k0, bool partial) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool zero = partial && k0 + a_chunk[i] * 8 >= K;
+      const void* gh = zero ? (const void*)g_zero16 : (const void*)(Ah + a_src[i] + k0);
+      const void* gl = zero ? (const void*)g_zero16 : (const void*)(Al + a_src[i] + k0);
+      unsigned char* l = smem + (w * 64 + i * 16) * 64;
+      __builtin_amdgcn_global_load_lds((glb_void*)gh, (lds_void*)l, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void*)gl, (lds_void*)(l + IMG3A_BYTES), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool zero = partial && k0 + b_chunk[i] * 8 >= K;
+      const void* gh = zero ? (const void*)g_zero16 : (const void*)(Bh + b_src[i] + k0);
+      const void* gl = zero ? (const void*)g_zero16 : (const void*)(Bl + b_src[i] + k0);
+      unsigned char* l = smem + 2 * IMG3A_BYTES + (w * 32 + i * 16) * 64;
+      __builtin_amdgcn_global_load_lds((glb_void*)gh, (lds_void*)l, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void*)gl, (lds_void*)(l + IMG3B_BYTES), 16, 0, 0);
+    }
+  };
+  int a_off[4], a_sw[4], b_off[2], b_sw[2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int ar = wm * 128 + t * 32 + li;
+    a_off[t] = ar * 64;
+    a_sw[t] = (ar >> 2) & 3;
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int br = wn * 64 + t * 32 + li;
+    b_off[t] = 2 * IMG3A_BYTES + br * 64;
+    b_sw[t] = (br >> 2) & 3;
+  }
+  auto compute = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c = ks * 2 + lh;
+      bf16x8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int bo = b_off[t] + ((c ^ b_sw[t]) << 4);
+        bh[t] = *reinterpret_cast<const bf16x8*>(smem + bo);
+        bl[t] = *reinterpret_cast<const bf16x8*>(smem + IMG3B_BYTES + bo);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int ao = a_off[t] + ((c ^ a_sw[t]) << 4);
+        ah[t] = *reinterpret_cast<const bf16x8*>(smem + ao);
+        al[t] = *reinterpret_cast<const bf16x8*>(smem + IMG3A_BYTES + ao);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+
+  const int ntiles = (int)((K + BK - 1) / BK);
+  const bool tail = (K % BK) != 0;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    dma_tile((int64_t)kt * BK, tail && kt + 1 == ntiles);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // the tile has landed for every wave
+    compute();
+    __syncthreads();  // every wave is done reading before the next DMA overwrites the buffer
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t col = n0 + wn * 64 + j * 32 + li;
+      const float cv = col < N ? epi.column(col) : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < M && col < N) epi.store(row, col, acc[i][j][r], cv);
+      }
+    }
+  }
+}
+
 inline int launch_split(const float* x, const float* scale, int64_t R, int64_t K, uint16_t* hi, uint16_t* lo, hipStream_t st) {
   int64_t blocks = (R * K + 255) / 256;
   const int64_t cap = (int64_t)num_cus() * 16;
@@ -199,7 +348,16 @@ int launch_gemm3_nt(ProfScope& prof, const uint16_t* Ah, const uint16_t* Al, int
   SL_REQUIRE(tm * tn < (1ll << 31), "GEMM: too many tiles");
   SL_REQUIRE(K % 8 == 0, "bf16x3 GEMM: K must be a multiple of 8");
   if (tm * tn == 0) return 0;
-  SL_LAUNCH(prof, (gemm3_nt_kernel<Epi>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, Ah, Al, Bh, Bl, M, N, K, (int)tn, epi);
+  static const int forced = [] {
+    const char* e = getenv("SL_G3_TILE");  // 128: register-staged 128 x 128 tiles, 256: LDS-DMA staged 256 x 128 tiles
+    return e ? atoi(e) : 0;
+  }();
+  const int64_t tm3 = (M + BM3 - 1) / BM3;
+  const bool big = forced ? forced == 256 : tm3 * tn >= (int64_t)8 * num_cus();
+  if (big)
+    SL_LAUNCH(prof, (gemm3_nt_dma256_kernel<Epi>), dim3((unsigned)(tm3 * tn)), dim3(256), 0, st, Ah, Al, Bh, Bl, M, N, K, (int)tn, epi);
+  else
+    SL_LAUNCH(prof, (gemm3_nt_kernel<Epi>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, Ah, Al, Bh, Bl, M, N, K, (int)tn, epi);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -503,3 +503,55 @@ def test_probe_dict_uses_one_native_call_and_matches_per_layer():
     # host tensors in -> host tensors out
     host = _probe(q.cpu(), {k: v.cpu() for k, v in db.items() if k != "quirk"})
     assert all(t.device.type == "cpu" for t in host.values())
+
+
+# ---------------------------------------------------------------------------------------------- K6 variants
+def test_fused_multi_layer_probe_equals_per_layer_similarity():
+    """sl_similarity_multi (all layers in ONE GEMM launch, routing epilogue) == sl_similarity layer by layer, bit for
+    bit in both arithmetic modes; ragged layer sizes, an empty layer, column counts that are not tile multiples."""
+    torch.manual_seed(5)
+    q = torch.randn(333, 136, device=DEV)
+    ys = [torch.randn(c, 136, device=DEV) for c in (768, 5, 0, 130, 257, 1024)]
+    try:
+        for mode in ("bf16x3", "f32"):
+            N.set_gemm_mode(mode)
+            outs = N.similarity_multi(q, ys)
+            assert outs is not None and len(outs) == len(ys)
+            for y, o in zip(ys, outs):
+                assert o.shape == (333, y.shape[0])
+                if y.shape[0]:
+                    assert torch.equal(o, N.similarity(q, y)), (mode, y.shape)
+                    ref = oracle.similarity(q.cpu().numpy(), y.cpu().numpy())
+                    assert np.abs(o.cpu().numpy() - ref).max() < 1e-5
+    finally:
+        N.set_gemm_mode(None)
+    # a layer that would hit a shape quirk makes the native call decline (the caller goes layer by layer)
+    assert N.similarity_multi(q, [torch.randn(333, 136, device=DEV)]) is None
+
+
+def test_gemm_tile_variants_are_bit_identical(tmp_path):
+    """The 128x128 register-staged and the 256x128 LDS-DMA staged split-bf16 kernels accumulate every output element
+    in the same order: same bits (the variant is latched per process, hence subprocesses)."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[2])
+from semanticlens_amd import _native as N
+torch.manual_seed(0)
+outs = []
+for (q, c, d) in [(1000, 768, 1152), (130, 257, 64), (129, 128, 72), (1, 5, 4096), (300, 301, 104), (2048, 1024, 512), (513, 259, 200)]:
+    x = torch.randn(q, d, device="cuda:0"); y = torch.randn(c, d, device="cuda:0")
+    outs.append(N.similarity(x, y).cpu())
+torch.save(outs, sys.argv[1])
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tile in ("128", "256"):
+        out = tmp_path / f"g3_{tile}.pt"
+        subprocess.run([sys.executable, "-c", code, str(out), root], check=True, env=dict(os.environ, SL_G3_TILE=tile))
+        res[tile] = torch.load(out)
+    for a, b in zip(res["128"], res["256"]):
+        assert torch.equal(a, b), tuple(a.shape)

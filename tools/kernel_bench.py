@@ -110,9 +110,13 @@ def bench_preprocess(B, h, w, S=224, cpu_images=16):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
-    ap.add_argument("--only", default=None, help="run one family: preprocess")
+    ap.add_argument("--only", default=None, help="run one family: preprocess | gemm")
     args = ap.parse_args()
     out = []
+    if args.only == "gemm":
+        for q, c, d in ((10000, 768, 1152), (10000, 9216, 1152), (4096, 2048, 512), (12800, 768, 768), (12800, 3072, 768), (12800, 768, 3072)):
+            print(json.dumps(("gemm", bench_gemm(q, c, d))), flush=True)
+        return
     if args.only == "preprocess":
         for B, h, w in ((256, 500, 375), (256, 375, 500), (256, 224, 224), (64, 1200, 1600)):
             print(json.dumps(("preprocess", bench_preprocess(B, h, w))), flush=True)
