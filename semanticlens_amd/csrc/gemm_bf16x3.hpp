@@ -195,8 +195,10 @@ __global__ __launch_bounds__(256, SL_G3_WAVES) void gemm3_nt_kernel(const uint16
 // Accumulation order per output element is the same as in the kernel above: results are bit-identical
 // (tools/g3test.py).  Measured at 10000 x 9216 x 1152: 250 -> 272 TFLOP/s algorithmic including the normalise/split
 // passes; a 128 x 128 DMA variant with double buffering and one barrier per k-step was no faster than the
-// register-staged kernel (246 vs 239) and is not kept.  Used for grids of >= 8 tiles per CU; smaller problems fill
-// the chip better with 128 x 128 tiles.
+// register-staged kernel (246 vs 239) and is not kept; nor are two prefetching forms of this kernel, both slower than
+// letting two co-resident workgroups cover each other: double-buffered 32-wide stages (96 KB, one workgroup per CU:
+// 245 vs 270) and double-buffered 16-wide stages (48 KB, two per CU, twice the barriers: 230).  Used for grids of
+// >= 8 tiles per CU; smaller problems fill the chip better with 128 x 128 tiles.
 __device__ __attribute__((aligned(16))) const uint32_t g_zero16[4] = {0, 0, 0, 0};
 
 constexpr int BM3 = 256;
