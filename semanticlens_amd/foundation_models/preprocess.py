@@ -92,18 +92,24 @@ class DevicePreprocess:
         return self
 
     def pack(self, imgs):
-        """Host side of a batch: raw bytes concatenated into one pinned buffer + the launch plan."""
+        """Host side of a batch: raw bytes concatenated into one pinned staging buffer + the launch plan.  Two
+        staging buffers alternate; a buffer is reused only after the upload that last read it has completed."""
         arrays = [_rgb_bytes(i) for i in imgs]
         hw = [a.shape[:2] for a in arrays]
         plan, info = N.preprocess_plan(hw, self.size, self.resize_mode, self.interpolation)
-        buf = torch.empty((max(info["pixel_bytes"], 1),), dtype=torch.uint8)
-        if torch.cuda.is_available():
-            buf = buf.pin_memory()
-        view = buf.numpy()
-        off = 0
-        for a in arrays:
-            view[off : off + a.size] = a.reshape(-1)
-            off += a.size
+        total = info["pixel_bytes"]
+        slot = self._slot = (getattr(self, "_slot", 1) + 1) % 2
+        stage = self.__dict__.setdefault("_staging", [None, None])
+        events = self.__dict__.setdefault("_events", [None, None])
+        if events[slot] is not None:
+            events[slot].synchronize()
+            events[slot] = None
+        if stage[slot] is None or stage[slot].numel() < max(total, 1):
+            buf = torch.empty((max(total, 1) * 5 // 4 + 64,), dtype=torch.uint8)
+            stage[slot] = buf.pin_memory() if torch.cuda.is_available() else buf
+        buf = stage[slot][: max(total, 1)]
+        if arrays:
+            np.concatenate([a.reshape(-1) for a in arrays], out=buf.numpy()[:total])
         return buf, plan, info
 
     def __call__(self, img):
@@ -114,6 +120,10 @@ class DevicePreprocess:
         dev = self._device or N.default_device()
         buf, plan, info = self.pack(imgs)
         pixels = buf.to(dev, non_blocking=True)
+        if buf.is_pinned():  # the staging buffer may be rewritten once this upload is done
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            self._events[self._slot] = ev
         out, _ = N.preprocess(pixels, plan, info, self.size, self.mean, self.std, self.interpolation)
         return out[0] if single else out
 
