@@ -449,3 +449,74 @@ def test_visualize_components_renders_and_saves(mock_model, mock_dataset, tmp_pa
     assert len(saved) == 1 and saved[0].stat().st_size > 0
     with pytest.raises(ValueError):
         cv.visualize_components(torch.tensor([0]), "nope")
+
+
+# ---- foundation_models.clip wrappers (reference tests/foundation_models/test_clip.py) with a stand-in open_clip -------
+@pytest.fixture
+def fake_open_clip(monkeypatch):
+    """open_clip is third-party and not installed here: a stand-in module with the two entry points the wrappers use,
+    recording how it was called.  The towers are tiny torch modules with CLIP's encode_* / context_length surface."""
+    import types
+
+    calls = []
+
+    class Tiny(nn.Module):
+        context_length = 7
+
+        def __init__(self):
+            super().__init__()
+            self.img = nn.Linear(3 * 8 * 8, 12)
+            self.txt = nn.Embedding(50, 12)
+
+        def encode_image(self, x):
+            return self.img(x.flatten(1))
+
+        def encode_text(self, t):
+            return self.txt(t).mean(1)
+
+    def create_model_and_transforms(url, **kwargs):
+        calls.append(("create", url, kwargs))
+        to_tensor = lambda im: torch.from_numpy(np.asarray(im.resize((8, 8)), dtype=np.float32)).permute(2, 0, 1) / 255  # noqa: E731
+        return Tiny(), None, to_tensor
+
+    def get_tokenizer(url):
+        calls.append(("tokenizer", url))
+        return lambda txt, context_length: torch.stack(
+            [torch.tensor(([ord(c) % 50 for c in s] + [0] * context_length)[:context_length]) for s in ([txt] if isinstance(txt, str) else txt)])
+
+    mod = types.ModuleType("open_clip")
+    mod.create_model_and_transforms, mod.get_tokenizer = create_model_and_transforms, get_tokenizer
+    monkeypatch.setitem(sys.modules, "open_clip", mod)
+    return calls
+
+
+def test_open_clip_wrappers_shapes_and_plumbing(fake_open_clip):
+    from PIL import Image
+
+    from semanticlens_amd.foundation_models import ClipMobile, OpenClip, SigLipV2
+
+    img, text = Image.new("RGB", (64, 64), color="red"), ["a red square", "a photo of a cat"]
+    fm = OpenClip(url="ViT-B-32-quickgelu", device="cpu", load_weights=False)
+    assert fake_open_clip[0] == ("create", "ViT-B-32-quickgelu", {"load_weights": False})
+    assert "cpu" in str(fm.device) and "OpenClip(url='ViT-B-32-quickgelu'" in repr(fm)
+    x = fm.preprocess(img)
+    assert x.ndim == 4  # a single image gets a batch axis (clip.py:160-162)
+    assert fm.preprocess([img, img]).shape[0] == 2
+    fi, ft = fm.encode_image(x), fm.encode_text(fm.tokenize(text))
+    assert fi.shape == (1, 12) and ft.shape == (2, 12) and not fi.requires_grad
+    assert fm.tokenize(text).shape == (2, 7) and fm.tokenize(text, context_length=5).shape == (2, 5)
+    for cls, url, extra in ((SigLipV2, "hf-hub:timm/ViT-B-16-SigLIP2", {}), (ClipMobile, "MobileCLIP-S1", {"pretrained": "datacompdr"})):
+        del fake_open_clip[:]
+        fm = cls(device="cpu", load_weights=False)
+        assert fake_open_clip[0] == ("create", url, {**extra, "load_weights": False}) and fake_open_clip[1] == ("tokenizer", url)
+        assert fm.encode_image(fm.preprocess(img)).shape[1] == fm.encode_text(fm.tokenize(text)).shape[1]
+    assert ClipMobile(version="s2").url == "MobileCLIP-S2"
+
+
+def test_open_clip_missing_raises_import_error():
+    from semanticlens_amd.foundation_models import OpenClip
+
+    if "open_clip" in sys.modules:
+        pytest.skip("open_clip importable here")
+    with pytest.raises(ImportError):
+        OpenClip("ViT-B-32")
