@@ -520,3 +520,26 @@ def test_open_clip_missing_raises_import_error():
         pytest.skip("open_clip importable here")
     with pytest.raises(ImportError):
         OpenClip("ViT-B-32")
+
+
+def test_device_preprocess_from_transform_reads_open_clip_pipeline():
+    """from_transform introspects a torchvision-style Compose by class name (torchvision itself is not installed)."""
+    from semanticlens_amd.foundation_models import DevicePreprocess
+
+    def T(name, **attrs):
+        return type(name, (), attrs)()
+
+    class Interp:
+        value = "bicubic"
+
+    shortest = T("Compose", transforms=[T("Resize", size=224, interpolation=Interp()), T("CenterCrop", size=(224, 224)),
+                                        T("_convert_to_rgb"), T("ToTensor"), T("Normalize", mean=(0.5, 0.4, 0.3), std=(0.2, 0.25, 0.3))])
+    pp = DevicePreprocess.from_transform(shortest)
+    assert (pp.size, pp.resize_mode, pp.interpolation, pp.mean, pp.std) == (224, "shortest", "bicubic", (0.5, 0.4, 0.3), (0.2, 0.25, 0.3))
+    squash = T("Compose", transforms=[T("Resize", size=(256, 256), interpolation="bilinear"), T("ToTensor")])
+    pp = DevicePreprocess.from_transform(squash)
+    assert (pp.size, pp.resize_mode, pp.interpolation) == (256, "squash", "bilinear")
+    with pytest.raises(ValueError):
+        DevicePreprocess.from_transform(T("Compose", transforms=[T("ToTensor")]))
+    with pytest.raises(ValueError):
+        DevicePreprocess.from_transform(T("Compose", transforms=[T("Resize", size=224, interpolation=Interp()), T("CenterCrop", size=200)]))
