@@ -7,6 +7,9 @@
 // gemm_f32.hpp with bias / GELU / residual (and, for the patch embedding, the token scatter + positional
 // add) fused into its epilogue; LayerNorm, attention and patch extraction are small bandwidth-bound kernels.
 // The orchestration (weights, layer loop) lives in semanticlens_amd/foundation_models/native_clip.py.
+#include <cstdlib>
+#include <cstring>
+
 #include "gemm_bf16x3.hpp"
 #include "gemm_f32.hpp"
 
@@ -181,6 +184,138 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
   }
 }
 
+// ---- the same attention on the fp32-input matrix cores ---------------------------------------------------------
+// The VALU kernel above re-reads K and V from LDS for every group of 16 query rows (1.6 MB of LDS traffic per head at
+// T = 50) and is LDS-bandwidth bound.  Here a wave owns 32 query rows and works on 32-key tiles with
+// v_mfma_f32_32x32x2_f32 (exact fp32 products and accumulation):
+//   S^T (keys x queries) = K Q^T : A = K rows from LDS (lane l: key l % 32, dims 32 (l / 32) + s), B = Q^T from
+//                                  registers (lane l: query l % 32, the same 32 dims, pre-scaled by 1/8)
+//   O^T (dims x queries) += V^T P^T : computing the TRANSPOSED scores puts P^T in the accumulator exactly where the B
+//                                  operand of this product wants it: k-step s takes keys (s&3) + 8 (s>>2) + 4 (l/32),
+//                                  the rows accumulator register s holds, so P never moves between lanes or through LDS
+// Online softmax per query = per lane (its two half-waves combine max and sum with one cross-half exchange each).
+// K / V rows are padded to 68 floats: the 16-byte K fragment reads are conflict-free, V is read one float per lane.
+typedef float floatx16_t __attribute__((ext_vector_type(16)));
+constexpr int kKvLd = 68;
+
+__device__ inline float xhalf(float v) {  // value held by the lane 32 away
+  return __shfl_xor(v, 32, 64);
+}
+
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv, int T, int H, int causal,
+                                                              float* __restrict__ out, uint16_t* __restrict__ oh,
+                                                              uint16_t* __restrict__ ol) {
+  extern __shared__ __align__(16) float smem[];
+  const int Tp = (T + 31) & ~31;
+  float* sK = smem;                       // Tp x 68
+  float* sV = smem + (size_t)Tp * kKvLd;  // Tp x 68
+  const int tid = threadIdx.x;
+  const int nwaves = blockDim.x >> 6;
+  const int w = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int64_t b = blockIdx.x / H;
+  const int h = blockIdx.x % H;
+  const int64_t ld = 3ll * H * kDh;
+  const float* base = qkv + b * T * ld + h * kDh;
+  for (int e = tid; e < Tp * (kDh / 4); e += blockDim.x) {
+    const int t = e / (kDh / 4), c = e % (kDh / 4);
+    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+    if (t < T) {
+      kv = *reinterpret_cast<const float4*>(base + t * ld + (int64_t)H * kDh + c * 4);
+      vv = *reinterpret_cast<const float4*>(base + t * ld + 2ll * H * kDh + c * 4);
+    }
+    *reinterpret_cast<float4*>(sK + (size_t)t * kKvLd + c * 4) = kv;
+    *reinterpret_cast<float4*>(sV + (size_t)t * kKvLd + c * 4) = vv;
+  }
+  __syncthreads();
+  const int nqt = Tp / 32;
+  for (int qt = w; qt < nqt; qt += nwaves) {
+    const int q = qt * 32 + li;  // this lane's query row (both half-waves)
+    float qf[32];
+    {
+      const float* qp = base + (int64_t)(q < T ? q : T - 1) * ld + lh * 32;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(qp + c * 4);
+        qf[4 * c] = v.x * 0.125f; qf[4 * c + 1] = v.y * 0.125f; qf[4 * c + 2] = v.z * 0.125f; qf[4 * c + 3] = v.w * 0.125f;
+      }
+    }
+    floatx16_t o0, o1;  // O^T: dims 0..31 and 32..63 (rows) x this lane's query
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o0[e] = o1[e] = 0.f;
+    float m = -__builtin_huge_valf(), l = 0.f;
+    const int nkt = causal ? qt + 1 : nqt;
+    for (int kt = 0; kt < nkt; ++kt) {
+      floatx16_t st;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) st[e] = 0.f;
+      const float* kp = sK + (size_t)(kt * 32 + li) * kKvLd + lh * 32;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float4 kv = *reinterpret_cast<const float4*>(kp + c * 4);
+        st = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.x, qf[4 * c], st, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.y, qf[4 * c + 1], st, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.z, qf[4 * c + 2], st, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.w, qf[4 * c + 3], st, 0, 0, 0);
+      }
+      // st[r] = score of key kt*32 + (r&3) + 8 (r>>2) + 4 lh against query q
+      float mx = -__builtin_huge_valf();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const bool masked = key >= T || (causal && key > q);
+        st[r] = masked ? -__builtin_huge_valf() : st[r];
+        mx = fmaxf(mx, st[r]);
+      }
+      mx = fmaxf(mx, xhalf(mx));
+      const float mn = fmaxf(m, mx);  // key 0 is never masked for a valid query, so mn is finite from the first tile on
+      const float alpha = expf(m - mn);
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[r] = expf(st[r] - mn);  // exp(-inf) = 0 for masked keys
+        ps += st[r];
+      }
+      ps += xhalf(ps);
+      l = l * alpha + ps;
+      m = mn;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        o0[e] *= alpha;
+        o1[e] *= alpha;
+      }
+      // O^T += V^T P^T: k-step s covers keys (s&3) + 8 (s>>2) + 4 (lane/32), whose probabilities are st[s]
+      const float* vp = sV + (size_t)(kt * 32 + 4 * lh) * kKvLd + li;
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) {
+        const float* vr = vp + (size_t)((s2 & 3) + 8 * (s2 >> 2)) * kKvLd;
+        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[0], st[s2], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[32], st[s2], o1, 0, 0, 0);
+      }
+    }
+    if (q < T) {
+      const float inv = 1.f / l;
+      const int64_t obase = (b * T + q) * (int64_t)H * kDh + h * kDh;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {  // accumulator registers 4g..4g+3 are dims 8g + 4 lh + (0..3)
+        const int d = 8 * g + 4 * lh;
+        const float4 v0 = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+        const float4 v1 = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        if (out) {
+          *reinterpret_cast<float4*>(out + obase + d) = v0;
+          *reinterpret_cast<float4*>(out + obase + 32 + d) = v1;
+        }
+        if (oh) {
+          store_split(v0.x, obase + d, oh, ol); store_split(v0.y, obase + d + 1, oh, ol);
+          store_split(v0.z, obase + d + 2, oh, ol); store_split(v0.w, obase + d + 3, oh, ol);
+          store_split(v1.x, obase + 32 + d, oh, ol); store_split(v1.y, obase + 33 + d, oh, ol);
+          store_split(v1.z, obase + 34 + d, oh, ol); store_split(v1.w, obase + 35 + d, oh, ol);
+        }
+      }
+    }
+  }
+}
+
 // ---- patch extraction: (B, C, Hi, Wi) -> (B * gh * gw, C * P * P), k = c*P*P + py*P + px (conv weight order) --
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, int64_t B, int C, int Hi, int Wi,
                                                         int P, float* __restrict__ out, uint16_t* __restrict__ oh,
@@ -293,6 +428,21 @@ SL_API int sl_attention(const float* d_qkv, int64_t B, int64_t T, int64_t H, int
   if (B == 0) return 0;
   SL_REQUIRE(d_qkv && (d_out || (d_out_hi && d_out_lo)), "sl_attention: null pointer");
   SL_REQUIRE(B * H < (1ll << 31), "sl_attention: too many heads");
+  static const int impl = [] {
+    const char* e = getenv("SL_ATTENTION_IMPL");  // "valu": the 4-lanes-per-row kernel; default: fp32-MFMA kernel
+    return (e && strcmp(e, "valu") == 0) ? 0 : 1;
+  }();
+  if (impl == 1) {
+    const int64_t Tp = (T + 31) & ~(int64_t)31;
+    const size_t smem = (size_t)Tp * kKvLd * 4 * 2;
+    const int waves = (int)(Tp / 32 < 4 ? Tp / 32 : 4);
+    if (smem > 64 * 1024)
+      SL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(attention_mfma_kernel, dim3((unsigned)(B * H)), dim3(64 * waves), smem, (hipStream_t)stream, d_qkv, (int)T,
+                       (int)H, causal, d_out, d_out_hi, d_out_lo);
+    SL_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   const size_t smem = (size_t)T * kDh * 4 * 2;
   if (smem > 64 * 1024)
     SL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

@@ -107,3 +107,23 @@ def test_native_clip_drops_into_lens_pipeline():
     probe_t = Lens(fm, device=DEV).text_probing(["cat", "dog"], {"1": db_torch["1"].mean(1)})
     probe_n = Lens(NativeClip(fm), device=DEV).text_probing(["cat", "dog"], {"1": db_native["1"].mean(1)})
     np.testing.assert_allclose(probe_n["1"].cpu().numpy(), probe_t["1"].cpu().numpy(), rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("T,causal", [(1, False), (31, True), (32, False), (33, True), (50, False), (64, True), (77, True),
+                                       (130, False), (197, False), (256, True)])
+def test_attention_matches_fp32_softmax_reference(T, causal):
+    """sl_attention (fp32 matrix-core kernel) against softmax(q k^T / 8) v in torch fp32, head by head; the split
+    (hi, lo) output form carries the same values."""
+    g = torch.Generator(device=DEV).manual_seed(T)
+    B, H = 2, 3
+    qkv = torch.randn(B * T, 3 * H * 64, device=DEV, generator=g)
+    q, k, v = (qkv.reshape(B, T, 3, H, 64)[:, :, i].permute(0, 2, 1, 3) for i in range(3))  # (B, H, T, 64)
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    if causal:
+        s = s + torch.full((T, T), float("-inf"), device=DEV).triu_(1)
+    want = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * T, H * 64)
+    got = N.attention(qkv, B, T, H, 64, causal)
+    assert (got - want).abs().max().item() < 2e-6 * max(1.0, want.abs().max().item()), (T, causal)
+    sp = N.Split(B * T, H * 64, DEV)
+    N.attention(qkv, B, T, H, 64, causal, out_split=sp)
+    assert (sp.hi.float() + sp.lo.float() - got).abs().max().item() <= 2.0 ** -16 * got.abs().max().item() + 1e-9
