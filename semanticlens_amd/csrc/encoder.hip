@@ -68,7 +68,19 @@ int run_linear3(ProfScope& prof, const uint16_t* xh, const uint16_t* xl, int64_t
   return gemm3::launch_gemm3_nt(prof, xh, xl, M, wh, wl, N, K, epi, st);
 }
 
-// ---- LayerNorm over the last dim: one wave per row, three passes over the (L1-resident) row ---------------
+// ---- LayerNorm over the last dim: one wave per row -------------------------------------------------------------
+// Fast path (cols % 4 == 0, cols <= 1024, 16-byte aligned rows): the row is read once into registers (up to four
+// float4 per lane), mean and variance are two wave reductions, the result leaves as 16-byte fp32 stores or as
+// 8-byte packed bf16 hi / lo stores.  Other shapes: three passes over the (L1-resident) row.
+__device__ inline void store_split4(const float4 y, int64_t idx, uint16_t* hi, uint16_t* lo) {
+  const uint16_t h0 = f32_to_bf16_rne(y.x), h1 = f32_to_bf16_rne(y.y), h2 = f32_to_bf16_rne(y.z), h3 = f32_to_bf16_rne(y.w);
+  const uint16_t l0 = f32_to_bf16_rne(y.x - bf16_to_f32(h0)), l1 = f32_to_bf16_rne(y.y - bf16_to_f32(h1));
+  const uint16_t l2 = f32_to_bf16_rne(y.z - bf16_to_f32(h2)), l3 = f32_to_bf16_rne(y.w - bf16_to_f32(h3));
+  *reinterpret_cast<uint2*>(hi + idx) = make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16));
+  *reinterpret_cast<uint2*>(lo + idx) = make_uint2((uint32_t)l0 | ((uint32_t)l1 << 16), (uint32_t)l2 | ((uint32_t)l3 << 16));
+}
+
+template <bool FAST>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t rows, int cols,
                                                          int64_t xs, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps,
@@ -77,6 +89,50 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nw = (int64_t)gridDim.x * 4;
+  if constexpr (FAST) {
+    const int nq = cols >> 2;  // float4 chunks per row, <= 256
+    float4 g[4], bt[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = lane + 64 * j;
+      g[j] = q < nq ? reinterpret_cast<const float4*>(gamma)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      bt[j] = q < nq ? reinterpret_cast<const float4*>(beta)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int64_t r = wave; r < rows; r += nw) {
+      const float4* p = reinterpret_cast<const float4*>(x + r * xs);
+      float4 v[4];
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int q = lane + 64 * j;
+        v[j] = q < nq ? p[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+      }
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+      const float mean = s / (float)cols;
+      float var = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (lane + 64 * j < nq) {
+          const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
+          var += (a * a + b * b) + (c * c + d * d);
+        }
+      }
+      for (int off = 32; off > 0; off >>= 1) var += __shfl_xor(var, off, 64);
+      const float rstd = 1.f / sqrtf(var / (float)cols + eps);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int q = lane + 64 * j;
+        if (q < nq) {
+          const float4 y = make_float4((v[j].x - mean) * rstd * g[j].x + bt[j].x, (v[j].y - mean) * rstd * g[j].y + bt[j].y,
+                                       (v[j].z - mean) * rstd * g[j].z + bt[j].z, (v[j].w - mean) * rstd * g[j].w + bt[j].w);
+          if (out) *reinterpret_cast<float4*>(out + r * os + q * 4) = y;
+          if (oh) store_split4(y, r * os + q * 4, oh, ol);
+        }
+      }
+    }
+    return;
+  }
   for (int64_t r = wave; r < rows; r += nw) {
     const float* p = x + r * xs;
     float s = 0.f;
@@ -414,8 +470,15 @@ SL_API int sl_layernorm(const float* d_x, int64_t rows, int64_t cols, int64_t x_
   int64_t blocks = (rows + 3) / 4;
   const int64_t cap = (int64_t)num_cus() * 8;
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_x, rows, (int)cols,
-                     x_row_stride, d_gamma, d_beta, eps, d_out, out_row_stride, d_out_hi, d_out_lo);
+  const uintptr_t ptrs = (uintptr_t)d_x | (uintptr_t)d_gamma | (uintptr_t)d_beta | (uintptr_t)d_out | (uintptr_t)d_out_hi |
+                         (uintptr_t)d_out_lo;
+  const bool fast = cols % 4 == 0 && cols <= 1024 && x_row_stride % 4 == 0 && out_row_stride % 4 == 0 && (ptrs & 15) == 0;
+  if (fast)
+    hipLaunchKernelGGL(layernorm_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_x, rows, (int)cols,
+                       x_row_stride, d_gamma, d_beta, eps, d_out, out_row_stride, d_out_hi, d_out_lo);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_x, rows, (int)cols,
+                       x_row_stride, d_gamma, d_beta, eps, d_out, out_row_stride, d_out_hi, d_out_lo);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
 }

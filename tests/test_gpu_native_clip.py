@@ -127,3 +127,17 @@ def test_attention_matches_fp32_softmax_reference(T, causal):
     sp = N.Split(B * T, H * 64, DEV)
     N.attention(qkv, B, T, H, 64, causal, out_split=sp)
     assert (sp.hi.float() + sp.lo.float() - got).abs().max().item() <= 2.0 ** -16 * got.abs().max().item() + 1e-9
+
+
+@pytest.mark.parametrize("cols", [4, 130, 200, 768, 1024, 1028, 2048])
+def test_layernorm_paths(cols):
+    """register-cached fast path (cols % 4 == 0, <= 1024) and the three-pass fallback, fp32 and split outputs, and a
+    strided input (every 5th row, as the class-token pick of the vision tower does)."""
+    g = torch.Generator(device=DEV).manual_seed(cols)
+    x = torch.randn(77, cols, device=DEV, generator=g) * 3 + 1
+    gam, bet = torch.randn(cols, device=DEV, generator=g), torch.randn(cols, device=DEV, generator=g)
+    want = torch.nn.functional.layer_norm(x, (cols,), gam, bet, 1e-5)
+    assert rel_err(N.layernorm(x, gam, bet, 1e-5), want) < 1e-5
+    sp = N.layernorm(x, gam, bet, 1e-5, out_split=N.Split(77, cols, DEV))
+    assert rel_err(sp.hi.float() + sp.lo.float(), want) < 1e-5
+    assert rel_err(N.layernorm(x, gam, bet, 1e-5, rows=16, x_row_stride=5 * cols), want[::5]) < 1e-5
