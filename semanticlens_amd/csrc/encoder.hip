@@ -258,13 +258,16 @@ __device__ inline float xhalf(float v) {  // value held by the lane 32 away
   return __shfl_xor(v, 32, 64);
 }
 
+constexpr int kAttnChunk = 256;  // keys resident in LDS at a time (2 x 256 x 68 floats = 136 KB)
+
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv, int T, int H, int causal,
                                                               float* __restrict__ out, uint16_t* __restrict__ oh,
                                                               uint16_t* __restrict__ ol) {
   extern __shared__ __align__(16) float smem[];
   const int Tp = (T + 31) & ~31;
-  float* sK = smem;                       // Tp x 68
-  float* sV = smem + (size_t)Tp * kKvLd;  // Tp x 68
+  const int KC = Tp < kAttnChunk ? Tp : kAttnChunk;  // keys per LDS chunk (multiple of 32)
+  float* sK = smem;                       // KC x 68
+  float* sV = smem + (size_t)KC * kKvLd;  // KC x 68
   const int tid = threadIdx.x;
   const int nwaves = blockDim.x >> 6;
   const int w = tid >> 6, lane = tid & 63;
@@ -273,19 +276,13 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
   const int h = blockIdx.x % H;
   const int64_t ld = 3ll * H * kDh;
   const float* base = qkv + b * T * ld + h * kDh;
-  for (int e = tid; e < Tp * (kDh / 4); e += blockDim.x) {
-    const int t = e / (kDh / 4), c = e % (kDh / 4);
-    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-    if (t < T) {
-      kv = *reinterpret_cast<const float4*>(base + t * ld + (int64_t)H * kDh + c * 4);
-      vv = *reinterpret_cast<const float4*>(base + t * ld + 2ll * H * kDh + c * 4);
-    }
-    *reinterpret_cast<float4*>(sK + (size_t)t * kKvLd + c * 4) = kv;
-    *reinterpret_cast<float4*>(sV + (size_t)t * kKvLd + c * 4) = vv;
-  }
-  __syncthreads();
-  const int nqt = Tp / 32;
-  for (int qt = w; qt < nqt; qt += nwaves) {
+  const int nqt = Tp / 32, kct = KC / 32;
+  int loaded = -1;  // first key tile of the chunk in LDS (workgroup-uniform)
+  // rounds of `nwaves` query tiles; within a round the waves walk the key chunks together (longer sequences than one
+  // chunk re-stream K / V from L2 once per round)
+  for (int qt0 = 0; qt0 < nqt; qt0 += nwaves) {
+    const int qt = qt0 + w;
+    const bool active = qt < nqt;
     const int q = qt * 32 + li;  // this lane's query row (both half-waves)
     float qf[32];
     {
@@ -300,56 +297,78 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
 #pragma unroll
     for (int e = 0; e < 16; ++e) o0[e] = o1[e] = 0.f;
     float m = -__builtin_huge_valf(), l = 0.f;
-    const int nkt = causal ? qt + 1 : nqt;
-    for (int kt = 0; kt < nkt; ++kt) {
-      floatx16_t st;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) st[e] = 0.f;
-      const float* kp = sK + (size_t)(kt * 32 + li) * kKvLd + lh * 32;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const float4 kv = *reinterpret_cast<const float4*>(kp + c * 4);
-        st = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.x, qf[4 * c], st, 0, 0, 0);
-        st = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.y, qf[4 * c + 1], st, 0, 0, 0);
-        st = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.z, qf[4 * c + 2], st, 0, 0, 0);
-        st = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.w, qf[4 * c + 3], st, 0, 0, 0);
+    const int round_last = qt0 + nwaves < nqt ? qt0 + nwaves : nqt;  // key tiles any wave of this round may need
+    const int nkt_round = causal ? round_last : nqt;
+    const int nkt = !active ? 0 : (causal ? qt + 1 : nqt);
+    for (int kc0 = 0; kc0 < nkt_round; kc0 += kct) {
+      if (kc0 != loaded) {
+        if (loaded >= 0) __syncthreads();  // every wave is done with the previous chunk
+        for (int e = tid; e < KC * (kDh / 4); e += blockDim.x) {
+          const int tl = e / (kDh / 4), c = e % (kDh / 4);
+          const int t = kc0 * 32 + tl;
+          float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+          if (t < T) {
+            kv = *reinterpret_cast<const float4*>(base + t * ld + (int64_t)H * kDh + c * 4);
+            vv = *reinterpret_cast<const float4*>(base + t * ld + 2ll * H * kDh + c * 4);
+          }
+          *reinterpret_cast<float4*>(sK + (size_t)tl * kKvLd + c * 4) = kv;
+          *reinterpret_cast<float4*>(sV + (size_t)tl * kKvLd + c * 4) = vv;
+        }
+        loaded = kc0;
+        __syncthreads();
       }
-      // st[r] = score of key kt*32 + (r&3) + 8 (r>>2) + 4 lh against query q
-      float mx = -__builtin_huge_valf();
+      const int kt_end = kc0 + kct < nkt ? kc0 + kct : nkt;
+      for (int kt = kc0; kt < kt_end; ++kt) {
+        const int kl = (kt - kc0) * 32;  // first row of this key tile inside the chunk
+        floatx16_t st;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const bool masked = key >= T || (causal && key > q);
-        st[r] = masked ? -__builtin_huge_valf() : st[r];
-        mx = fmaxf(mx, st[r]);
-      }
-      mx = fmaxf(mx, xhalf(mx));
-      const float mn = fmaxf(m, mx);  // key 0 is never masked for a valid query, so mn is finite from the first tile on
-      const float alpha = expf(m - mn);
-      float ps = 0.f;
+        for (int e = 0; e < 16; ++e) st[e] = 0.f;
+        const float* kp = sK + (size_t)(kl + li) * kKvLd + lh * 32;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        st[r] = expf(st[r] - mn);  // exp(-inf) = 0 for masked keys
-        ps += st[r];
-      }
-      ps += xhalf(ps);
-      l = l * alpha + ps;
-      m = mn;
+        for (int c = 0; c < 8; ++c) {
+          const float4 kv = *reinterpret_cast<const float4*>(kp + c * 4);
+          st = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.x, qf[4 * c], st, 0, 0, 0);
+          st = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.y, qf[4 * c + 1], st, 0, 0, 0);
+          st = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.z, qf[4 * c + 2], st, 0, 0, 0);
+          st = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.w, qf[4 * c + 3], st, 0, 0, 0);
+        }
+        // st[r] = score of key kt*32 + (r&3) + 8 (r>>2) + 4 lh against query q
+        float mx = -__builtin_huge_valf();
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        o0[e] *= alpha;
-        o1[e] *= alpha;
-      }
-      // O^T += V^T P^T: k-step s covers keys (s&3) + 8 (s>>2) + 4 (lane/32), whose probabilities are st[s]
-      const float* vp = sV + (size_t)(kt * 32 + 4 * lh) * kKvLd + li;
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const bool masked = key >= T || (causal && key > q);
+          st[r] = masked ? -__builtin_huge_valf() : st[r];
+          mx = fmaxf(mx, st[r]);
+        }
+        mx = fmaxf(mx, xhalf(mx));
+        const float mn = fmaxf(m, mx);  // key 0 is never masked for a valid query, so mn is finite from the first tile on
+        const float alpha = expf(m - mn);
+        float ps = 0.f;
 #pragma unroll
-      for (int s2 = 0; s2 < 16; ++s2) {
-        const float* vr = vp + (size_t)((s2 & 3) + 8 * (s2 >> 2)) * kKvLd;
-        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[0], st[s2], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[32], st[s2], o1, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) {
+          st[r] = expf(st[r] - mn);  // exp(-inf) = 0 for masked keys
+          ps += st[r];
+        }
+        ps += xhalf(ps);
+        l = l * alpha + ps;
+        m = mn;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          o0[e] *= alpha;
+          o1[e] *= alpha;
+        }
+        // O^T += V^T P^T: k-step s covers keys (s&3) + 8 (s>>2) + 4 (lane/32), whose probabilities are st[s]
+        const float* vp = sV + (size_t)(kl + 4 * lh) * kKvLd + li;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+          const float* vr = vp + (size_t)((s2 & 3) + 8 * (s2 >> 2)) * kKvLd;
+          o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[0], st[s2], o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[32], st[s2], o1, 0, 0, 0);
+        }
       }
     }
-    if (q < T) {
+    if (active && q < T) {
       const float inv = 1.f / l;
       const int64_t obase = (b * T + q) * (int64_t)H * kDh + h * kDh;
 #pragma unroll
@@ -487,7 +506,7 @@ SL_API int sl_attention(const float* d_qkv, int64_t B, int64_t T, int64_t H, int
                         uint16_t* d_out_hi, uint16_t* d_out_lo, void* stream) {
   SL_REQUIRE(B >= 0 && T >= 1 && H >= 1, "sl_attention: bad shape");
   SL_REQUIRE(head_dim == kDh, "sl_attention: head_dim=%lld (only 64 is built)", (long long)head_dim);
-  SL_REQUIRE(T <= 256, "sl_attention: sequence length %lld exceeds 256", (long long)T);
+  SL_REQUIRE(T < (1 << 24), "sl_attention: sequence length %lld too long", (long long)T);
   if (B == 0) return 0;
   SL_REQUIRE(d_qkv && (d_out || (d_out_hi && d_out_lo)), "sl_attention: null pointer");
   SL_REQUIRE(B * H < (1ll << 31), "sl_attention: too many heads");
@@ -497,7 +516,7 @@ SL_API int sl_attention(const float* d_qkv, int64_t B, int64_t T, int64_t H, int
   }();
   if (impl == 1) {
     const int64_t Tp = (T + 31) & ~(int64_t)31;
-    const size_t smem = (size_t)Tp * kKvLd * 4 * 2;
+    const size_t smem = (size_t)(Tp < kAttnChunk ? Tp : kAttnChunk) * kKvLd * 4 * 2;
     const int waves = (int)(Tp / 32 < 4 ? Tp / 32 : 4);
     if (smem > 64 * 1024)
       SL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -506,6 +525,7 @@ SL_API int sl_attention(const float* d_qkv, int64_t B, int64_t T, int64_t H, int
     SL_CHECK_HIP(hipGetLastError());
     return 0;
   }
+  SL_REQUIRE(T <= 256, "sl_attention (valu kernel): sequence length %lld exceeds 256", (long long)T);
   const size_t smem = (size_t)T * kDh * 4 * 2;
   if (smem > 64 * 1024)
     SL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

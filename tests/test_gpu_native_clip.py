@@ -110,7 +110,7 @@ def test_native_clip_drops_into_lens_pipeline():
 
 
 @pytest.mark.parametrize("T,causal", [(1, False), (31, True), (32, False), (33, True), (50, False), (64, True), (77, True),
-                                       (130, False), (197, False), (256, True)])
+                                       (130, False), (197, False), (256, True), (257, True), (300, False), (577, True), (600, False)])
 def test_attention_matches_fp32_softmax_reference(T, causal):
     """sl_attention (fp32 matrix-core kernel) against softmax(q k^T / 8) v in torch fp32, head by head; the split
     (hi, lo) output form carries the same values."""
