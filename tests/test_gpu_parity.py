@@ -545,6 +545,12 @@ outs = []
 for (q, c, d) in [(1000, 768, 1152), (130, 257, 64), (129, 128, 72), (1, 5, 4096), (300, 301, 104), (2048, 1024, 512), (513, 259, 200)]:
     x = torch.randn(q, d, device="cuda:0"); y = torch.randn(c, d, device="cuda:0")
     outs.append(N.similarity(x, y).cpu())
+# full-size probe (race screen for the LDS-DMA pipeline): three runs, order-sensitive checksums of the raw bits
+x = torch.randn(10000, 1152, device="cuda:0"); y = torch.randn(9216, 1152, device="cuda:0")
+wts = torch.arange(1, 9217, device="cuda:0", dtype=torch.int64)
+for _ in range(3):
+    o = N.similarity(x, y).view(torch.int32).to(torch.int64)
+    outs.append(torch.stack([o.sum(), (o * wts).sum(), (o.sum(1) * torch.arange(1, 10001, device="cuda:0")).sum()]).cpu())
 torch.save(outs, sys.argv[1])
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
