@@ -206,7 +206,8 @@ int sl_layernorm(const float* d_x, int64_t rows, int64_t cols, int64_t x_row_str
                  const float* d_beta, float eps, float* d_out, uint16_t* d_out_hi, uint16_t* d_out_lo,
                  int64_t out_row_stride, void* stream);
 /* softmax(q k^T / sqrt(head_dim)) v per (batch, head); d_qkv (B*T, 3*H*head_dim) rows [q | k | v]
- * (torch MultiheadAttention in_proj layout), out (B*T, H*head_dim); causal != 0 masks keys j > i. */
+ * (torch MultiheadAttention in_proj layout), out (B*T, H*head_dim); causal != 0 masks keys j > i.
+ * head_dim in {32, 64, 72, 80, 88, 96, 104, 128}; any sequence length (K/V stream through LDS in chunks). */
 int sl_attention(const float* d_qkv, int64_t B, int64_t T, int64_t H, int64_t head_dim, int causal, float* d_out,
                  uint16_t* d_out_hi, uint16_t* d_out_lo, void* stream);
 /* (B,C,Hi,Wi) image -> (B*(Hi/P)*(Wi/P), C*P*P) patch rows, k = c*P*P + py*P + px (Conv2d weight order). */

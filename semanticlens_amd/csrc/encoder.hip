@@ -252,17 +252,25 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 // Online softmax per query = per lane (its two half-waves combine max and sum with one cross-half exchange each).
 // K / V rows are padded to 68 floats: the 16-byte K fragment reads are conflict-free, V is read one float per lane.
 typedef float floatx16_t __attribute__((ext_vector_type(16)));
-constexpr int kKvLd = 68;
 
 __device__ inline float xhalf(float v) {  // value held by the lane 32 away
   return __shfl_xor(v, 32, 64);
 }
 
-constexpr int kAttnChunk = 256;  // keys resident in LDS at a time (2 x 256 x 68 floats = 136 KB)
+// head_dim D (multiple of 8, <= 128): each half-wave owns D/2 of the dims in the score product; the output has
+// NT = ceil(D / 32) tiles of 32 dims (V columns past D are zero).  K / V rows hold 32 NT + 4 floats.
+__host__ __device__ constexpr int attn_ld(int D) { return ((D + 31) / 32) * 32 + 4; }
+__host__ __device__ constexpr int attn_chunk(int D) { return D <= 64 ? 256 : (D <= 96 ? 192 : 128); }  // keys in LDS at a time
 
-__global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv, int T, int H, int causal,
+template <int D>
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv, int T, int H, int causal, float scale,
                                                               float* __restrict__ out, uint16_t* __restrict__ oh,
                                                               uint16_t* __restrict__ ol) {
+  constexpr int kDh = D;  // shadows the 64 of the VALU kernel
+  constexpr int NT = (D + 31) / 32;
+  constexpr int HD = D / 2;  // dims per half-wave in the score product (multiple of 4)
+  constexpr int kKvLd = attn_ld(D);
+  constexpr int kAttnChunk = attn_chunk(D);
   extern __shared__ __align__(16) float smem[];
   const int Tp = (T + 31) & ~31;
   const int KC = Tp < kAttnChunk ? Tp : kAttnChunk;  // keys per LDS chunk (multiple of 32)
@@ -284,18 +292,20 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
     const int qt = qt0 + w;
     const bool active = qt < nqt;
     const int q = qt * 32 + li;  // this lane's query row (both half-waves)
-    float qf[32];
+    float qf[HD];
     {
-      const float* qp = base + (int64_t)(q < T ? q : T - 1) * ld + lh * 32;
+      const float* qp = base + (int64_t)(q < T ? q : T - 1) * ld + lh * HD;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
+      for (int c = 0; c < HD / 4; ++c) {
         const float4 v = *reinterpret_cast<const float4*>(qp + c * 4);
-        qf[4 * c] = v.x * 0.125f; qf[4 * c + 1] = v.y * 0.125f; qf[4 * c + 2] = v.z * 0.125f; qf[4 * c + 3] = v.w * 0.125f;
+        qf[4 * c] = v.x * scale; qf[4 * c + 1] = v.y * scale; qf[4 * c + 2] = v.z * scale; qf[4 * c + 3] = v.w * scale;
       }
     }
-    floatx16_t o0, o1;  // O^T: dims 0..31 and 32..63 (rows) x this lane's query
+    floatx16_t o[NT];  // O^T: tile t = dims 32 t .. 32 t + 31 (rows) x this lane's query
 #pragma unroll
-    for (int e = 0; e < 16; ++e) o0[e] = o1[e] = 0.f;
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
     float m = -__builtin_huge_valf(), l = 0.f;
     const int round_last = qt0 + nwaves < nqt ? qt0 + nwaves : nqt;  // key tiles any wave of this round may need
     const int nkt_round = causal ? round_last : nqt;
@@ -303,11 +313,11 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
     for (int kc0 = 0; kc0 < nkt_round; kc0 += kct) {
       if (kc0 != loaded) {
         if (loaded >= 0) __syncthreads();  // every wave is done with the previous chunk
-        for (int e = tid; e < KC * (kDh / 4); e += blockDim.x) {
-          const int tl = e / (kDh / 4), c = e % (kDh / 4);
+        for (int e = tid; e < KC * (NT * 8); e += blockDim.x) {  // NT * 8 float4 per row, zero past D and past T
+          const int tl = e / (NT * 8), c = e % (NT * 8);
           const int t = kc0 * 32 + tl;
           float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-          if (t < T) {
+          if (t < T && c * 4 < D) {
             kv = *reinterpret_cast<const float4*>(base + t * ld + (int64_t)H * kDh + c * 4);
             vv = *reinterpret_cast<const float4*>(base + t * ld + 2ll * H * kDh + c * 4);
           }
@@ -323,9 +333,9 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
         floatx16_t st;
 #pragma unroll
         for (int e = 0; e < 16; ++e) st[e] = 0.f;
-        const float* kp = sK + (size_t)(kl + li) * kKvLd + lh * 32;
+        const float* kp = sK + (size_t)(kl + li) * kKvLd + lh * HD;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
+        for (int c = 0; c < HD / 4; ++c) {
           const float4 kv = *reinterpret_cast<const float4*>(kp + c * 4);
           st = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.x, qf[4 * c], st, 0, 0, 0);
           st = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.y, qf[4 * c + 1], st, 0, 0, 0);
@@ -354,17 +364,16 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
         l = l * alpha + ps;
         m = mn;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          o0[e] *= alpha;
-          o1[e] *= alpha;
-        }
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
         // O^T += V^T P^T: k-step s covers keys (s&3) + 8 (s>>2) + 4 (lane/32), whose probabilities are st[s]
         const float* vp = sV + (size_t)(kl + 4 * lh) * kKvLd + li;
 #pragma unroll
         for (int s2 = 0; s2 < 16; ++s2) {
           const float* vr = vp + (size_t)((s2 & 3) + 8 * (s2 >> 2)) * kKvLd;
-          o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[0], st[s2], o0, 0, 0, 0);
-          o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[32], st[s2], o1, 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[32 * t], st[s2], o[t], 0, 0, 0);
         }
       }
     }
@@ -372,21 +381,19 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
       const float inv = 1.f / l;
       const int64_t obase = (b * T + q) * (int64_t)H * kDh + h * kDh;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {  // accumulator registers 4g..4g+3 are dims 8g + 4 lh + (0..3)
-        const int d = 8 * g + 4 * lh;
-        const float4 v0 = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
-        const float4 v1 = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
-        if (out) {
-          *reinterpret_cast<float4*>(out + obase + d) = v0;
-          *reinterpret_cast<float4*>(out + obase + 32 + d) = v1;
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // accumulator registers 4g..4g+3 of tile t are dims 32 t + 8 g + 4 lh + (0..3)
+          const int d = 32 * t + 8 * g + 4 * lh;
+          if (d < D) {
+            const float4 v = make_float4(o[t][4 * g] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
+            if (out) *reinterpret_cast<float4*>(out + obase + d) = v;
+            if (oh) {
+              store_split(v.x, obase + d, oh, ol); store_split(v.y, obase + d + 1, oh, ol);
+              store_split(v.z, obase + d + 2, oh, ol); store_split(v.w, obase + d + 3, oh, ol);
+            }
+          }
         }
-        if (oh) {
-          store_split(v0.x, obase + d, oh, ol); store_split(v0.y, obase + d + 1, oh, ol);
-          store_split(v0.z, obase + d + 2, oh, ol); store_split(v0.w, obase + d + 3, oh, ol);
-          store_split(v1.x, obase + 32 + d, oh, ol); store_split(v1.y, obase + 33 + d, oh, ol);
-          store_split(v1.z, obase + 34 + d, oh, ol); store_split(v1.w, obase + 35 + d, oh, ol);
-        }
-      }
     }
   }
 }
@@ -502,35 +509,55 @@ SL_API int sl_layernorm(const float* d_x, int64_t rows, int64_t cols, int64_t x_
   return 0;
 }
 
+template <int D>
+static int launch_attention_mfma(const float* qkv, int64_t B, int64_t T, int64_t H, int causal, float* out, uint16_t* oh,
+                                 uint16_t* ol, hipStream_t st) {
+  const int64_t Tp = (T + 31) & ~(int64_t)31;
+  const int64_t kc = Tp < attn_chunk(D) ? Tp : attn_chunk(D);
+  const size_t smem = (size_t)kc * attn_ld(D) * 4 * 2;
+  const int waves = (int)(Tp / 32 < 4 ? Tp / 32 : 4);
+  if (smem > 64 * 1024)
+    SL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_mfma_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  const float scale = (float)(1.0 / sqrt((double)D));  // torch: q * head_dim ** -0.5
+  hipLaunchKernelGGL(attention_mfma_kernel<D>, dim3((unsigned)(B * H)), dim3(64 * waves), smem, st, qkv, (int)T, (int)H, causal,
+                     scale, out, oh, ol);
+  SL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 SL_API int sl_attention(const float* d_qkv, int64_t B, int64_t T, int64_t H, int64_t head_dim, int causal, float* d_out,
                         uint16_t* d_out_hi, uint16_t* d_out_lo, void* stream) {
   SL_REQUIRE(B >= 0 && T >= 1 && H >= 1, "sl_attention: bad shape");
-  SL_REQUIRE(head_dim == kDh, "sl_attention: head_dim=%lld (only 64 is built)", (long long)head_dim);
   SL_REQUIRE(T < (1 << 24), "sl_attention: sequence length %lld too long", (long long)T);
   if (B == 0) return 0;
   SL_REQUIRE(d_qkv && (d_out || (d_out_hi && d_out_lo)), "sl_attention: null pointer");
   SL_REQUIRE(B * H < (1ll << 31), "sl_attention: too many heads");
   static const int impl = [] {
-    const char* e = getenv("SL_ATTENTION_IMPL");  // "valu": the 4-lanes-per-row kernel; default: fp32-MFMA kernel
+    const char* e = getenv("SL_ATTENTION_IMPL");  // "valu": the 4-lanes-per-row kernel (head_dim 64, T <= 256)
     return (e && strcmp(e, "valu") == 0) ? 0 : 1;
   }();
+  hipStream_t st = (hipStream_t)stream;
   if (impl == 1) {
-    const int64_t Tp = (T + 31) & ~(int64_t)31;
-    const size_t smem = (size_t)(Tp < kAttnChunk ? Tp : kAttnChunk) * kKvLd * 4 * 2;
-    const int waves = (int)(Tp / 32 < 4 ? Tp / 32 : 4);
-    if (smem > 64 * 1024)
-      SL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(attention_mfma_kernel, dim3((unsigned)(B * H)), dim3(64 * waves), smem, (hipStream_t)stream, d_qkv, (int)T,
-                       (int)H, causal, d_out, d_out_hi, d_out_lo);
-    SL_CHECK_HIP(hipGetLastError());
-    return 0;
+    switch (head_dim) {
+      case 32: return launch_attention_mfma<32>(d_qkv, B, T, H, causal, d_out, d_out_hi, d_out_lo, st);
+      case 64: return launch_attention_mfma<64>(d_qkv, B, T, H, causal, d_out, d_out_hi, d_out_lo, st);
+      case 72: return launch_attention_mfma<72>(d_qkv, B, T, H, causal, d_out, d_out_hi, d_out_lo, st);
+      case 80: return launch_attention_mfma<80>(d_qkv, B, T, H, causal, d_out, d_out_hi, d_out_lo, st);
+      case 88: return launch_attention_mfma<88>(d_qkv, B, T, H, causal, d_out, d_out_hi, d_out_lo, st);
+      case 96: return launch_attention_mfma<96>(d_qkv, B, T, H, causal, d_out, d_out_hi, d_out_lo, st);
+      case 104: return launch_attention_mfma<104>(d_qkv, B, T, H, causal, d_out, d_out_hi, d_out_lo, st);
+      case 128: return launch_attention_mfma<128>(d_qkv, B, T, H, causal, d_out, d_out_hi, d_out_lo, st);
+      default: break;
+    }
+    SL_REQUIRE(false, "sl_attention: head_dim=%lld (built: 32, 64, 72, 80, 88, 96, 104, 128)", (long long)head_dim);
   }
+  SL_REQUIRE(head_dim == kDh, "sl_attention (valu kernel): head_dim=%lld (only 64 is built)", (long long)head_dim);
   SL_REQUIRE(T <= 256, "sl_attention (valu kernel): sequence length %lld exceeds 256", (long long)T);
   const size_t smem = (size_t)T * kDh * 4 * 2;
   if (smem > 64 * 1024)
     SL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL(attention_kernel, dim3((unsigned)(B * H)), dim3(256), smem, (hipStream_t)stream, d_qkv, (int)T, (int)H,
-                     causal, d_out, d_out_hi, d_out_lo);
+  hipLaunchKernelGGL(attention_kernel, dim3((unsigned)(B * H)), dim3(256), smem, st, d_qkv, (int)T, (int)H, causal, d_out,
+                     d_out_hi, d_out_lo);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -14,7 +14,7 @@ way features agree with the torch modules to ~1e-5 relative, and the object plug
 Supported layout (probed by attribute, the names open_clip's ``VisionTransformer`` / ``TextTransformer`` and
 ``synth.SyntheticClip`` use): ``conv1`` (patch embedding, no bias), ``class_embedding``, positional embedding,
 ``ln_pre``, blocks with ``ln_1`` / ``attn`` (``torch.nn.MultiheadAttention``) / ``ln_2`` / ``mlp`` (Linear, GELU or
-QuickGELU, Linear), ``ln_post`` / ``ln_final``, projection matrices; head_dim 64.
+QuickGELU, Linear), ``ln_post`` / ``ln_final``, projection matrices; head_dim 32 / 64 / 72 / 80 / 88 / 96 / 104 / 128.
 """
 from __future__ import annotations
 
@@ -52,8 +52,9 @@ class _Block:
             raise TypeError("NativeClip expects torch.nn.MultiheadAttention blocks with a packed in_proj_weight")
         self.heads = attn.num_heads
         self.width = attn.embed_dim
-        if self.width // self.heads != 64:
-            raise ValueError(f"head_dim {self.width // self.heads} is not supported (64 only)")
+        self.head_dim = self.width // self.heads
+        if self.head_dim not in (32, 64, 72, 80, 88, 96, 104, 128) or self.head_dim * self.heads != self.width:
+            raise ValueError(f"head_dim {self.head_dim} is not supported (32, 64, 72, 80, 88, 96, 104, 128)")
         self.ln1 = (_f32(blk.ln_1.weight, device), _f32(blk.ln_1.bias, device), blk.ln_1.eps)
         self.ln2 = (_f32(blk.ln_2.weight, device), _f32(blk.ln_2.bias, device), blk.ln_2.eps)
         self.w_qkv, self.b_qkv = _f32(attn.in_proj_weight, device), _f32(attn.in_proj_bias, device)
@@ -89,7 +90,7 @@ class _Tower:
             for blk in self.blocks:
                 N.layernorm(x, *blk.ln1, out_split=h)
                 N.linear3(h, blk.s_qkv, blk.b_qkv, out=qkv)
-                N.attention(qkv, B, T, blk.heads, 64, causal, out_split=att)
+                N.attention(qkv, B, T, blk.heads, blk.head_dim, causal, out_split=att)
                 N.linear3(att, blk.s_o, blk.b_o, residual=x, out=x)  # x += out_proj(attn)
                 N.layernorm(x, *blk.ln2, out_split=h)
                 N.linear3(h, blk.s_fc, blk.b_fc, act=blk.act, out_split=hid)  # GELU output leaves as split bf16
@@ -101,7 +102,7 @@ class _Tower:
         for blk in self.blocks:
             N.layernorm(x, *blk.ln1, out=h)
             N.linear(h, blk.w_qkv, blk.b_qkv, out=qkv)
-            N.attention(qkv, B, T, blk.heads, 64, causal, out=att)
+            N.attention(qkv, B, T, blk.heads, blk.head_dim, causal, out=att)
             N.linear(att, blk.w_o, blk.b_o, residual=x, out=x)
             N.layernorm(x, *blk.ln2, out=h)
             N.linear(h, blk.w_fc, blk.b_fc, act=blk.act, out=hid)

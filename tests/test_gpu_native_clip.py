@@ -65,6 +65,7 @@ def test_primitives_against_torch():
 
 @pytest.mark.parametrize("arch", [
     dict(embed_dim=64, image_size=64, patch=16, v_width=128, v_layers=2, v_heads=2, ctx=16, vocab=49408, t_width=128, t_layers=2, t_heads=2),
+    dict(embed_dim=48, image_size=64, patch=16, v_width=160, v_layers=2, v_heads=2, ctx=16, vocab=49408, t_width=64, t_layers=1, t_heads=2),  # head_dim 80 / 32
     dict(),  # CLIP ViT-B/32: 12 x 768 image tower (50 tokens), 12 x 512 text tower (77 tokens), 512-d joint space
 ])
 @pytest.mark.parametrize("gemm", ["bf16x3", "f32"])
@@ -109,24 +110,29 @@ def test_native_clip_drops_into_lens_pipeline():
     np.testing.assert_allclose(probe_n["1"].cpu().numpy(), probe_t["1"].cpu().numpy(), rtol=0, atol=1e-4)
 
 
-@pytest.mark.parametrize("T,causal", [(1, False), (31, True), (32, False), (33, True), (50, False), (64, True), (77, True),
-                                       (130, False), (197, False), (256, True), (257, True), (300, False), (577, True), (600, False)])
-def test_attention_matches_fp32_softmax_reference(T, causal):
-    """sl_attention (fp32 matrix-core kernel) against softmax(q k^T / 8) v in torch fp32, head by head; the split
-    (hi, lo) output form carries the same values."""
-    g = torch.Generator(device=DEV).manual_seed(T)
+@pytest.mark.parametrize("T,causal,D", [(1, False, 64), (31, True, 64), (32, False, 64), (33, True, 64), (50, False, 64), (64, True, 64),
+                                         (77, True, 64), (130, False, 64), (197, False, 64), (256, True, 64), (257, True, 64), (300, False, 64),
+                                         (577, True, 64), (600, False, 64), (50, False, 32), (77, True, 72), (257, False, 80), (40, True, 88),
+                                         (200, True, 96), (65, False, 104), (300, True, 128)])
+def test_attention_matches_fp32_softmax_reference(T, causal, D):
+    """sl_attention (fp32 matrix-core kernel) against softmax(q k^T / sqrt(D)) v in torch fp32, head by head, for every
+    built head_dim and sequence lengths on both sides of the 32-row tiles and of the LDS chunk; the split (hi, lo)
+    output form carries the same values."""
+    g = torch.Generator(device=DEV).manual_seed(T + D)
     B, H = 2, 3
-    qkv = torch.randn(B * T, 3 * H * 64, device=DEV, generator=g)
-    q, k, v = (qkv.reshape(B, T, 3, H, 64)[:, :, i].permute(0, 2, 1, 3) for i in range(3))  # (B, H, T, 64)
-    s = (q @ k.transpose(-1, -2)) * 0.125
+    qkv = torch.randn(B * T, 3 * H * D, device=DEV, generator=g)
+    q, k, v = (qkv.reshape(B, T, 3, H, D)[:, :, i].permute(0, 2, 1, 3) for i in range(3))  # (B, H, T, D)
+    s = (q @ k.transpose(-1, -2)) * (D ** -0.5)
     if causal:
         s = s + torch.full((T, T), float("-inf"), device=DEV).triu_(1)
-    want = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * T, H * 64)
-    got = N.attention(qkv, B, T, H, 64, causal)
-    assert (got - want).abs().max().item() < 2e-6 * max(1.0, want.abs().max().item()), (T, causal)
-    sp = N.Split(B * T, H * 64, DEV)
-    N.attention(qkv, B, T, H, 64, causal, out_split=sp)
+    want = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * T, H * D)
+    got = N.attention(qkv, B, T, H, D, causal)
+    assert (got - want).abs().max().item() < 2e-6 * max(1.0, want.abs().max().item()), (T, causal, D)
+    sp = N.Split(B * T, H * D, DEV)
+    N.attention(qkv, B, T, H, D, causal, out_split=sp)
     assert (sp.hi.float() + sp.lo.float() - got).abs().max().item() <= 2.0 ** -16 * got.abs().max().item() + 1e-9
+    with pytest.raises(ValueError):
+        N.attention(qkv, B, T, H, 48, causal)
 
 
 @pytest.mark.parametrize("cols", [4, 130, 200, 768, 1024, 1028, 2048])
