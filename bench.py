@@ -191,6 +191,25 @@ def cpu_baseline(args, model_cpu, fm_cpu):
 
 
 @torch.no_grad()
+def probing_end_to_end(fm, dev):
+    """Lens.text_probing on 10,000 synthetic prompts: tokenise + text tower + template-free probe against 12 x 768
+    concept embeddings in the tower's own joint space (D=512 for ViT-B/32)."""
+    words = ["zebra", "stripe", "wheel", "sky", "grass", "dog", "cat", "red", "round", "metal", "wood", "water", "face", "text"]
+    prompts = [f"a photo of a {words[i % 14]} {words[(i // 14) % 14]} {i}" for i in range(10000)]
+    g = torch.Generator(device=dev).manual_seed(3)
+    db = {f"block{i}": torch.randn(768, 512, device=dev, generator=g) for i in range(12)}
+    lens = Lens(fm, device=dev)
+    lens.text_probing(prompts[:1024], db, batch_size=1024)  # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = lens.text_probing(prompts, db, batch_size=1024)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    assert all(v.shape == (10000, 768) for v in out.values())
+    return {"queries_per_s": 10000 / wall, "wall_ms": wall * 1e3,
+            "workload": "10,000 prompts -> tokenizer -> text tower (12 x 512, ctx 77, batches of 1024) -> probe vs 12 x 768 x 512"}
+
+
 def probing_leg(dev):
     """text_probing at BASELINE configs[3] shapes: Q=10,000 query embeddings (D=1152, SigLIP-so400m width) against
     12 layers x 768 components, through `_probe` (lens.py:206-214).  The cosine GEMM (K6) is timed per dispatch
@@ -363,6 +382,7 @@ def main():
     }
     if world == 1 and not args.no_probing:
         line["text_probing"] = probing_leg(dev)
+        line["text_probing"]["from_prompts"] = probing_end_to_end(fm, dev)
     if world == 1 and not args.no_cpu_baseline:
         torch.manual_seed(0)
         line["cpu_baseline"] = cpu_baseline(args, synth.resnet50(), synth.SyntheticClip(device="cpu"))

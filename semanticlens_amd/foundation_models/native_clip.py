@@ -163,15 +163,23 @@ class NativeTextTower:
         proj = _first(model, "text_projection", "proj_t")
         self.w_proj = _f32(proj.t(), device)
         self.tower = _Tower(blocks, device, split)
+        self.truncate = True  # skip the positions after the batch's last end-of-text token (see __call__)
 
     @torch.no_grad()
     def __call__(self, tokens: torch.Tensor) -> torch.Tensor:
         tokens = N.to_device(tokens).to(torch.int64).contiguous()
         B, T = tokens.shape
+        eot = tokens.argmax(dim=-1)  # end-of-text token (highest id): the position CLIP's text tower pools
+        if self.truncate and B > 0:
+            # the tower is causal: position t only sees positions <= t, so nothing after the last end-of-text token of
+            # the batch can reach a pooled feature.  Dropping those (padding) positions leaves every pooled value
+            # bit-identical and shrinks the work from context_length to the longest prompt (one scalar readback).
+            t_eff = int(eot.max().item()) + 1
+            if t_eff < T:
+                tokens, T = tokens[:, :t_eff].contiguous(), t_eff
         x = N.embed_tokens(self.table, tokens, self.pos[:T].contiguous())
         x = self.tower.forward(x, B, T, causal=True)
-        # features of the end-of-text token (highest id), as CLIP's text tower pools them
-        rows = torch.arange(B, device=tokens.device) * T + tokens.argmax(dim=-1)
+        rows = torch.arange(B, device=tokens.device) * T + eot
         picked = N.gather_rows(x, rows)
         pooled = N.layernorm(picked, *self.ln_final)
         return N.linear(pooled, self.w_proj)

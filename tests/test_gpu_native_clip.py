@@ -83,6 +83,12 @@ def test_native_towers_match_torch_modules(arch, gemm):
     want_t = fm.encode_text(toks)
     got_t = nat.encode_text(toks)
     assert rel_err(got_t, want_t) < 1e-4, rel_err(got_t, want_t)
+    # dropping the padding after the batch's last end-of-text token (causal tower) changes no pooled bit
+    short = fm.tokenize(["a photo of a cat", "dog", "two red wheels"])
+    nat.text.truncate = False
+    full = nat.encode_text(short)
+    nat.text.truncate = True
+    assert torch.equal(nat.encode_text(short), full)
     # cosine between the two implementations' features ~ 1
     cos = torch.nn.functional.cosine_similarity(got, want, dim=-1)
     assert (1 - cos).abs().max().item() < 1e-6
