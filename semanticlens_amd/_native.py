@@ -225,8 +225,10 @@ def actmax_merge_states(vals, ids, other_vals: torch.Tensor, other_ids: torch.Te
 # ------------------------------------------------------------------------------------------------
 # K5
 # ------------------------------------------------------------------------------------------------
-def gather_rows(emb: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
-    """``emb[ids]`` for emb (N,D) f32 on the device; negative ids wrap; out-of-range raises IndexError."""
+def gather_rows(emb: torch.Tensor, ids: torch.Tensor, check: bool = True) -> torch.Tensor:
+    """``emb[ids]`` for emb (N,D) f32 on the device; negative ids wrap; out-of-range raises IndexError
+    (``check=False`` skips that readback — and its host synchronisation — for indices known to be in range;
+    out-of-range rows are then left unwritten)."""
     assert emb.is_cuda and emb.dtype == torch.float32 and emb.ndim == 2
     emb = emb.contiguous()
     ids_d = to_device(ids, emb.device).to(torch.int64).contiguous()
@@ -236,7 +238,7 @@ def gather_rows(emb: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     with torch.cuda.device(emb.device):
         rc = lib().sl_gather_rows(_ptr(emb), N, D, _ptr(ids_d), ids_d.numel(), _ptr(out), _ptr(flag), _stream(emb))
     _check(rc, "sl_gather_rows")
-    if int(flag.item()) != 0:
+    if check and int(flag.item()) != 0:
         raise IndexError(f"index out of range in embeds[sample_ids] (dataset size {N})")
     return out
 

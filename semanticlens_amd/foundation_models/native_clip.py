@@ -81,33 +81,52 @@ class _Tower:
         self.width = self.blocks[0].width
         self.heads = self.blocks[0].heads
 
-    def forward(self, x: torch.Tensor, B: int, T: int, causal: bool) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, B: int, T: int, causal: bool, pool_rows: torch.Tensor | None = None) -> torch.Tensor:
+        """Runs the blocks over ``x`` in place.  ``pool_rows`` (B int64 row indices): only those rows of the final
+        residual stream are needed (class token / end-of-text token), so the last block stops being computed for
+        the other rows after its attention (keys and values still come from every token) and ``(B, W)`` is returned.
+        Each GEMM row depends on its own input row only, so the pooled rows are bit-identical either way."""
         M, W = x.shape
         F = self.blocks[0].w_fc.shape[0]
         qkv = torch.empty((M, 3 * W), dtype=torch.float32, device=x.device)
+        last = len(self.blocks) - 1
         if self.split:
             h, att, hid = N.Split(M, W, x.device), N.Split(M, W, x.device), N.Split(M, F, x.device)
-            for blk in self.blocks:
+            for i, blk in enumerate(self.blocks):
                 N.layernorm(x, *blk.ln1, out_split=h)
                 N.linear3(h, blk.s_qkv, blk.b_qkv, out=qkv)
+                if i == last and pool_rows is not None:
+                    att32 = N.attention(qkv, B, T, blk.heads, blk.head_dim, causal)
+                    xp = N.gather_rows(x, pool_rows, check=False)
+                    N.linear3(N.Split.of(N.gather_rows(att32, pool_rows, check=False)), blk.s_o, blk.b_o, residual=xp, out=xp)
+                    hp = N.layernorm(xp, *blk.ln2, out_split=N.Split(B, W, x.device))
+                    hidp = N.linear3(hp, blk.s_fc, blk.b_fc, act=blk.act, out_split=N.Split(B, F, x.device))
+                    N.linear3(hidp, blk.s_pr, blk.b_pr, residual=xp, out=xp)
+                    return xp
                 N.attention(qkv, B, T, blk.heads, blk.head_dim, causal, out_split=att)
                 N.linear3(att, blk.s_o, blk.b_o, residual=x, out=x)  # x += out_proj(attn)
                 N.layernorm(x, *blk.ln2, out_split=h)
                 N.linear3(h, blk.s_fc, blk.b_fc, act=blk.act, out_split=hid)  # GELU output leaves as split bf16
                 N.linear3(hid, blk.s_pr, blk.b_pr, residual=x, out=x)  # x += c_proj(gelu(c_fc))
-            return x
+            return x if pool_rows is None else N.gather_rows(x, pool_rows, check=False)
         h = torch.empty_like(x)
         att = torch.empty_like(x)
         hid = torch.empty((M, F), dtype=torch.float32, device=x.device)
-        for blk in self.blocks:
+        for i, blk in enumerate(self.blocks):
             N.layernorm(x, *blk.ln1, out=h)
             N.linear(h, blk.w_qkv, blk.b_qkv, out=qkv)
             N.attention(qkv, B, T, blk.heads, blk.head_dim, causal, out=att)
+            if i == last and pool_rows is not None:
+                xp = N.gather_rows(x, pool_rows, check=False)
+                N.linear(N.gather_rows(att, pool_rows, check=False), blk.w_o, blk.b_o, residual=xp, out=xp)
+                hp = N.layernorm(xp, *blk.ln2)
+                N.linear(N.linear(hp, blk.w_fc, blk.b_fc, act=blk.act), blk.w_pr, blk.b_pr, residual=xp, out=xp)
+                return xp
             N.linear(att, blk.w_o, blk.b_o, residual=x, out=x)
             N.layernorm(x, *blk.ln2, out=h)
             N.linear(h, blk.w_fc, blk.b_fc, act=blk.act, out=hid)
             N.linear(hid, blk.w_pr, blk.b_pr, residual=x, out=x)
-        return x
+        return x if pool_rows is None else N.gather_rows(x, pool_rows, check=False)
 
 
 class NativeVisionTower:
@@ -129,6 +148,7 @@ class NativeVisionTower:
         if split:
             self.s_patch = N.Split.of(self.w_patch)
         self.tower = _Tower(blocks, device, split)
+        self.pool_shortcut = True  # last block: out-proj / MLP for the class-token rows only (see _Tower.forward)
 
     @torch.no_grad()
     def __call__(self, img: torch.Tensor) -> torch.Tensor:
@@ -149,8 +169,12 @@ class NativeVisionTower:
             N.linear(patches, self.w_patch, out=x, scatter=(n_patch, T, 1), rowadd=self.pos)
         N.broadcast_row(self.cls, self.pos[0], B, T * W, x)  # token 0 = class embedding + pos[0]
         h = N.layernorm(x, *self.ln_pre)
-        h = self.tower.forward(h, B, T, causal=False)
-        pooled = N.layernorm(h, *self.ln_post, rows=B, x_row_stride=T * W)  # class-token rows only
+        if self.pool_shortcut:
+            cls_rows = torch.arange(B, device=img.device, dtype=torch.int64) * T
+            pooled = N.layernorm(self.tower.forward(h, B, T, causal=False, pool_rows=cls_rows), *self.ln_post)
+        else:
+            h = self.tower.forward(h, B, T, causal=False)
+            pooled = N.layernorm(h, *self.ln_post, rows=B, x_row_stride=T * W)  # class-token rows only
         return N.linear(pooled, self.w_proj)
 
 
@@ -164,6 +188,7 @@ class NativeTextTower:
         self.w_proj = _f32(proj.t(), device)
         self.tower = _Tower(blocks, device, split)
         self.truncate = True  # skip the positions after the batch's last end-of-text token (see __call__)
+        self.pool_shortcut = True  # last block: out-proj / MLP for the end-of-text rows only
 
     @torch.no_grad()
     def __call__(self, tokens: torch.Tensor) -> torch.Tensor:
@@ -178,9 +203,11 @@ class NativeTextTower:
             if t_eff < T:
                 tokens, T = tokens[:, :t_eff].contiguous(), t_eff
         x = N.embed_tokens(self.table, tokens, self.pos[:T].contiguous())
-        x = self.tower.forward(x, B, T, causal=True)
         rows = torch.arange(B, device=tokens.device) * T + eot
-        picked = N.gather_rows(x, rows)
+        if self.pool_shortcut:
+            picked = self.tower.forward(x, B, T, causal=True, pool_rows=rows)
+        else:
+            picked = N.gather_rows(self.tower.forward(x, B, T, causal=True), rows, check=False)
         pooled = N.layernorm(picked, *self.ln_final)
         return N.linear(pooled, self.w_proj)
 

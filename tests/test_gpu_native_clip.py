@@ -89,6 +89,11 @@ def test_native_towers_match_torch_modules(arch, gemm):
     full = nat.encode_text(short)
     nat.text.truncate = True
     assert torch.equal(nat.encode_text(short), full)
+    # last block computed for the pooled rows only: same bits as running it over every token
+    nat.text.pool_shortcut = nat.vision.pool_shortcut = False
+    full_t, full_v = nat.encode_text(toks), nat.encode_image(x)
+    nat.text.pool_shortcut = nat.vision.pool_shortcut = True
+    assert torch.equal(nat.encode_text(toks), full_t) and torch.equal(nat.encode_image(x), full_v)
     # cosine between the two implementations' features ~ 1
     cos = torch.nn.functional.cosine_similarity(got, want, dim=-1)
     assert (1 - cos).abs().max().item() < 1e-6
