@@ -106,3 +106,24 @@ def test_zero_samples_and_empty_layers(tmp_path):
     cv0.run(batch_size=2)
     am = cv0.actmax_cache.cache["0"]
     assert am.n_collect == 0 and am.sample_ids.shape[1] == 0 and am.activations.shape[1] == 0
+
+
+def test_referenced_only_embedding_gives_the_same_concept_db():
+    """Embedding only the samples some component refers to == embedding the whole dataset, including
+    the -1 sentinel (gathers the LAST sample) and repeated / unsorted ids; the encoder sees fewer samples."""
+    model = make_int_conv_model().to(DEV)
+    for n, k in ((40, 3), (5, 9)):  # plenty of unreferenced samples; fewer samples than k (-1 slots)
+        ds = TensorPairDataset(make_int_images(n))
+        def build():
+            return ActivationComponentVisualizer(model, ds, ds, ["0", "2"], num_samples=k, aggregate_fn=aggregators.aggregate_conv_max, tie_mode="aten")
+        fm_all, fm_ref = FakeVLM().to(DEV), FakeVLM().to(DEV)
+        want = build()._compute_concept_db(fm_all, batch_size=4)
+        cv = build()
+        got = cv._compute_concept_db(fm_ref, batch_size=4, referenced_only=True)
+        for name in ("0", "2"):
+            assert torch.equal(got[name], want[name]), (n, k, name)
+        refs = torch.cat([cv.get_max_reference(l).reshape(-1) for l in ("0", "2")])
+        n_ref = len(set((refs % n).tolist()))
+        assert fm_ref.calls["encode_image"] == -(-n_ref // 4) and fm_all.calls["encode_image"] == -(-n // 4)
+        if n == 40:
+            assert n_ref < n
