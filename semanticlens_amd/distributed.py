@@ -127,31 +127,47 @@ def gather_concept_db_sharded(embeds_local: torch.Tensor, shard_start: int, n_to
 
 
 @torch.no_grad()
-def compute_concept_db_sharded(cv, fm, batch_size: int = 64, num_workers: int = 0, group=None):
-    """Multi-GPU ``cv._compute_concept_db(fm)``: every rank returns the same ``{layer: (C, k, D)}`` (device tensors)."""
+def compute_concept_db_sharded(cv, fm, batch_size: int = 64, num_workers: int = 0, group=None, referenced_only: bool = False):
+    """Multi-GPU ``cv._compute_concept_db(fm)``: every rank returns the same ``{layer: (C, k, D)}`` (device tensors).
+
+    ``referenced_only``: after the merge every rank knows the global top-k ids; each rank then embeds only the
+    referenced samples of its own shard instead of its whole shard."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     n_total = len(cv.dataset)
     start, stop = shard_range(n_total, rank, world)
     run_sharded(cv, batch_size=batch_size, num_workers=num_workers, group=group)
     fm.to(cv.device)
+    refs = {name: cv.get_max_reference(name).to(torch.int64) for name in cv.layer_names}
+    if referenced_only and refs:
+        flat = torch.cat([r.reshape(-1) for r in refs.values()])
+        flat = torch.where(flat < 0, flat + n_total, flat)  # the -1 sentinel gathers the LAST sample
+        uniq = torch.unique(flat)  # sorted global ids, identical on every rank
+        lo = int(torch.searchsorted(uniq, torch.tensor(start)))
+        hi = int(torch.searchsorted(uniq, torch.tensor(stop)))
+        subset, n_rows, row0 = uniq[lo:hi].tolist(), uniq.numel(), lo
+        refs = {name: torch.searchsorted(uniq, torch.where(r < 0, r + n_total, r)) for name, r in refs.items()}
+    else:
+        subset, n_rows, row0 = range(start, stop), n_total, start
     loader = torch.utils.data.DataLoader(
-        torch.utils.data.Subset(cv.dataset_fm, range(start, stop)), batch_size=batch_size, shuffle=False,
+        torch.utils.data.Subset(cv.dataset_fm, subset), batch_size=batch_size, shuffle=False,
         collate_fn=lambda b: [i[0] if isinstance(i, (tuple, list)) else i for i in b], num_workers=num_workers,
     )
     embeds, filled = None, 0
     for items in loader:
-        embeds, filled = cv.embed_batch(fm, items, embeds, filled, stop - start)
+        embeds, filled = cv.embed_batch(fm, items, embeds, filled, len(subset))
     if embeds is None:  # empty shard: still take part in the collectives
         dim = torch.zeros(1, dtype=torch.int64, device=cv.device)
     else:
         dim = torch.tensor([embeds.shape[1]], dtype=torch.int64, device=embeds.device)
-    dist.all_reduce(dim, op=dist.ReduceOp.MAX, group=group)
+    if _host_staged(group) and dim.is_cuda:
+        host = dim.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
+        dim = host
+    else:
+        dist.all_reduce(dim, op=dist.ReduceOp.MAX, group=group)
     if embeds is None:
         embeds = torch.empty((0, int(dim.item())), dtype=torch.float32, device=cv.device)
-    return {
-        name: gather_concept_db_sharded(embeds, start, n_total, cv.get_max_reference(name), group)
-        for name in cv.layer_names
-    }
+    return {name: gather_concept_db_sharded(embeds, row0, n_rows, ids, group) for name, ids in refs.items()}
 
 
 # ------------------------------------------------------------------------------------------------

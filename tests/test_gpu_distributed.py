@@ -41,8 +41,12 @@ def _worker(rank, world, port, out_dir):
     try:
         cv, fm = _build()
         db = sld.compute_concept_db_sharded(cv, fm, batch_size=8)
+        cv2, fm2 = _build()
+        db_ref = sld.compute_concept_db_sharded(cv2, fm2, batch_size=8, referenced_only=True)
+        assert fm2.calls["encode_image"] <= fm.calls["encode_image"]
         np.savez(os.path.join(out_dir, f"w{world}_r{rank}.npz"),
                  **{f"db_{k}": v.cpu().numpy() for k, v in db.items()},
+                 **{f"dbref_{k}": v.cpu().numpy() for k, v in db_ref.items()},
                  **{f"ids_{k}": cv.get_max_reference(k).numpy() for k in db},
                  **{f"vals_{k}": cv.actmax_cache.cache[k].activations.view(torch.int16).numpy() for k in db})
     finally:
@@ -60,6 +64,7 @@ def test_sharded_build_equals_single_process(world, tmp_path):
             assert np.array_equal(got[f"ids_{k}"], cv.get_max_reference(k).numpy()), (world, r, k)
             assert np.array_equal(got[f"vals_{k}"], cv.actmax_cache.cache[k].activations.view(torch.int16).numpy())
             assert np.array_equal(got[f"db_{k}"], want[k].numpy()), (world, r, k)
+            assert np.array_equal(got[f"dbref_{k}"], want[k].numpy()), (world, r, k, "referenced_only")
 
 
 def test_sharded_requires_total_order():
