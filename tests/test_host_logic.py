@@ -543,3 +543,15 @@ def test_device_preprocess_from_transform_reads_open_clip_pipeline():
         DevicePreprocess.from_transform(T("Compose", transforms=[T("ToTensor")]))
     with pytest.raises(ValueError):
         DevicePreprocess.from_transform(T("Compose", transforms=[T("Resize", size=224, interpolation=Interp()), T("CenterCrop", size=200)]))
+
+
+def test_denormalization_transform_inverts_normalisation():
+    from semanticlens_amd.utils import get_denormalization_transform
+
+    mean, std = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
+    img = torch.rand(3, 8, 9)
+    norm = (img - mean[:, None, None]) / std[:, None, None]
+    den = get_denormalization_transform()
+    assert torch.allclose(den(norm), img, atol=1e-6)
+    assert torch.allclose(den(norm[None].repeat(2, 1, 1, 1)), img[None].repeat(2, 1, 1, 1), atol=1e-6)
+    assert torch.allclose(get_denormalization_transform([0.5] * 3, [0.25] * 3)(torch.zeros(3, 2, 2)), torch.full((3, 2, 2), 0.5))
