@@ -23,6 +23,15 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BM = 128, BN = 128, BK = 32;
+// tools/native/clock_probe.hip -DSL_G3_LAYOUT_EXPERIMENT: timing-only emulation of an operand layout in which the hi and
+// lo halves of a 32-wide k-tile share one 128-byte line (row stride 2 K, k-tile stride 64 elements, lo = hi + 32)
+#ifdef SL_G3_LAYOUT_EXPERIMENT
+#define SL_G3_LD(K) (2 * (K))
+constexpr int KSTEP = 64;
+#else
+#define SL_G3_LD(K) (K)
+constexpr int KSTEP = BK;
+#endif
 constexpr int ROW_BYTES = 80;                 // 64 data + 16 pad
 constexpr int IMG_BYTES = BM * ROW_BYTES;     // one 128-row image
 
@@ -79,10 +88,10 @@ __global__ __launch_bounds__(256, SL_G3_WAVES) void gemm3_nt_kernel(const uint16
     const int row = piece >> 2, qt = piece & 3;
     const int64_t ar = m0 + row < M ? m0 + row : M - 1;
     const int64_t br = n0 + row < N ? n0 + row : N - 1;
-    src[0][p] = Ah + ar * K + qt * 8;
-    src[1][p] = Al + ar * K + qt * 8;
-    src[2][p] = Bh + br * K + qt * 8;
-    src[3][p] = Bl + br * K + qt * 8;
+    src[0][p] = Ah + ar * SL_G3_LD(K) + qt * 8;
+    src[1][p] = Al + ar * SL_G3_LD(K) + qt * 8;
+    src[2][p] = Bh + br * SL_G3_LD(K) + qt * 8;
+    src[3][p] = Bl + br * SL_G3_LD(K) + qt * 8;
     lds_off[p] = row * ROW_BYTES + qt * 16;
   }
   uint4 stg[4][2];
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(256, SL_G3_WAVES) void gemm3_nt_kernel(const uint16
     __syncthreads();
     int kt = 0;
     for (; kt + 1 < nfull; ++kt) {
-      load_tile_full((int64_t)(kt + 1) * BK);  // flies during the MFMAs
+      load_tile_full((int64_t)(kt + 1) * KSTEP);  // flies during the MFMAs
       __builtin_amdgcn_sched_barrier(0);
       compute();
       __builtin_amdgcn_sched_barrier(0);
@@ -197,8 +206,14 @@ __global__ __launch_bounds__(256, SL_G3_WAVES) void gemm3_nt_kernel(const uint16
 // passes; a 128 x 128 DMA variant with double buffering and one barrier per k-step was no faster than the
 // register-staged kernel (246 vs 239) and is not kept; nor are two prefetching forms of this kernel, both slower than
 // letting two co-resident workgroups cover each other: double-buffered 32-wide stages (96 KB, one workgroup per CU:
-// 245 vs 270) and double-buffered 16-wide stages (48 KB, two per CU, twice the barriers: 230).  Used for grids of
-// >= 8 tiles per CU; smaller problems fill the chip better with 128 x 128 tiles.
+// 245 vs 270) and double-buffered 16-wide stages (48 KB, two per CU, twice the barriers: 230).  A 512-thread
+// "ping-pong" kernel (256 x 256 tile, two wave groups alternating between a fragment-load phase and an MFMA phase,
+// bit-identical results) was also built and measured: 284 TFLOP/s with 32-wide stages, 237 with 16-wide stages and
+// counted vmcnt waits; with its LDS-DMA switched off the same schedule runs at 907 cycles per 768-cycle MFMA phase
+// (583 TFLOP/s-equivalent), with it 1697 — the global -> LDS feed, not the MFMA / LDS schedule, is what holds all of
+// these kernels near 50 % matrix-pipe duty.  Storing hi and lo of a k-tile in one 128-byte line (whole-line DMA,
+// tools/native/fullline_probe.hip) recovers 9 % of the cycles.  Used for grids of >= 8 tiles per CU; smaller problems
+// fill the chip better with 128 x 128 tiles.
 __device__ __attribute__((aligned(16))) const uint32_t g_zero16[4] = {0, 0, 0, 0};
 
 constexpr int BM3 = 256;
@@ -218,6 +233,9 @@ __global__ __launch_bounds__(256, 2) void gemm3_nt_dma256_kernel(const uint16_t*
   const int tile = blockIdx.x;
   const int64_t m0 = (int64_t)(tile / tiles_n) * BM3;
   const int64_t n0 = (int64_t)(tile % tiles_n) * BN;
+#ifdef SL_GEMM_CLOCKPROBE  // tools/native/clock_probe.hip
+  const unsigned long long probe_c0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   floatx16 acc[4][2];
 #pragma unroll
@@ -236,14 +254,14 @@ __global__ __launch_bounds__(256, 2) void gemm3_nt_dma256_kernel(const uint16_t*
     const int row = w * 64 + i * 16 + lrow;
     a_chunk[i] = (lane & 3) ^ ((row >> 2) & 3);
     const int64_t ar = m0 + row < M ? m0 + row : M - 1;
-    a_src[i] = ar * K + a_chunk[i] * 8;
+    a_src[i] = ar * SL_G3_LD(K) + a_chunk[i] * 8;
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = w * 32 + i * 16 + lrow;
     b_chunk[i] = (lane & 3) ^ ((row >> 2) & 3);
     const int64_t br = n0 + row < N ? n0 + row : N - 1;
-    b_src[i] = br * K + b_chunk[i] * 8;
+    b_src[i] = br * SL_G3_LD(K) + b_chunk[i] * 8;
   }
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
@@ -311,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_nt_dma256_kernel(const uint16_t*
   const int ntiles = (int)((K + BK - 1) / BK);
   const bool tail = (K % BK) != 0;
   for (int kt = 0; kt < ntiles; ++kt) {
-    dma_tile((int64_t)kt * BK, tail && kt + 1 == ntiles);
+    dma_tile((int64_t)kt * KSTEP, tail && kt + 1 == ntiles);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // the tile has landed for every wave
     compute();
@@ -331,6 +349,12 @@ __global__ __launch_bounds__(256, 2) void gemm3_nt_dma256_kernel(const uint16_t*
       }
     }
   }
+#ifdef SL_GEMM_CLOCKPROBE
+  if (tid == 0) {
+    epi.probe[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - probe_c0;
+    epi.probe[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - probe_r0;
+  }
+#endif
 }
 
 inline int launch_split(const float* x, const float* scale, int64_t R, int64_t K, uint16_t* hi, uint16_t* lo, hipStream_t st) {

@@ -30,11 +30,21 @@ static double run(bool zero, bool f32mode, int64_t M, int64_t N, int64_t K) {
   for (auto& v : h) v = zero ? 0 : (uint16_t)(0x3c00 + (rand() & 0x3ff) + ((rand() & 1) << 15));
   for (auto& v : hf) v = zero ? 0.f : (float)rand() / RAND_MAX - 0.5f;
   uint16_t *Ah, *Al, *Bh, *Bl; float *Af, *Bf, *out; unsigned long long* st;
+#ifdef SL_G3_LAYOUT_EXPERIMENT  // hi and lo of a k-tile in one 128-byte line: one buffer of 2 K per row, lo = hi + 32
+  hipMalloc(&Ah, M * K * 4 + 256); hipMalloc(&Bh, N * K * 4 + 256);
+  Al = Ah + 32; Bl = Bh + 32;
+#else
   hipMalloc(&Ah, M * K * 2); hipMalloc(&Al, M * K * 2); hipMalloc(&Bh, N * K * 2); hipMalloc(&Bl, N * K * 2);
+#endif
   hipMalloc(&Af, M * K * 4); hipMalloc(&Bf, N * K * 4);
   hipMalloc(&out, M * N * 4); hipMalloc(&st, 16 * 65536);
+#ifdef SL_G3_LAYOUT_EXPERIMENT
+  hipMemcpy(Ah, h.data(), M * K * 2, hipMemcpyHostToDevice); hipMemcpy(Ah + M * K, h.data(), M * K * 2, hipMemcpyHostToDevice);
+  hipMemcpy(Bh, h.data(), N * K * 2, hipMemcpyHostToDevice); hipMemcpy(Bh + N * K, h.data(), N * K * 2, hipMemcpyHostToDevice);
+#else
   hipMemcpy(Ah, h.data(), M * K * 2, hipMemcpyHostToDevice); hipMemcpy(Al, h.data(), M * K * 2, hipMemcpyHostToDevice);
   hipMemcpy(Bh, h.data(), N * K * 2, hipMemcpyHostToDevice); hipMemcpy(Bl, h.data(), N * K * 2, hipMemcpyHostToDevice);
+#endif
   hipMemcpy(Af, hf.data(), M * K * 4, hipMemcpyHostToDevice); hipMemcpy(Bf, hf.data(), N * K * 4, hipMemcpyHostToDevice);
   ProbeEpi epi{out, N, st};
   sl::ProfScope prof(-1, nullptr, 0.0);
@@ -51,7 +61,9 @@ static double run(bool zero, bool f32mode, int64_t M, int64_t N, int64_t K) {
   hipEventRecord(e1, nullptr);
   hipDeviceSynchronize();
   float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-  const int64_t nblk = ((M + 127) / 128) * ((N + 127) / 128);
+  const char* tile_env = getenv("SL_G3_TILE");
+  const int tile_sel = (!f32mode && tile_env) ? atoi(tile_env) : 128;
+  const int64_t nblk = tile_sel == 256 ? ((M + 255) / 256) * ((N + 127) / 128) : ((M + 127) / 128) * ((N + 127) / 128);
   std::vector<unsigned long long> hs(2 * nblk); hipMemcpy(hs.data(), st, 16 * nblk, hipMemcpyDeviceToHost);
   double cyc = 0, rt = 0;
   for (int64_t b = 0; b < nblk; ++b) { cyc += (double)hs[2 * b]; rt += (double)hs[2 * b + 1]; }
@@ -61,7 +73,12 @@ static double run(bool zero, bool f32mode, int64_t M, int64_t N, int64_t K) {
   cyc = cyc; rt = rt / 100e6;
   printf("%s %s: %.3f ms/launch, %.1f TFLOP/s algorithmic, shader clock %.0f MHz\n", f32mode ? "f32-mfma" : "bf16x3  ",
          zero ? "zeros " : "random", real / reps * 1e3, tf, cyc / rt / 1e6);
-  hipFree(Ah); hipFree(Al); hipFree(Bh); hipFree(Bl); hipFree(Af); hipFree(Bf); hipFree(out); hipFree(st);
+#ifdef SL_G3_LAYOUT_EXPERIMENT
+  hipFree(Ah); hipFree(Bh);
+#else
+  hipFree(Ah); hipFree(Al); hipFree(Bh); hipFree(Bl);
+#endif
+  hipFree(Af); hipFree(Bf); hipFree(out); hipFree(st);
   return tf;
 }
 
