@@ -179,25 +179,66 @@ class ActivationComponentVisualizer(AbstractComponentVisualizer):
 
     # ---- hot loop 2 + gather (activation_based.py:360-451) ---------------------------------------
     @torch.no_grad()
-    def _compute_concept_db(self, fm, batch_size=32, keep_on_device: bool = False, referenced_only: bool = False, **kwargs):
+    def _compute_concept_db(self, fm, batch_size=32, keep_on_device: bool = False, referenced_only: bool = False,
+                            single_pass: bool = False, **kwargs):
         """``{layer: (n_components, n_samples, D)}`` = embeddings of each component's top samples.
 
         Returns host tensors like the reference unless ``keep_on_device`` is set.  ``referenced_only`` embeds only the
         samples some component actually refers to (at most ``sum(C) * k`` of the ``N`` samples — 72 k of ImageNet's
         1.28 M for ResNet-50 layer2-4 at k=20) instead of the whole dataset as the reference does
         (activation_based.py:392-433); the concept DB is the same whenever ``fm`` embeds a sample independently of
-        its batch.
+        its batch.  ``single_pass`` walks ``dataset`` and ``dataset_fm`` together, one batch at a
+        time: forward + collect on the current HIP stream, the embedding of the same batch on a second stream beside it
+        (the reference makes two sequential passes, activation_based.py:341-358 then :392-433); same top-k states and
+        concept DB, +6 % throughput in ``bench.py``.  When the top-k cache exists only the embedding pass runs.
         """
-        self.run(batch_size=batch_size, **kwargs)
-        if referenced_only:
-            return self._concept_db_from_referenced(fm, batch_size, keep_on_device, **kwargs)
-        embeds = self._embed_vision_dataset(fm, batch_size, **kwargs)
+        if single_pass and not referenced_only:
+            embeds = self._collect_and_embed_single_pass(fm, batch_size, **kwargs)
+        else:
+            self.run(batch_size=batch_size, **kwargs)
+            if referenced_only:
+                return self._concept_db_from_referenced(fm, batch_size, keep_on_device, **kwargs)
+            embeds = self._embed_vision_dataset(fm, batch_size, **kwargs)
         concept_db = dict()
         for layer_name in self.layer_names:
             ids = self.get_max_reference(layer_name)
             gathered = N.gather_rows(embeds, ids)
             concept_db[layer_name] = gathered if keep_on_device else gathered.cpu()
         return concept_db
+
+    def _collect_and_embed_single_pass(self, fm, batch_size, num_workers: int = 0, **kwargs):
+        """Hot loops 1 and 2 fused over one walk of the data, on two HIP streams.  Returns the ``(N, D)`` table."""
+        if self._cache_root is not None:
+            try:
+                self.actmax_cache.load(self.storage_dir)
+                return self._embed_vision_dataset(fm, batch_size, num_workers=num_workers, **kwargs)
+            except FileNotFoundError:
+                logger.debug(f"Activation maximization cache not found at {self.storage_dir}. Running computation...")
+        fm.to(self.device)
+
+        def first(batch):
+            return [item[0] if isinstance(item, (tuple, list)) else item for item in batch]
+
+        loader_m = torch.utils.data.DataLoader(self.dataset, batch_size=batch_size, shuffle=False, num_workers=num_workers)
+        loader_f = torch.utils.data.DataLoader(self.dataset_fm, batch_size=batch_size, shuffle=False, collate_fn=first,
+                                               num_workers=num_workers)
+        n_total = len(self.dataset_fm)
+        main = torch.cuda.current_stream(self.device)
+        side = torch.cuda.Stream(self.device)
+        embeds, filled = None, 0
+        with self.actmax_cache.hook_context(self.model):
+            for (images, _), items in tqdm(zip(loader_m, loader_f), total=len(loader_m), desc="Collecting + embedding"):
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    embeds, filled = self.embed_batch(fm, items, embeds, filled, n_total)
+                self.collect_batch(images)
+        main.wait_stream(side)
+        if embeds is None:
+            raise RuntimeError("dataset_fm is empty: nothing to embed")
+        assert filled == n_total, "Number of embeddings does not match number of ids!"
+        if self._cache_root:
+            self.actmax_cache.store(self.storage_dir)
+        return embeds
 
     def _concept_db_from_referenced(self, fm, batch_size, keep_on_device, **kwargs):
         n_total = len(self.dataset_fm)

@@ -127,3 +127,30 @@ def test_referenced_only_embedding_gives_the_same_concept_db():
         assert fm_ref.calls["encode_image"] == -(-n_ref // 4) and fm_all.calls["encode_image"] == -(-n // 4)
         if n == 40:
             assert n_ref < n
+
+
+def test_single_pass_two_stream_build_equals_two_pass(tmp_path):
+    """collect + embed fused over one walk of the data on two HIP streams == the reference's two sequential passes:
+    same top-k states, same concept DB; with a cache directory the states are stored, and a second call (cache hit)
+    only embeds."""
+    model = make_int_conv_model().to(DEV)
+    ds = TensorPairDataset(make_int_images(37))
+
+    def build(cache=None):
+        return ActivationComponentVisualizer(model, ds, ds, ["0", "2"], num_samples=5, aggregate_fn=aggregators.aggregate_conv_max,
+                                             tie_mode="aten", cache_dir=cache)
+
+    cv_ref = build()
+    want = cv_ref._compute_concept_db(FakeVLM().to(DEV), batch_size=8)
+    cv = build(str(tmp_path))
+    got = cv._compute_concept_db(FakeVLM().to(DEV), batch_size=8, single_pass=True)
+    for name in ("0", "2"):
+        assert torch.equal(cv.get_max_reference(name), cv_ref.get_max_reference(name))
+        assert torch.equal(got[name], want[name])
+    assert any(cv.storage_dir.rglob("*.safetensors"))
+    cv2 = build(str(tmp_path))  # constructor + run() find the cache: no forward pass of the model any more
+    model_calls = []
+    h = model.register_forward_hook(lambda m, i, o: model_calls.append(1))
+    again = cv2._compute_concept_db(FakeVLM().to(DEV), batch_size=8, single_pass=True)
+    h.remove()
+    assert not model_calls and all(torch.equal(again[n], want[n]) for n in ("0", "2"))
