@@ -46,6 +46,13 @@ def transform(arr, size, resize_mode, interp):
     return u8, t.numpy()
 
 
+def procedural_image(h, w):
+    """Deterministic (h, w, 3) uint8 test image: hard edges + gradients, no RNG (tests regenerate it)."""
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.int64)
+    chans = [((yy * 131 + xx * 71 + c * 29 + (yy // 17) * (xx // 23) * 7) % 256) for c in range(3)]
+    return np.stack(chans, axis=-1).astype(np.uint8)
+
+
 def main():
     rng = np.random.default_rng(7)
     cases = [  # (h, w, S, mode, interp)
@@ -80,6 +87,17 @@ def main():
             out[f"u8_{i}_sum"] = np.int64(u8.astype(np.int64).sum())
             out[f"u8_{i}_sample"] = u8[::7, ::5].copy()
             out[f"f32_{i}_sample"] = f[:, ::7, ::5].copy()
+    # large sources, generated procedurally so the fixture stores no input: long filters (ksize up to 127) and a tile
+    # of the output as the expectation
+    for j, (h, w, S, mode, interp) in enumerate([(1500, 1000, 32, "shortest", "bicubic"), (37, 2900, 48, "squash", "bilinear"),
+                                                  (2000, 3000, 224, "shortest", "bicubic")]):
+        arr = procedural_image(h, w)
+        u8, f = transform(arr, S, mode, interp)
+        out[f"proc_cfg{j}"] = np.array([h, w, S, {"shortest": 0, "squash": 1}[mode], {"bicubic": 0, "bilinear": 1}[interp]], np.int64)
+        out[f"proc_u8_{j}_sum"] = np.int64(u8.astype(np.int64).sum())
+        out[f"proc_u8_{j}_sample"] = u8[::3, ::3].copy()
+        out[f"proc_f32_{j}_sample"] = f[:, ::5, ::5].copy()
+    out["n_proc"] = np.int64(3)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, OUT.stat().st_size, "bytes")
 

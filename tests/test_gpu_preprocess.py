@@ -93,3 +93,15 @@ def test_native_clip_with_device_preprocess_matches_host_transform():
     host = np.stack([oracle.preprocess(i, S, pp.mean, pp.std)[1] for i in imgs])
     exp = fm.encode_image(torch.from_numpy(host).to(DEV)).cpu()
     assert torch.equal(got, exp)
+
+
+def test_long_filters_and_large_sources_match_pillow_golden(golden):
+    """1500x1000 -> 32 (127 taps), 37x2900 squash, 2000x3000 -> 224: procedurally generated sources, Pillow's output."""
+    from test_oracle_golden import _procedural_image
+
+    g = golden("preprocess")
+    for j in range(int(g["n_proc"])):
+        h, w, S, mode, interp = (int(v) for v in g[f"proc_cfg{j}"])
+        f, u8 = _run([_procedural_image(h, w)], S, g["mean"], g["std"], ["shortest", "squash"][mode], ["bicubic", "bilinear"][interp])
+        assert int(u8[0].astype(np.int64).sum()) == int(g[f"proc_u8_{j}_sum"]), j
+        assert np.array_equal(u8[0][::3, ::3], g[f"proc_u8_{j}_sample"]) and np.array_equal(f[0][:, ::5, ::5], g[f"proc_f32_{j}_sample"]), j
