@@ -130,7 +130,7 @@ int sl_gather_rows_shard(const float* d_emb_local, int64_t n_local, int64_t D, c
  * (xr,yr)); SL_E_INVALID for incompatible shapes (the reference raises ValueError).
  * d_ws: scratch of sl_similarity_ws_bytes(...) bytes.
  * Arithmetic of the plain branch: split-bf16 x3 on the bf16 matrix cores (|error| ~1e-6 on cosines) when
- * K % 8 == 0 and K >= 64, else fp32-input MFMA; SL_GEMM_MODE=f32 in the environment forces the latter. */
+ * K >= 64, else fp32-input MFMA; SL_GEMM_MODE=f32 in the environment forces the latter. */
 int sl_similarity(const float* d_x, int64_t xr, int64_t xc, const float* d_y, int64_t yr, int64_t yc, float* d_out,
                   void* d_ws, size_t ws_bytes, void* stream);
 size_t sl_similarity_ws_bytes(int64_t xr, int64_t xc, int64_t yr, int64_t yc);
@@ -190,29 +190,30 @@ int sl_template_mean(const float* d_E, const float* d_E0, int64_t Q, int64_t T, 
 int sl_linear(const float* d_x, int64_t M, int64_t K, const float* d_w, int64_t N, const float* d_bias, int act,
               const float* d_residual, float* d_out, int64_t ldo, int64_t rows_per_group, int64_t group_stride,
               int64_t row_offset, const float* d_rowadd, void* stream);
-/* Split-bf16 operands: every fp32 value v is carried as hi = bf16(v), lo = bf16(v - hi) (two (R,K) bf16 arrays).
+/* Split matrices: every fp32 value v is carried as hi = bf16(v), lo = bf16(v - hi).  An (R,K) matrix is stored as R
+ * rows of 2*Kp bf16 values (Kp = K rounded up to 32, zero padded, the padding must stay zero); each 32-wide k-tile of
+ * a row is one 128-byte line [hi(32) | lo(32)]; the buffer is 128-byte aligned and holds sl_split_elems(R,K) uint16.
  * sl_linear_bf16x3 multiplies such operands with three bf16 MFMAs per product (hi*hi + hi*lo + lo*hi, fp32
  * accumulate): fp32-class accuracy at ~2.4x the speed of sl_linear.  Producers (sl_layernorm, sl_attention,
- * sl_patchify, and sl_linear_bf16x3 itself) can emit the split form directly through their d_out_hi/d_out_lo
- * arguments (then d_out may be NULL); sl_split_bf16 converts an fp32 matrix (optionally scaling each row first). */
-int sl_split_bf16(const float* d_x, const float* d_row_scale, int64_t R, int64_t K, uint16_t* d_hi, uint16_t* d_lo,
-                  void* stream);
-int sl_linear_bf16x3(const uint16_t* d_xh, const uint16_t* d_xl, int64_t M, int64_t K, const uint16_t* d_wh,
-                     const uint16_t* d_wl, int64_t N, const float* d_bias, int act, const float* d_residual, float* d_out,
-                     uint16_t* d_out_hi, uint16_t* d_out_lo, int64_t ldo, int64_t rows_per_group, int64_t group_stride,
-                     int64_t row_offset, const float* d_rowadd, void* stream);
-/* LayerNorm over the last dim (biased variance, like torch.nn.LayerNorm); row strides in elements. */
+ * sl_patchify, and sl_linear_bf16x3 itself) can emit the split form directly through d_out_split (then d_out is
+ * NULL); sl_split_bf16 converts an fp32 matrix (optionally scaling each row first) and writes the zero padding. */
+size_t sl_split_elems(int64_t R, int64_t K);
+int sl_split_bf16(const float* d_x, const float* d_row_scale, int64_t R, int64_t K, uint16_t* d_split, void* stream);
+int sl_linear_bf16x3(const uint16_t* d_x_split, int64_t M, int64_t K, const uint16_t* d_w_split, int64_t N,
+                     const float* d_bias, int act, const float* d_residual, float* d_out, uint16_t* d_out_split, int64_t ldo,
+                     int64_t rows_per_group, int64_t group_stride, int64_t row_offset, const float* d_rowadd, void* stream);
+/* LayerNorm over the last dim (biased variance, like torch.nn.LayerNorm); row strides in elements (fp32 output);
+ * d_out_split: (rows, cols) split matrix. */
 int sl_layernorm(const float* d_x, int64_t rows, int64_t cols, int64_t x_row_stride, const float* d_gamma,
-                 const float* d_beta, float eps, float* d_out, uint16_t* d_out_hi, uint16_t* d_out_lo,
-                 int64_t out_row_stride, void* stream);
+                 const float* d_beta, float eps, float* d_out, uint16_t* d_out_split, int64_t out_row_stride, void* stream);
 /* softmax(q k^T / sqrt(head_dim)) v per (batch, head); d_qkv (B*T, 3*H*head_dim) rows [q | k | v]
- * (torch MultiheadAttention in_proj layout), out (B*T, H*head_dim); causal != 0 masks keys j > i.
+ * (torch MultiheadAttention in_proj layout), out (B*T, H*head_dim) fp32 or split; causal != 0 masks keys j > i.
  * head_dim in {32, 64, 72, 80, 88, 96, 104, 128}; any sequence length (K/V stream through LDS in chunks). */
 int sl_attention(const float* d_qkv, int64_t B, int64_t T, int64_t H, int64_t head_dim, int causal, float* d_out,
-                 uint16_t* d_out_hi, uint16_t* d_out_lo, void* stream);
+                 uint16_t* d_out_split, void* stream);
 /* (B,C,Hi,Wi) image -> (B*(Hi/P)*(Wi/P), C*P*P) patch rows, k = c*P*P + py*P + px (Conv2d weight order). */
 int sl_patchify(const float* d_img, int64_t B, int64_t C, int64_t Hi, int64_t Wi, int64_t P, float* d_out,
-                uint16_t* d_out_hi, uint16_t* d_out_lo, void* stream);
+                uint16_t* d_out_split, void* stream);
 /* out[g * group_stride_elems + c] = v[c] + add[c] for g < G (class-token row of every image). */
 int sl_broadcast_row(const float* d_v, const float* d_add, int64_t G, int64_t group_stride_elems, int64_t N, float* d_out,
                      void* stream);

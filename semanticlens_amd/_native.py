@@ -62,11 +62,12 @@ SIGNATURES = {
     "sl_poly2means": (_int, [_vp, _i64, _i64, _i64, _vp, _int, _vp, _int, _vp, _vp, _vp, _sz, _vp]),
     "sl_poly2means_ws_bytes": (_sz, [_i64, _i64, _i64]),
     "sl_linear": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
-    "sl_layernorm": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _i64, _vp]),
-    "sl_attention": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp, _vp]),
-    "sl_patchify": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
-    "sl_split_bf16": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
-    "sl_linear_bf16x3": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _int, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "sl_layernorm": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, ctypes.c_float, _vp, _vp, _i64, _vp]),
+    "sl_attention": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp]),
+    "sl_patchify": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "sl_split_elems": (_sz, [_i64, _i64]),
+    "sl_split_bf16": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "sl_linear_bf16x3": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "sl_broadcast_row": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "sl_embed_tokens": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "sl_preprocess_plan": (_int, [_vp, _vp, _i64, _int, _int, _int, _vp, _vp]),
@@ -422,25 +423,44 @@ def linear(x, w, bias=None, act=SL_ACT_NONE, residual=None, out=None, scatter=No
 
 
 class Split:
-    """An fp32 matrix carried as two bf16 matrices (hi = bf16(v), lo = bf16(v - hi)): operand of the bf16x3 GEMM."""
+    """An fp32 matrix carried as a split matrix (hi = bf16(v), lo = bf16(v - hi)): operand of the bf16x3 GEMM.
+
+    One buffer of ``rows x 2 Kp`` bf16 values, ``Kp`` = ``cols`` rounded up to 32 and zero padded; each 32-wide k-tile of a
+    row is one 128-byte line ``[hi(32) | lo(32)]`` (``include/semanticlens_amd.h``).  ``hi`` / ``lo`` materialise the two
+    halves as ``(rows, cols)`` bf16 tensors (tests, debugging)."""
 
     def __init__(self, rows: int, cols: int, device):
-        self.hi = torch.empty((rows, cols), dtype=torch.bfloat16, device=device)
-        self.lo = torch.empty((rows, cols), dtype=torch.bfloat16, device=device)
         self.shape = (rows, cols)
+        self.kp = (cols + 31) // 32 * 32
+        # producers write columns < cols only; the padding (if any) must read as zero in the GEMM
+        alloc = torch.empty if self.kp == cols else torch.zeros
+        self.buf = alloc((rows, 2 * self.kp), dtype=torch.bfloat16, device=device)
+        assert self.buf.numel() == int(lib().sl_split_elems(rows, cols))
+
+    def _half(self, which: int) -> torch.Tensor:
+        rows, cols = self.shape
+        return self.buf.view(rows, self.kp // 32, 2, 32)[:, :, which, :].reshape(rows, self.kp)[:, :cols]
+
+    @property
+    def hi(self) -> torch.Tensor:
+        return self._half(0)
+
+    @property
+    def lo(self) -> torch.Tensor:
+        return self._half(1)
 
     @classmethod
     def of(cls, x: torch.Tensor, row_scale: torch.Tensor | None = None) -> "Split":
         x = x.contiguous()
         out = cls(x.shape[0], x.shape[1], x.device)
         with torch.cuda.device(x.device):
-            rc = lib().sl_split_bf16(_ptr(x), _ptr(row_scale), x.shape[0], x.shape[1], _ptr(out.hi), _ptr(out.lo), _stream(x))
+            rc = lib().sl_split_bf16(_ptr(x), _ptr(row_scale), x.shape[0], x.shape[1], _ptr(out.buf), _stream(x))
         _check(rc, "sl_split_bf16")
         return out
 
 
-def _split_ptrs(sp):
-    return (_ptr(sp.hi), _ptr(sp.lo)) if sp is not None else (_vp(None), _vp(None))
+def _split_ptr(sp):
+    return _ptr(sp.buf) if sp is not None else _vp(None)
 
 
 def linear3(x: Split, w: Split, bias=None, act=SL_ACT_NONE, residual=None, out=None, out_split: Split | None = None,
@@ -449,15 +469,16 @@ def linear3(x: Split, w: Split, bias=None, act=SL_ACT_NONE, residual=None, out=N
     + residual, or scattered rows) or, with ``out_split``, split bf16 ready to feed the next GEMM."""
     M, K = x.shape
     Nn = w.shape[0]
-    dev = x.hi.device
+    dev = x.buf.device
+    if w.shape[1] != K:
+        raise ValueError(f"linear3: x has {K} columns, w has {w.shape[1]}")
     if out is None and out_split is None:
         out = torch.empty((M, Nn), dtype=torch.float32, device=dev)
     ldo = out.stride(0) if out is not None else Nn
     rpg, gs, ro = scatter if scatter is not None else (0, 0, 0)
-    oh, ol = _split_ptrs(out_split)
     with torch.cuda.device(dev):
-        rc = lib().sl_linear_bf16x3(_ptr(x.hi), _ptr(x.lo), M, K, _ptr(w.hi), _ptr(w.lo), Nn, _ptr(bias), act, _ptr(residual),
-                                    _ptr(out), oh, ol, ldo, rpg, gs, ro, _ptr(rowadd), _stream(x.hi))
+        rc = lib().sl_linear_bf16x3(_ptr(x.buf), M, K, _ptr(w.buf), Nn, _ptr(bias), act, _ptr(residual), _ptr(out),
+                                    _split_ptr(out_split), ldo, rpg, gs, ro, _ptr(rowadd), _stream(x.buf))
     _check(rc, "sl_linear_bf16x3")
     return out if out is not None else out_split
 
@@ -468,9 +489,9 @@ def layernorm(x, gamma, beta, eps, out=None, rows=None, x_row_stride=None, out_s
     xs = x_row_stride if x_row_stride is not None else cols
     if out is None and out_split is None:
         out = torch.empty((rows, cols), dtype=torch.float32, device=x.device)
-    oh, ol = _split_ptrs(out_split)
     with torch.cuda.device(x.device):
-        rc = lib().sl_layernorm(_ptr(x), rows, cols, xs, _ptr(gamma), _ptr(beta), float(eps), _ptr(out), oh, ol, cols, _stream(x))
+        rc = lib().sl_layernorm(_ptr(x), rows, cols, xs, _ptr(gamma), _ptr(beta), float(eps), _ptr(out), _split_ptr(out_split),
+                                cols, _stream(x))
     _check(rc, "sl_layernorm")
     return out if out is not None else out_split
 
@@ -478,9 +499,8 @@ def layernorm(x, gamma, beta, eps, out=None, rows=None, x_row_stride=None, out_s
 def attention(qkv, B, T, H, head_dim, causal, out=None, out_split: Split | None = None):
     if out is None and out_split is None:
         out = torch.empty((B * T, H * head_dim), dtype=torch.float32, device=qkv.device)
-    oh, ol = _split_ptrs(out_split)
     with torch.cuda.device(qkv.device):
-        rc = lib().sl_attention(_ptr(qkv), B, T, H, head_dim, 1 if causal else 0, _ptr(out), oh, ol, _stream(qkv))
+        rc = lib().sl_attention(_ptr(qkv), B, T, H, head_dim, 1 if causal else 0, _ptr(out), _split_ptr(out_split), _stream(qkv))
     _check(rc, "sl_attention")
     return out if out is not None else out_split
 
@@ -489,9 +509,8 @@ def patchify(img, P, out=None, out_split: Split | None = None):
     B, C, Hi, Wi = img.shape
     if out is None and out_split is None:
         out = torch.empty((B * (Hi // P) * (Wi // P), C * P * P), dtype=torch.float32, device=img.device)
-    oh, ol = _split_ptrs(out_split)
     with torch.cuda.device(img.device):
-        rc = lib().sl_patchify(_ptr(img), B, C, Hi, Wi, P, _ptr(out), oh, ol, _stream(img))
+        rc = lib().sl_patchify(_ptr(img), B, C, Hi, Wi, P, _ptr(out), _split_ptr(out_split), _stream(img))
     _check(rc, "sl_patchify")
     return out if out is not None else out_split
 

@@ -151,7 +151,7 @@ bool use_bf16x3() {
 void set_gemm_mode(int m) { g_gemm_mode = m; }
 
 // bytes of split-bf16 scratch for an (R x K) operand: hi + lo
-size_t split_bytes(int64_t R, int64_t K) { return 2 * align256_((size_t)R * (size_t)K * 2); }
+size_t split_bytes(int64_t R, int64_t K) { return align256_(gemm3::split_elems(R, K) * 2); }
 
 // out[M][N] = cos(A rows, B rows).  ra/rb: scratch for the inverse norms; split: scratch of
 // split_bytes(M,K) + split_bytes(N,K) bytes (may be NULL -> fp32 path).  Used by K6 and K8.
@@ -165,20 +165,17 @@ int cosine_matrix_nt(const float* A, int64_t M, const float* B, int64_t N, int64
     return rc;
   }
   // below K = 64 too few products average the ~2^-16 split error down; those GEMMs are tiny anyway
-  if (split && use_bf16x3() && K % 8 == 0 && K >= 64) {
+  if (split && use_bf16x3() && K >= 64) {
     unsigned char* p = (unsigned char*)split;
-    uint16_t* ah = (uint16_t*)p;
-    uint16_t* al = (uint16_t*)(p + align256_((size_t)M * K * 2));
-    uint16_t* bh = ah;
-    uint16_t* bl = al;
-    if (int rc = gemm3::launch_split(A, ra, M, K, ah, al, st)) return rc;  // x_hat = x * rinv, then hi/lo
+    uint16_t* as = (uint16_t*)p;
+    uint16_t* bs = as;
+    if (int rc = gemm3::launch_split(A, ra, M, K, as, st)) return rc;  // x_hat = x * rinv, then the split matrix
     if (!same) {
-      bh = (uint16_t*)(p + split_bytes(M, K));
-      bl = (uint16_t*)(p + split_bytes(M, K) + align256_((size_t)N * K * 2));
-      if (int rc = gemm3::launch_split(B, rb, N, K, bh, bl, st)) return rc;
+      bs = (uint16_t*)(p + split_bytes(M, K));
+      if (int rc = gemm3::launch_split(B, rb, N, K, bs, st)) return rc;
     }
     ProfScope prof(SL_PROF_GEMM, st, 2.0 * (double)M * (double)N * (double)K);
-    return gemm3::launch_gemm3_nt(prof, ah, al, M, bh, bl, N, K, PlainEpi{out, N}, st);
+    return gemm3::launch_gemm3_nt(prof, as, M, bs, N, K, PlainEpi{out, N}, st);
   }
   ProfScope prof(SL_PROF_GEMM, st, 2.0 * (double)M * (double)N * (double)K);
   return gemm::launch_gemm_nt(prof, A, M, B, N, K, CosineEpi{ra, rb, out, N}, st);
@@ -195,29 +192,28 @@ int cosine_matrix_multi(const float* X, int64_t Q, int64_t K, const float* const
     cmax = Cs[l] > cmax ? Cs[l] : cmax;
     csum += Cs[l];
   }
-  const bool fast = use_bf16x3() && K % 8 == 0 && K >= 64;
+  const bool fast = use_bf16x3() && K >= 64;
   const bool fused = fast && L <= kMaxFusedLayers;
   const int64_t yrows = fused ? csum : cmax;  // rows of the y scratch (all layers, or one at a time)
   float* rx = (float*)ws;
   float* ry = (float*)(ws + align256_((size_t)Q * 4));
   unsigned char* sp = ws + align256_((size_t)Q * 4) + align256_((size_t)yrows * 4);
   if (int rc = launch_inv_norm(X, Q, K, 1e-12f, rx, st)) return rc;
-  uint16_t* xh = (uint16_t*)sp;
-  uint16_t* xl = (uint16_t*)(sp + align256_((size_t)Q * K * 2));
-  uint16_t* yh = (uint16_t*)(sp + split_bytes(Q, K));
-  uint16_t* yl = (uint16_t*)(sp + split_bytes(Q, K) + align256_((size_t)yrows * K * 2));
+  uint16_t* xs = (uint16_t*)sp;
+  uint16_t* ys = (uint16_t*)(sp + split_bytes(Q, K));
+  const int64_t row_elems = 2 * gemm3::split_kp(K);
   if (fast)
-    if (int rc = gemm3::launch_split(X, rx, Q, K, xh, xl, st)) return rc;
+    if (int rc = gemm3::launch_split(X, rx, Q, K, xs, st)) return rc;
   if (fused) {
     // every layer is normalised + split into its rows of ONE (sum C, K) operand; a single GEMM launch then fills the
-    // chip (12 x 768 columns: 2880 tiles of 256 x 128 instead of 12 launches of 474 tiles of 128 x 128)
+    // chip (12 x 768 columns: 1440 tiles of 256 x 128 instead of 12 launches of 474 tiles of 128 x 128)
     MultiEpi epi{};
     epi.n = 0;
     int64_t off = 0;
     for (int l = 0; l < L; ++l) {
       if (Cs[l] == 0) continue;
       if (int rc = launch_inv_norm(Ys[l], Cs[l], K, 1e-12f, ry + off, st)) return rc;
-      if (int rc = gemm3::launch_split(Ys[l], ry + off, Cs[l], K, yh + off * K, yl + off * K, st)) return rc;
+      if (int rc = gemm3::launch_split(Ys[l], ry + off, Cs[l], K, ys + off * row_elems, st)) return rc;
       epi.out[epi.n] = outs[l];
       epi.start[epi.n] = off;
       ++epi.n;
@@ -226,7 +222,7 @@ int cosine_matrix_multi(const float* X, int64_t Q, int64_t K, const float* const
     epi.start[epi.n] = off;
     if (Q * off == 0) return 0;
     ProfScope prof(SL_PROF_GEMM, st, 2.0 * (double)Q * (double)off * (double)K);
-    return gemm3::launch_gemm3_nt(prof, xh, xl, Q, yh, yl, off, K, epi, st);
+    return gemm3::launch_gemm3_nt(prof, xs, Q, ys, off, K, epi, st);
   }
   for (int l = 0; l < L; ++l) {
     if (Q * Cs[l] == 0) continue;
@@ -234,8 +230,8 @@ int cosine_matrix_multi(const float* X, int64_t Q, int64_t K, const float* const
     ProfScope prof(SL_PROF_GEMM, st, 2.0 * (double)Q * (double)Cs[l] * (double)K);
     int rc;
     if (fast) {
-      if ((rc = gemm3::launch_split(Ys[l], ry, Cs[l], K, yh, yl, st))) return rc;
-      rc = gemm3::launch_gemm3_nt(prof, xh, xl, Q, yh, yl, Cs[l], K, PlainEpi{outs[l], Cs[l]}, st);
+      if ((rc = gemm3::launch_split(Ys[l], ry, Cs[l], K, ys, st))) return rc;
+      rc = gemm3::launch_gemm3_nt(prof, xs, Q, ys, Cs[l], K, PlainEpi{outs[l], Cs[l]}, st);
     } else {
       rc = gemm::launch_gemm_nt(prof, X, Q, Ys[l], Cs[l], K, CosineEpi{rx, ry, outs[l], Cs[l]}, st);
     }

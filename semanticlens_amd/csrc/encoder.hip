@@ -17,20 +17,17 @@ namespace sl {
 namespace {
 
 // ---- linear: out = act(x W^T + b) (+ residual), optional row scatter for the patch embedding ----------
-// write v as split bf16 (hi = bf16(v), lo = bf16(v - hi)): the operand format of the bf16x3 GEMM
-__device__ inline void store_split(float v, int64_t idx, uint16_t* hi, uint16_t* lo) {
-  const uint16_t h = f32_to_bf16_rne(v);
-  hi[idx] = h;
-  lo[idx] = f32_to_bf16_rne(v - bf16_to_f32(h));
-}
+using gemm3::split_kp;
+using gemm3::store_split;   // (v, row, col, Kp, split matrix): see gemm_bf16x3.hpp for the layout
+using gemm3::store_split4;
 
 template <int ACT, bool RES, bool REMAP, bool SPLIT = false>
 struct LinearEpi {
   const float* bias;  // (N) or nullptr
   const float* res;   // (M, ldo) or nullptr; may alias out (same element read then written by one lane)
   float* out;
-  uint16_t* out_hi;   // SPLIT: the result goes out as split bf16 instead of fp32
-  uint16_t* out_lo;
+  uint16_t* out_sp;   // SPLIT: the result goes out as a split matrix (M x N, gemm_bf16x3.hpp) instead of fp32
+  int64_t out_kp;     // its padded row length split_kp(N)
   int64_t ldo;
   int64_t rpg, gstride, roff;  // REMAP: out row = (r / rpg) * gstride + roff + r % rpg
   const float* rowadd;         // REMAP: (roff + r % rpg, col) of this (T, N) table is added (positional embedding)
@@ -47,7 +44,7 @@ struct LinearEpi {
       if (rowadd) v += rowadd[(roff + i) * N + col];
     }
     if constexpr (RES) v += res[orow * ldo + col];
-    if constexpr (SPLIT) store_split(v, orow * ldo + col, out_hi, out_lo);
+    if constexpr (SPLIT) store_split(v, orow, col, out_kp, out_sp);
     else out[orow * ldo + col] = v;
   }
 };
@@ -56,36 +53,28 @@ template <int ACT, bool RES, bool REMAP>
 int run_linear(ProfScope& prof, const float* x, int64_t M, int64_t K, const float* w, int64_t N, const float* bias,
                const float* res, float* out, int64_t ldo, int64_t rpg, int64_t gstride, int64_t roff,
                const float* rowadd, hipStream_t st) {
-  LinearEpi<ACT, RES, REMAP> epi{bias, res, out, nullptr, nullptr, ldo, rpg, gstride, roff, rowadd, N};
+  LinearEpi<ACT, RES, REMAP> epi{bias, res, out, nullptr, 0, ldo, rpg, gstride, roff, rowadd, N};
   return gemm::launch_gemm_nt(prof, x, M, w, N, K, epi, st);
 }
 
 template <int ACT, bool RES, bool REMAP, bool SPLIT>
-int run_linear3(ProfScope& prof, const uint16_t* xh, const uint16_t* xl, int64_t M, int64_t K, const uint16_t* wh,
-                const uint16_t* wl, int64_t N, const float* bias, const float* res, float* out, uint16_t* oh, uint16_t* ol,
-                int64_t ldo, int64_t rpg, int64_t gstride, int64_t roff, const float* rowadd, hipStream_t st) {
-  LinearEpi<ACT, RES, REMAP, SPLIT> epi{bias, res, out, oh, ol, ldo, rpg, gstride, roff, rowadd, N};
-  return gemm3::launch_gemm3_nt(prof, xh, xl, M, wh, wl, N, K, epi, st);
+int run_linear3(ProfScope& prof, const uint16_t* xs, int64_t M, int64_t K, const uint16_t* ws, int64_t N, const float* bias,
+                const float* res, float* out, uint16_t* osp, int64_t ldo, int64_t rpg, int64_t gstride, int64_t roff,
+                const float* rowadd, hipStream_t st) {
+  LinearEpi<ACT, RES, REMAP, SPLIT> epi{bias, res, out, osp, split_kp(N), ldo, rpg, gstride, roff, rowadd, N};
+  return gemm3::launch_gemm3_nt(prof, xs, M, ws, N, K, epi, st);
 }
 
 // ---- LayerNorm over the last dim: one wave per row -------------------------------------------------------------
 // Fast path (cols % 4 == 0, cols <= 1024, 16-byte aligned rows): the row is read once into registers (up to four
 // float4 per lane), mean and variance are two wave reductions, the result leaves as 16-byte fp32 stores or as
 // 8-byte packed bf16 hi / lo stores.  Other shapes: three passes over the (L1-resident) row.
-__device__ inline void store_split4(const float4 y, int64_t idx, uint16_t* hi, uint16_t* lo) {
-  const uint16_t h0 = f32_to_bf16_rne(y.x), h1 = f32_to_bf16_rne(y.y), h2 = f32_to_bf16_rne(y.z), h3 = f32_to_bf16_rne(y.w);
-  const uint16_t l0 = f32_to_bf16_rne(y.x - bf16_to_f32(h0)), l1 = f32_to_bf16_rne(y.y - bf16_to_f32(h1));
-  const uint16_t l2 = f32_to_bf16_rne(y.z - bf16_to_f32(h2)), l3 = f32_to_bf16_rne(y.w - bf16_to_f32(h3));
-  *reinterpret_cast<uint2*>(hi + idx) = make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16));
-  *reinterpret_cast<uint2*>(lo + idx) = make_uint2((uint32_t)l0 | ((uint32_t)l1 << 16), (uint32_t)l2 | ((uint32_t)l3 << 16));
-}
-
 template <bool FAST>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t rows, int cols,
                                                          int64_t xs, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps,
-                                                         float* __restrict__ out, int64_t os, uint16_t* __restrict__ oh,
-                                                         uint16_t* __restrict__ ol) {
+                                                         float* __restrict__ out, int64_t os, uint16_t* __restrict__ osp) {
+  const int64_t okp = split_kp(cols);  // split output: a (rows x cols) split matrix
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nw = (int64_t)gridDim.x * 4;
@@ -127,7 +116,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
           const float4 y = make_float4((v[j].x - mean) * rstd * g[j].x + bt[j].x, (v[j].y - mean) * rstd * g[j].y + bt[j].y,
                                        (v[j].z - mean) * rstd * g[j].z + bt[j].z, (v[j].w - mean) * rstd * g[j].w + bt[j].w);
           if (out) *reinterpret_cast<float4*>(out + r * os + q * 4) = y;
-          if (oh) store_split4(y, r * os + q * 4, oh, ol);
+          if (osp) store_split4(y, r, q * 4, okp, osp);
         }
       }
     }
@@ -149,7 +138,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int i = lane; i < cols; i += 64) {
       const float y = (p[i] - mean) * rstd * gamma[i] + beta[i];
       if (out) out[r * os + i] = y;
-      if (oh) store_split(y, r * os + i, oh, ol);
+      if (osp) store_split(y, r, i, okp, osp);
     }
   }
 }
@@ -164,8 +153,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // and a score buffer, ran at one wave per SIMD and took 39 % of the encoder's time).
 constexpr int kDh = 64;
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, int T, int H, int causal,
-                                                         float* __restrict__ out, uint16_t* __restrict__ oh,
-                                                         uint16_t* __restrict__ ol) {
+                                                         float* __restrict__ out, uint16_t* __restrict__ osp) {
   extern __shared__ __align__(16) float smem[];
   float* sK = smem;                    // T x 64
   float* sV = smem + (size_t)T * kDh;  // T x 64
@@ -232,9 +220,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         for (int c = 0; c < 4; ++c)
           *reinterpret_cast<float4*>(out + o0 + c * 4) = make_float4(o[4 * c] * inv, o[4 * c + 1] * inv, o[4 * c + 2] * inv, o[4 * c + 3] * inv);
       }
-      if (oh) {
+      if (osp) {
 #pragma unroll
-        for (int d = 0; d < 16; ++d) store_split(o[d] * inv, o0 + d, oh, ol);
+        for (int d = 0; d < 16; ++d) store_split(o[d] * inv, b * T + i, h * kDh + part * 16 + d, split_kp((int64_t)H * kDh), osp);
       }
     }
   }
@@ -264,8 +252,7 @@ __host__ __device__ constexpr int attn_chunk(int D) { return D <= 64 ? 256 : (D 
 
 template <int D>
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv, int T, int H, int causal, float scale,
-                                                              float* __restrict__ out, uint16_t* __restrict__ oh,
-                                                              uint16_t* __restrict__ ol) {
+                                                              float* __restrict__ out, uint16_t* __restrict__ osp) {
   constexpr int kDh = D;  // shadows the 64 of the VALU kernel
   constexpr int NT = (D + 31) / 32;
   constexpr int HD = D / 2;  // dims per half-wave in the score product (multiple of 4)
@@ -388,10 +375,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
           if (d < D) {
             const float4 v = make_float4(o[t][4 * g] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
             if (out) *reinterpret_cast<float4*>(out + obase + d) = v;
-            if (oh) {
-              store_split(v.x, obase + d, oh, ol); store_split(v.y, obase + d + 1, oh, ol);
-              store_split(v.z, obase + d + 2, oh, ol); store_split(v.w, obase + d + 3, oh, ol);
-            }
+            if (osp) store_split4(v, b * T + q, h * kDh + d, split_kp((int64_t)H * kDh), osp);
           }
         }
     }
@@ -400,8 +384,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
 
 // ---- patch extraction: (B, C, Hi, Wi) -> (B * gh * gw, C * P * P), k = c*P*P + py*P + px (conv weight order) --
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, int64_t B, int C, int Hi, int Wi,
-                                                        int P, float* __restrict__ out, uint16_t* __restrict__ oh,
-                                                        uint16_t* __restrict__ ol) {
+                                                        int P, float* __restrict__ out, uint16_t* __restrict__ osp) {
   const int gh = Hi / P, gw = Wi / P;
   const int64_t kdim = (int64_t)C * P * P;
   const int64_t total4 = B * gh * gw * kdim / 4;  // P % 4 == 0
@@ -416,10 +399,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     const float* src = img + ((bb * C + c) * Hi + gy * P + py) * (int64_t)Wi + gx * P + px;
     const float4 v = *reinterpret_cast<const float4*>(src);
     if (out) reinterpret_cast<float4*>(out)[e] = v;
-    if (oh) {
-      store_split(v.x, idx + 0, oh, ol); store_split(v.y, idx + 1, oh, ol);
-      store_split(v.z, idx + 2, oh, ol); store_split(v.w, idx + 3, oh, ol);
-    }
+    if (osp) store_split4(v, row, k, split_kp(kdim), osp);
   }
 }
 
@@ -488,30 +468,29 @@ SL_API int sl_linear(const float* d_x, int64_t M, int64_t K, const float* d_w, i
 }
 
 SL_API int sl_layernorm(const float* d_x, int64_t rows, int64_t cols, int64_t x_row_stride, const float* d_gamma,
-                        const float* d_beta, float eps, float* d_out, uint16_t* d_out_hi, uint16_t* d_out_lo,
-                        int64_t out_row_stride, void* stream) {
+                        const float* d_beta, float eps, float* d_out, uint16_t* d_out_split, int64_t out_row_stride,
+                        void* stream) {
   SL_REQUIRE(rows >= 0 && cols >= 1 && cols < (1 << 30), "sl_layernorm: bad shape");
   if (rows == 0) return 0;
-  SL_REQUIRE(d_x && d_gamma && d_beta && (d_out || (d_out_hi && d_out_lo)), "sl_layernorm: null pointer");
+  SL_REQUIRE(d_x && d_gamma && d_beta && (d_out || d_out_split), "sl_layernorm: null pointer");
   int64_t blocks = (rows + 3) / 4;
   const int64_t cap = (int64_t)num_cus() * 8;
   if (blocks > cap) blocks = cap;
-  const uintptr_t ptrs = (uintptr_t)d_x | (uintptr_t)d_gamma | (uintptr_t)d_beta | (uintptr_t)d_out | (uintptr_t)d_out_hi |
-                         (uintptr_t)d_out_lo;
+  const uintptr_t ptrs = (uintptr_t)d_x | (uintptr_t)d_gamma | (uintptr_t)d_beta | (uintptr_t)d_out | (uintptr_t)d_out_split;
   const bool fast = cols % 4 == 0 && cols <= 1024 && x_row_stride % 4 == 0 && out_row_stride % 4 == 0 && (ptrs & 15) == 0;
   if (fast)
     hipLaunchKernelGGL(layernorm_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_x, rows, (int)cols,
-                       x_row_stride, d_gamma, d_beta, eps, d_out, out_row_stride, d_out_hi, d_out_lo);
+                       x_row_stride, d_gamma, d_beta, eps, d_out, out_row_stride, d_out_split);
   else
     hipLaunchKernelGGL(layernorm_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_x, rows, (int)cols,
-                       x_row_stride, d_gamma, d_beta, eps, d_out, out_row_stride, d_out_hi, d_out_lo);
+                       x_row_stride, d_gamma, d_beta, eps, d_out, out_row_stride, d_out_split);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
 template <int D>
-static int launch_attention_mfma(const float* qkv, int64_t B, int64_t T, int64_t H, int causal, float* out, uint16_t* oh,
-                                 uint16_t* ol, hipStream_t st) {
+static int launch_attention_mfma(const float* qkv, int64_t B, int64_t T, int64_t H, int causal, float* out, uint16_t* osp,
+                                 hipStream_t st) {
   const int64_t Tp = (T + 31) & ~(int64_t)31;
   const int64_t kc = Tp < attn_chunk(D) ? Tp : attn_chunk(D);
   const size_t smem = (size_t)kc * attn_ld(D) * 4 * 2;
@@ -520,17 +499,17 @@ static int launch_attention_mfma(const float* qkv, int64_t B, int64_t T, int64_t
     SL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_mfma_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   const float scale = (float)(1.0 / sqrt((double)D));  // torch: q * head_dim ** -0.5
   hipLaunchKernelGGL(attention_mfma_kernel<D>, dim3((unsigned)(B * H)), dim3(64 * waves), smem, st, qkv, (int)T, (int)H, causal,
-                     scale, out, oh, ol);
+                     scale, out, osp);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
 SL_API int sl_attention(const float* d_qkv, int64_t B, int64_t T, int64_t H, int64_t head_dim, int causal, float* d_out,
-                        uint16_t* d_out_hi, uint16_t* d_out_lo, void* stream) {
+                        uint16_t* d_out_split, void* stream) {
   SL_REQUIRE(B >= 0 && T >= 1 && H >= 1, "sl_attention: bad shape");
   SL_REQUIRE(T < (1 << 24), "sl_attention: sequence length %lld too long", (long long)T);
   if (B == 0) return 0;
-  SL_REQUIRE(d_qkv && (d_out || (d_out_hi && d_out_lo)), "sl_attention: null pointer");
+  SL_REQUIRE(d_qkv && (d_out || d_out_split), "sl_attention: null pointer");
   SL_REQUIRE(B * H < (1ll << 31), "sl_attention: too many heads");
   static const int impl = [] {
     const char* e = getenv("SL_ATTENTION_IMPL");  // "valu": the 4-lanes-per-row kernel (head_dim 64, T <= 256)
@@ -539,14 +518,14 @@ SL_API int sl_attention(const float* d_qkv, int64_t B, int64_t T, int64_t H, int
   hipStream_t st = (hipStream_t)stream;
   if (impl == 1) {
     switch (head_dim) {
-      case 32: return launch_attention_mfma<32>(d_qkv, B, T, H, causal, d_out, d_out_hi, d_out_lo, st);
-      case 64: return launch_attention_mfma<64>(d_qkv, B, T, H, causal, d_out, d_out_hi, d_out_lo, st);
-      case 72: return launch_attention_mfma<72>(d_qkv, B, T, H, causal, d_out, d_out_hi, d_out_lo, st);
-      case 80: return launch_attention_mfma<80>(d_qkv, B, T, H, causal, d_out, d_out_hi, d_out_lo, st);
-      case 88: return launch_attention_mfma<88>(d_qkv, B, T, H, causal, d_out, d_out_hi, d_out_lo, st);
-      case 96: return launch_attention_mfma<96>(d_qkv, B, T, H, causal, d_out, d_out_hi, d_out_lo, st);
-      case 104: return launch_attention_mfma<104>(d_qkv, B, T, H, causal, d_out, d_out_hi, d_out_lo, st);
-      case 128: return launch_attention_mfma<128>(d_qkv, B, T, H, causal, d_out, d_out_hi, d_out_lo, st);
+      case 32: return launch_attention_mfma<32>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
+      case 64: return launch_attention_mfma<64>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
+      case 72: return launch_attention_mfma<72>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
+      case 80: return launch_attention_mfma<80>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
+      case 88: return launch_attention_mfma<88>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
+      case 96: return launch_attention_mfma<96>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
+      case 104: return launch_attention_mfma<104>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
+      case 128: return launch_attention_mfma<128>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
       default: break;
     }
     SL_REQUIRE(false, "sl_attention: head_dim=%lld (built: 32, 64, 72, 80, 88, 96, 104, 128)", (long long)head_dim);
@@ -557,20 +536,20 @@ SL_API int sl_attention(const float* d_qkv, int64_t B, int64_t T, int64_t H, int
   if (smem > 64 * 1024)
     SL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(attention_kernel, dim3((unsigned)(B * H)), dim3(256), smem, st, d_qkv, (int)T, (int)H, causal, d_out,
-                     d_out_hi, d_out_lo);
+                     d_out_split);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
 SL_API int sl_patchify(const float* d_img, int64_t B, int64_t C, int64_t Hi, int64_t Wi, int64_t P, float* d_out,
-                       uint16_t* d_out_hi, uint16_t* d_out_lo, void* stream) {
+                       uint16_t* d_out_split, void* stream) {
   SL_REQUIRE(B >= 0 && C >= 1 && P >= 4 && P % 4 == 0 && Hi % P == 0 && Wi % P == 0, "sl_patchify: bad geometry");
   if (B == 0) return 0;
-  SL_REQUIRE(d_img && (d_out || (d_out_hi && d_out_lo)), "sl_patchify: null pointer");
+  SL_REQUIRE(d_img && (d_out || d_out_split), "sl_patchify: null pointer");
   SL_REQUIRE((((uintptr_t)d_img | (uintptr_t)d_out) & 15) == 0 && Wi % 4 == 0, "sl_patchify: needs 16-byte aligned rows");
   const int64_t total4 = B * C * Hi * Wi / 4;
   hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)grid_for(total4)), dim3(256), 0, (hipStream_t)stream, d_img, B, (int)C,
-                     (int)Hi, (int)Wi, (int)P, d_out, d_out_hi, d_out_lo);
+                     (int)Hi, (int)Wi, (int)P, d_out, d_out_split);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -597,31 +576,33 @@ SL_API int sl_embed_tokens(const float* d_table, int64_t vocab, const int64_t* d
   return 0;
 }
 
-SL_API int sl_split_bf16(const float* d_x, const float* d_row_scale, int64_t R, int64_t K, uint16_t* d_hi, uint16_t* d_lo,
-                         void* stream) {
+SL_API size_t sl_split_elems(int64_t R, int64_t K) { return (R < 0 || K < 0) ? 0 : gemm3::split_elems(R, K); }
+
+SL_API int sl_split_bf16(const float* d_x, const float* d_row_scale, int64_t R, int64_t K, uint16_t* d_split, void* stream) {
   SL_REQUIRE(R >= 0 && K >= 0, "sl_split_bf16: negative shape");
   if (R * K == 0) return 0;
-  SL_REQUIRE(d_x && d_hi && d_lo, "sl_split_bf16: null pointer");
-  return gemm3::launch_split(d_x, d_row_scale, R, K, d_hi, d_lo, (hipStream_t)stream);
+  SL_REQUIRE(d_x && d_split && ((uintptr_t)d_split & 127) == 0, "sl_split_bf16: null or unaligned pointer (128-byte lines)");
+  return gemm3::launch_split(d_x, d_row_scale, R, K, d_split, (hipStream_t)stream);
 }
 
-SL_API int sl_linear_bf16x3(const uint16_t* d_xh, const uint16_t* d_xl, int64_t M, int64_t K, const uint16_t* d_wh,
-                            const uint16_t* d_wl, int64_t N, const float* d_bias, int act, const float* d_residual,
-                            float* d_out, uint16_t* d_out_hi, uint16_t* d_out_lo, int64_t ldo, int64_t rows_per_group,
-                            int64_t group_stride, int64_t row_offset, const float* d_rowadd, void* stream) {
+SL_API int sl_linear_bf16x3(const uint16_t* d_x_split, int64_t M, int64_t K, const uint16_t* d_w_split, int64_t N,
+                            const float* d_bias, int act, const float* d_residual, float* d_out, uint16_t* d_out_split,
+                            int64_t ldo, int64_t rows_per_group, int64_t group_stride, int64_t row_offset,
+                            const float* d_rowadd, void* stream) {
   SL_REQUIRE(M >= 0 && K >= 0 && N >= 0 && ldo >= N, "sl_linear_bf16x3: bad shape");
-  SL_REQUIRE(K % 8 == 0, "sl_linear_bf16x3: K must be a multiple of 8");
   SL_REQUIRE(act >= SL_ACT_NONE && act <= SL_ACT_QUICKGELU, "sl_linear_bf16x3: bad activation %d", act);
   if (M * N == 0) return 0;
-  const bool split = d_out_hi && d_out_lo;
-  SL_REQUIRE(d_xh && d_xl && d_wh && d_wl && (d_out || split) && !(d_out && split), "sl_linear_bf16x3: null / ambiguous pointers");
+  const bool split = d_out_split != nullptr;
+  SL_REQUIRE(d_x_split && d_w_split && (d_out || split) && !(d_out && split), "sl_linear_bf16x3: null / ambiguous pointers");
+  SL_REQUIRE((((uintptr_t)d_x_split | (uintptr_t)d_w_split | (uintptr_t)d_out_split) & 127) == 0,
+             "sl_linear_bf16x3: split matrices must be 128-byte aligned");
   const bool remap = rows_per_group > 0;
   SL_REQUIRE(!(remap && (act != SL_ACT_NONE || d_residual || split)), "sl_linear_bf16x3: row scatter is plain fp32 only");
   SL_REQUIRE(!(split && d_residual), "sl_linear_bf16x3: split output takes no residual");
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof(SL_PROF_GEMM, st, 2.0 * (double)M * (double)N * (double)K);
 #define SL_RUN3(A_, R_, P_, S_) \
-  return run_linear3<A_, R_, P_, S_>(prof, d_xh, d_xl, M, K, d_wh, d_wl, N, d_bias, d_residual, d_out, d_out_hi, d_out_lo, ldo, rows_per_group, group_stride, row_offset, d_rowadd, st)
+  return run_linear3<A_, R_, P_, S_>(prof, d_x_split, M, K, d_w_split, N, d_bias, d_residual, d_out, d_out_split, ldo, rows_per_group, group_stride, row_offset, d_rowadd, st)
   if (remap) SL_RUN3(SL_ACT_NONE, false, true, false);
   if (split) {
     if (act == SL_ACT_NONE) SL_RUN3(SL_ACT_NONE, false, false, true);

@@ -5,13 +5,20 @@
 // fp32-input MFMAs of 64 cycles: 5.3x the fp32-MFMA rate at peak (2.5 PFLOP/s bf16 dense / 3 = 833 TFLOP/s of
 // fp32-equivalent work; always quoted as ALGORITHMIC flops 2*M*N*K, i.e. one third of the MFMA flops issued).
 //
-// Operands arrive pre-split (split_bf16_kernel: one pass that also applies the row scale, e.g. the L2
-// normalisation of K6), so this kernel only moves bf16: tile 128x128x32, 4 waves (2x2), wave tile 64x64 = 2x2
-// MFMA tiles; four LDS images per stage (A_hi, A_lo, B_hi, B_lo), rows of 32 bf16 padded to 80 bytes so the
-// 16-byte fragment reads of a 16-lane group land in 16 distinct 16-byte slots; single LDS stage with the next
-// tile prefetched into registers (2 pieces per image per thread), which keeps LDS at 40 KB and lets 3 workgroups
-// share a CU.  A and B fragments are read with the same (lane>>5)*8 + j k-pattern, so the result does not depend
-// on how the hardware orders k inside a fragment.
+// Operand format ("split matrix", produced by split_bf16_kernel and by the split-output epilogues of the encoder
+// kernels): an (R x K) fp32 matrix becomes R rows of 2 Kp bf16 values, Kp = K rounded up to 32, zero padded; each
+// 32-wide k-tile of a row is one 128-byte line [hi(32) | lo(32)].  A k-tile of a row is therefore fetched as a
+// whole cache line (with separate hi / lo matrices every line was requested twice, by consecutive k-tiles: measured
+// -9 % cycles for the LDS-DMA kernel), and no kernel needs a partial-tile path.
+//
+// Two kernels, same accumulation order per output element (bit-identical results, tests/test_gpu_parity.py):
+//   gemm3_nt_kernel         128 x 128 x 32 tile, 4 waves (2 x 2), wave tile 64 x 64; tiles staged through registers
+//                           into four LDS images (A_hi, A_lo, B_hi, B_lo) with 80-byte rows (conflict-free fragment
+//                           reads); single LDS stage + register prefetch, 40 KB, three workgroups per CU
+//   gemm3_nt_dma256_kernel  256 x 128 x 32 tile, wave tile 128 x 64, tiles staged by LDS-DMA (see below); used for
+//                           grids of >= 8 tiles per CU
+// A and B fragments are read with the same (lane>>5)*8 + j k-pattern, so the result does not depend on how the
+// hardware orders k inside a fragment.
 #pragma once
 #include "common.hpp"
 #include <cstdlib>
@@ -23,40 +30,56 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BM = 128, BN = 128, BK = 32;
-// tools/native/clock_probe.hip -DSL_G3_LAYOUT_EXPERIMENT: timing-only emulation of an operand layout in which the hi and
-// lo halves of a 32-wide k-tile share one 128-byte line (row stride 2 K, k-tile stride 64 elements, lo = hi + 32)
-#ifdef SL_G3_LAYOUT_EXPERIMENT
-#define SL_G3_LD(K) (2 * (K))
-constexpr int KSTEP = 64;
-#else
-#define SL_G3_LD(K) (K)
-constexpr int KSTEP = BK;
-#endif
 constexpr int ROW_BYTES = 80;                 // 64 data + 16 pad
 constexpr int IMG_BYTES = BM * ROW_BYTES;     // one 128-row image
 
-// fp32 (R x K) -> hi, lo bf16 (R x K each); optional per-row scale applied first (x * scale[r])
+// ---- split-matrix layout ---------------------------------------------------------------------------------------
+__host__ __device__ inline int64_t split_kp(int64_t K) { return (K + 31) & ~(int64_t)31; }
+__host__ __device__ inline size_t split_elems(int64_t R, int64_t K) { return (size_t)R * 2 * (size_t)split_kp(K); }
+// position of the hi half of element (row, col); its lo half sits 32 elements further
+__host__ __device__ inline int64_t split_pos(int64_t row, int64_t col, int64_t Kp) {
+  return row * 2 * Kp + (col >> 5) * 64 + (col & 31);
+}
+__device__ inline void store_split(float v, int64_t row, int64_t col, int64_t Kp, uint16_t* __restrict__ sp) {
+  const uint16_t h = f32_to_bf16_rne(v);
+  const int64_t p = split_pos(row, col, Kp);
+  sp[p] = h;
+  sp[p + 32] = f32_to_bf16_rne(v - bf16_to_f32(h));
+}
+// four consecutive columns (col % 4 == 0): two 8-byte stores
+__device__ inline void store_split4(const float4 y, int64_t row, int64_t col, int64_t Kp, uint16_t* __restrict__ sp) {
+  const uint16_t h0 = f32_to_bf16_rne(y.x), h1 = f32_to_bf16_rne(y.y), h2 = f32_to_bf16_rne(y.z), h3 = f32_to_bf16_rne(y.w);
+  const uint16_t l0 = f32_to_bf16_rne(y.x - bf16_to_f32(h0)), l1 = f32_to_bf16_rne(y.y - bf16_to_f32(h1));
+  const uint16_t l2 = f32_to_bf16_rne(y.z - bf16_to_f32(h2)), l3 = f32_to_bf16_rne(y.w - bf16_to_f32(h3));
+  const int64_t p = split_pos(row, col, Kp);
+  *reinterpret_cast<uint2*>(sp + p) = make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16));
+  *reinterpret_cast<uint2*>(sp + p + 32) = make_uint2((uint32_t)l0 | ((uint32_t)l1 << 16), (uint32_t)l2 | ((uint32_t)l3 << 16));
+}
+
+// fp32 (R x K, row stride K) -> split matrix; optional per-row scale applied first (x * scale[r]); zero padding
 static __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, const float* __restrict__ scale,
-                                                          int64_t R, int64_t K, uint16_t* __restrict__ hi,
-                                                          uint16_t* __restrict__ lo) {
-  const int64_t n = R * K;
+                                                                int64_t R, int64_t K, uint16_t* __restrict__ sp) {
+  const int64_t Kp = split_kp(K);
+  const int64_t n = R * Kp;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    float v = x[i];
-    if (scale) v *= scale[i / K];
-    const uint16_t h = f32_to_bf16_rne(v);
-    hi[i] = h;
-    lo[i] = f32_to_bf16_rne(v - bf16_to_f32(h));
+    const int64_t r = i / Kp, c = i % Kp;
+    float v = 0.f;
+    if (c < K) {
+      v = x[r * K + c];
+      if (scale) v *= scale[r];
+    }
+    store_split(v, r, c, Kp, sp);
   }
 }
 
+// ---- kernel 1: 128 x 128 tiles staged through registers ----------------------------------------------------------
 // Epi: same contract as gemm_f32.hpp (column(col), store(row, col, acc, colval))
 #ifndef SL_G3_WAVES
 #define SL_G3_WAVES 2
 #endif
 template <class Epi>
-__global__ __launch_bounds__(256, SL_G3_WAVES) void gemm3_nt_kernel(const uint16_t* __restrict__ Ah, const uint16_t* __restrict__ Al,
-                                                        const uint16_t* __restrict__ Bh, const uint16_t* __restrict__ Bl,
-                                                        int64_t M, int64_t N, int64_t K, int tiles_n, Epi epi) {
+__global__ __launch_bounds__(256, SL_G3_WAVES) void gemm3_nt_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
+                                                                    int64_t M, int64_t N, int64_t Kp, int tiles_n, Epi epi) {
   __shared__ __align__(16) unsigned char smem[4 * IMG_BYTES];  // A_hi | A_lo | B_hi | B_lo
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -66,7 +89,6 @@ __global__ __launch_bounds__(256, SL_G3_WAVES) void gemm3_nt_kernel(const uint16
   const int tile = blockIdx.x;
   const int64_t m0 = (int64_t)(tile / tiles_n) * BM;
   const int64_t n0 = (int64_t)(tile % tiles_n) * BN;
-
 #ifdef SL_GEMM_CLOCKPROBE  // tools/native/clock_probe.hip: shader cycles vs the 100 MHz constant clock, per workgroup
   const unsigned long long probe_c0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -79,8 +101,8 @@ __global__ __launch_bounds__(256, SL_G3_WAVES) void gemm3_nt_kernel(const uint16
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // staging: an image is 128 rows x 64 bytes = 512 pieces of 16 bytes; thread t owns pieces t and t + 256
-  // (row = piece / 4, quarter = piece % 4).  Rows past the edge are clamped (never stored); K % 8 == 0.
-  const uint16_t* src[4][2];
+  // (row = piece / 4, quarter = piece % 4) of every image.  Rows past the edge are clamped (never stored).
+  const uint16_t* src[4][2];  // [A_hi | A_lo | B_hi | B_lo][piece] in the first k-tile (the lo half of a line is 32 elements in)
   int lds_off[2];
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
@@ -88,37 +110,37 @@ __global__ __launch_bounds__(256, SL_G3_WAVES) void gemm3_nt_kernel(const uint16
     const int row = piece >> 2, qt = piece & 3;
     const int64_t ar = m0 + row < M ? m0 + row : M - 1;
     const int64_t br = n0 + row < N ? n0 + row : N - 1;
-    src[0][p] = Ah + ar * SL_G3_LD(K) + qt * 8;
-    src[1][p] = Al + ar * SL_G3_LD(K) + qt * 8;
-    src[2][p] = Bh + br * SL_G3_LD(K) + qt * 8;
-    src[3][p] = Bl + br * SL_G3_LD(K) + qt * 8;
+    src[0][p] = A + ar * 2 * Kp + qt * 8;
+    src[1][p] = src[0][p] + 32;
+    src[2][p] = B + br * 2 * Kp + qt * 8;
+    src[3][p] = src[2][p] + 32;
     lds_off[p] = row * ROW_BYTES + qt * 16;
   }
-  uint4 stg[4][2];
-  auto load_tile = [&](int64_t k0) {
-    // the last K tile may be partial: K % 8 == 0, so a 16-byte piece is inside or outside as a whole
-#pragma unroll
-    for (int im = 0; im < 4; ++im)
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const int qt = (tid + p * 256) & 3;
-        if (k0 + qt * 8 < K) stg[im][p] = *reinterpret_cast<const uint4*>(src[im][p] + k0);
-        else stg[im][p] = make_uint4(0, 0, 0, 0);
-      }
-  };
-  auto load_tile_full = [&](int64_t k0) {
-#pragma unroll
-    for (int im = 0; im < 4; ++im)
-#pragma unroll
-      for (int p = 0; p < 2; ++p) stg[im][p] = *reinterpret_cast<const uint4*>(src[im][p] + k0);
-  };
-  auto stage = [&]() {
-#pragma unroll
-    for (int im = 0; im < 4; ++im)
-#pragma unroll
-      for (int p = 0; p < 2; ++p) *reinterpret_cast<uint4*>(smem + im * IMG_BYTES + lds_off[p]) = stg[im][p];
-  };
-  auto compute = [&]() {
+  // the in-flight tile: eight named 16-byte registers (as an array hipcc leaves it in scratch memory in this loop shape)
+  uint4 s00, s01, s10, s11, s20, s21, s30, s31;
+#define SL_G3_LOAD_TILE(kt)                                                  \
+  do {                                                                       \
+    s00 = *reinterpret_cast<const uint4*>(src[0][0] + (int64_t)(kt) * 64);   \
+    s01 = *reinterpret_cast<const uint4*>(src[0][1] + (int64_t)(kt) * 64);   \
+    s10 = *reinterpret_cast<const uint4*>(src[1][0] + (int64_t)(kt) * 64);   \
+    s11 = *reinterpret_cast<const uint4*>(src[1][1] + (int64_t)(kt) * 64);   \
+    s20 = *reinterpret_cast<const uint4*>(src[2][0] + (int64_t)(kt) * 64);   \
+    s21 = *reinterpret_cast<const uint4*>(src[2][1] + (int64_t)(kt) * 64);   \
+    s30 = *reinterpret_cast<const uint4*>(src[3][0] + (int64_t)(kt) * 64);   \
+    s31 = *reinterpret_cast<const uint4*>(src[3][1] + (int64_t)(kt) * 64);   \
+  } while (0)
+#define SL_G3_STAGE()                                                          \
+  do {                                                                         \
+    *reinterpret_cast<uint4*>(smem + 0 * IMG_BYTES + lds_off[0]) = s00;        \
+    *reinterpret_cast<uint4*>(smem + 0 * IMG_BYTES + lds_off[1]) = s01;        \
+    *reinterpret_cast<uint4*>(smem + 1 * IMG_BYTES + lds_off[0]) = s10;        \
+    *reinterpret_cast<uint4*>(smem + 1 * IMG_BYTES + lds_off[1]) = s11;        \
+    *reinterpret_cast<uint4*>(smem + 2 * IMG_BYTES + lds_off[0]) = s20;        \
+    *reinterpret_cast<uint4*>(smem + 2 * IMG_BYTES + lds_off[1]) = s21;        \
+    *reinterpret_cast<uint4*>(smem + 3 * IMG_BYTES + lds_off[0]) = s30;        \
+    *reinterpret_cast<uint4*>(smem + 3 * IMG_BYTES + lds_off[1]) = s31;        \
+  } while (0)
+  auto compute = [&]() __attribute__((always_inline)) {
     const unsigned char* a_base = smem + (wm * 64 + li) * ROW_BYTES + lh * 16;
     const unsigned char* b_base = smem + 2 * IMG_BYTES + (wn * 64 + li) * ROW_BYTES + lh * 16;
 #pragma unroll
@@ -143,33 +165,24 @@ __global__ __launch_bounds__(256, SL_G3_WAVES) void gemm3_nt_kernel(const uint16
     }
   };
 
-  const int nfull = (int)(K / BK);
-  const int ntiles = nfull + ((K % BK) ? 1 : 0);
+  const int ntiles = (int)(Kp / BK);
   if (ntiles > 0) {
-    if (nfull > 0) load_tile_full(0);
-    else load_tile(0);
-    stage();
+    SL_G3_LOAD_TILE(0);
+    SL_G3_STAGE();
     __syncthreads();
-    int kt = 0;
-    for (; kt + 1 < nfull; ++kt) {
-      load_tile_full((int64_t)(kt + 1) * KSTEP);  // flies during the MFMAs
+    for (int kt = 1; kt < ntiles; ++kt) {
+      SL_G3_LOAD_TILE(kt);  // flies during the MFMAs
       __builtin_amdgcn_sched_barrier(0);
       compute();
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();  // everyone done reading this stage
-      stage();
+      SL_G3_STAGE();
       __syncthreads();
-    }
-    if (kt + 1 < ntiles) {
-      load_tile((int64_t)(kt + 1) * BK);
-      compute();
-      __syncthreads();
-      stage();
-      __syncthreads();
-      ++kt;
     }
     compute();
   }
+#undef SL_G3_LOAD_TILE
+#undef SL_G3_STAGE
 
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -192,38 +205,29 @@ __global__ __launch_bounds__(256, SL_G3_WAVES) void gemm3_nt_kernel(const uint16
 #endif
 }
 
-// ---- variant 2: 256 x 128 block tile, wave tile 128 x 64, tiles staged by LDS-DMA, single buffer -------------------
+// ---- kernel 2: 256 x 128 block tile, wave tile 128 x 64, tiles staged by LDS-DMA, single buffer ---------------------
 // The register-staged kernel above spends as many LDS cycles on its ds_write_b128 staging stores as on fragment
 // reads (PMC: LDS pipe ~87 % of the MFMA time) and 32 VGPRs on the in-flight tile.  Here each wave issues twelve
 // 1-KiB LDS-DMA loads (global_load_lds_dwordx4) per tile: no VGPR staging, no ds_write.  LDS-DMA writes lane L's 16
-// bytes at base + 16 L, so an image is unpadded rows of 64 bytes; fragment reads stay conflict-free through an XOR
-// swizzle of the 16-byte slot, slot = chunk ^ ((row >> 2) & 3), applied on the SOURCE address of the DMA and on the
-// ds_read address (for every ds_read_b128 lane group the 16 (row % 4, slot) pairs are distinct).  The wave tile is
-// 128 x 64: twice the MFMA work per barrier pair and per fragment read (12 ds_read_b128 feed 24 MFMAs per k-step
-// instead of 8 feeding 12); two workgroups per CU alternate between their DMA/wait phase and their 48-MFMA phase.
-// Accumulation order per output element is the same as in the kernel above: results are bit-identical
-// (tools/g3test.py).  Measured at 10000 x 9216 x 1152: 250 -> 272 TFLOP/s algorithmic including the normalise/split
-// passes; a 128 x 128 DMA variant with double buffering and one barrier per k-step was no faster than the
-// register-staged kernel (246 vs 239) and is not kept; nor are two prefetching forms of this kernel, both slower than
-// letting two co-resident workgroups cover each other: double-buffered 32-wide stages (96 KB, one workgroup per CU:
-// 245 vs 270) and double-buffered 16-wide stages (48 KB, two per CU, twice the barriers: 230).  A 512-thread
-// "ping-pong" kernel (256 x 256 tile, two wave groups alternating between a fragment-load phase and an MFMA phase,
-// bit-identical results) was also built and measured: 284 TFLOP/s with 32-wide stages, 237 with 16-wide stages and
-// counted vmcnt waits; with its LDS-DMA switched off the same schedule runs at 907 cycles per 768-cycle MFMA phase
-// (583 TFLOP/s-equivalent), with it 1697 — the global -> LDS feed, not the MFMA / LDS schedule, is what holds all of
-// these kernels near 50 % matrix-pipe duty.  Storing hi and lo of a k-tile in one 128-byte line (whole-line DMA,
-// tools/native/fullline_probe.hip) recovers 9 % of the cycles.  Used for grids of >= 8 tiles per CU; smaller problems
-// fill the chip better with 128 x 128 tiles.
-__device__ __attribute__((aligned(16))) const uint32_t g_zero16[4] = {0, 0, 0, 0};
-
+// bytes at base + 16 L; one instruction moves 8 rows x 128 bytes, i.e. eight whole [hi | lo] lines, so an LDS image is
+// unpadded rows of 128 bytes.  Fragment reads stay conflict-free through an XOR swizzle of the 16-byte slot,
+// slot = chunk ^ ((row >> 1) & 7) (chunks 0-3 = hi, 4-7 = lo), applied on the SOURCE address of the DMA and on the
+// ds_read address: a 256-byte bank window holds two rows, and for every ds_read_b128 lane group the 8 even and the 8
+// odd rows each get 8 distinct slots.  The wave tile is 128 x 64: twice the MFMA work per barrier pair and per fragment
+// read (12 ds_read_b128 feed 24 MFMAs per k-step instead of 8 feeding 12); two workgroups per CU alternate between
+// their DMA/wait phase and their 48-MFMA phase.
+// Measured alternatives that were dropped (all bit-identical): 128 x 128 DMA tiles with double buffering (no faster than
+// kernel 1), double-buffered 32- and 16-wide stages of this kernel (slower than two co-resident workgroups covering each
+// other), a 512-thread ping-pong kernel (two wave groups alternating fragment-load and MFMA phases, raw s_barrier and
+// counted vmcnt): with its LDS-DMA switched off the schedule runs at 907 cycles per 768-cycle MFMA phase, with it
+// 1697 — the global -> LDS feed, not the MFMA / LDS schedule, holds every variant near 50 % matrix-pipe duty.
 constexpr int BM3 = 256;
-constexpr int IMG3A_BYTES = BM3 * 64, IMG3B_BYTES = BN * 64;
-constexpr int BUF3_BYTES = 2 * IMG3A_BYTES + 2 * IMG3B_BYTES;  // A_hi | A_lo | B_hi | B_lo = 48 KB
+constexpr int IMG3A_BYTES = BM3 * 128, IMG3B_BYTES = BN * 128;
+constexpr int BUF3_BYTES = IMG3A_BYTES + IMG3B_BYTES;  // A [hi | lo] rows, then B rows: 48 KB
 
 template <class Epi>
-__global__ __launch_bounds__(256, 2) void gemm3_nt_dma256_kernel(const uint16_t* __restrict__ Ah, const uint16_t* __restrict__ Al,
-                                                                 const uint16_t* __restrict__ Bh, const uint16_t* __restrict__ Bl,
-                                                                 int64_t M, int64_t N, int64_t K, int tiles_n, Epi epi) {
+__global__ __launch_bounds__(256, 2) void gemm3_nt_dma256_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
+                                                                 int64_t M, int64_t N, int64_t Kp, int tiles_n, Epi epi) {
   __shared__ __align__(1024) unsigned char smem[BUF3_BYTES];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -245,75 +249,60 @@ __global__ __launch_bounds__(256, 2) void gemm3_nt_dma256_kernel(const uint16_t*
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // DMA: wave w stages A rows [64 w, 64 w + 64) (4 loads per image) and B rows [32 w, 32 w + 32) (2 loads per image)
-  const int lrow = lane >> 2;
-  int64_t a_src[4], b_src[2];  // element offsets of this lane's chunk inside the hi/lo matrices
-  int a_chunk[4], b_chunk[2];
+  // DMA: wave w stages A rows [64 w, 64 w + 64) (8 loads of 8 rows) and B rows [32 w, 32 w + 32) (4 loads).  Lane L
+  // lands in row (L >> 3) of the load, slot L & 7, so it fetches chunk (L & 7) ^ ((row >> 1) & 7) of that row's line.
+  const int lrow = lane >> 3;
+  int64_t a_src[8], b_src[4];  // element offset of this lane's chunk in the first k-tile
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = w * 64 + i * 16 + lrow;
-    a_chunk[i] = (lane & 3) ^ ((row >> 2) & 3);
-    const int64_t ar = m0 + row < M ? m0 + row : M - 1;
-    a_src[i] = ar * SL_G3_LD(K) + a_chunk[i] * 8;
+  for (int i = 0; i < 8; ++i) {
+    const int row = w * 64 + i * 8 + lrow;
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    a_src[i] = (m0 + row < M ? m0 + row : M - 1) * 2 * Kp + chunk * 8;  // rows past the edge are clamped (never stored)
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = w * 32 + i * 16 + lrow;
-    b_chunk[i] = (lane & 3) ^ ((row >> 2) & 3);
-    const int64_t br = n0 + row < N ? n0 + row : N - 1;
-    b_src[i] = br * SL_G3_LD(K) + b_chunk[i] * 8;
+  for (int i = 0; i < 4; ++i) {
+    const int row = w * 32 + i * 8 + lrow;
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    b_src[i] = (n0 + row < N ? n0 + row : N - 1) * 2 * Kp + chunk * 8;
   }
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
-  auto dma_tile = [&](int64_t k0, bool partial) {
+  auto dma_tile = [&](int64_t kt) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool zero = partial && k0 + a_chunk[i] * 8 >= K;
-      const void* gh = zero ? (const void*)g_zero16 : (const void*)(Ah + a_src[i] + k0);
-      const void* gl = zero ? (const void*)g_zero16 : (const void*)(Al + a_src[i] + k0);
-      unsigned char* l = smem + (w * 64 + i * 16) * 64;
-      __builtin_amdgcn_global_load_lds((glb_void*)gh, (lds_void*)l, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_void*)gl, (lds_void*)(l + IMG3A_BYTES), 16, 0, 0);
-    }
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void*)(A + a_src[i] + kt * 64), (lds_void*)(smem + (w * 64 + i * 8) * 128), 16, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const bool zero = partial && k0 + b_chunk[i] * 8 >= K;
-      const void* gh = zero ? (const void*)g_zero16 : (const void*)(Bh + b_src[i] + k0);
-      const void* gl = zero ? (const void*)g_zero16 : (const void*)(Bl + b_src[i] + k0);
-      unsigned char* l = smem + 2 * IMG3A_BYTES + (w * 32 + i * 16) * 64;
-      __builtin_amdgcn_global_load_lds((glb_void*)gh, (lds_void*)l, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_void*)gl, (lds_void*)(l + IMG3B_BYTES), 16, 0, 0);
-    }
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void*)(B + b_src[i] + kt * 64),
+                                       (lds_void*)(smem + IMG3A_BYTES + (w * 32 + i * 8) * 128), 16, 0, 0);
   };
   int a_off[4], a_sw[4], b_off[2], b_sw[2];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int ar = wm * 128 + t * 32 + li;
-    a_off[t] = ar * 64;
-    a_sw[t] = (ar >> 2) & 3;
+    a_off[t] = ar * 128;
+    a_sw[t] = (ar >> 1) & 7;
   }
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int br = wn * 64 + t * 32 + li;
-    b_off[t] = 2 * IMG3A_BYTES + br * 64;
-    b_sw[t] = (br >> 2) & 3;
+    b_off[t] = IMG3A_BYTES + br * 128;
+    b_sw[t] = (br >> 1) & 7;
   }
-  auto compute = [&]() {
+  auto compute = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const int c = ks * 2 + lh;
+      const int c = ks * 2 + lh;  // hi chunk of this lane's k-group; its lo chunk is 4 + c
       bf16x8 ah[4], al[4], bh[2], bl[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const int bo = b_off[t] + ((c ^ b_sw[t]) << 4);
-        bh[t] = *reinterpret_cast<const bf16x8*>(smem + bo);
-        bl[t] = *reinterpret_cast<const bf16x8*>(smem + IMG3B_BYTES + bo);
+        bh[t] = *reinterpret_cast<const bf16x8*>(smem + b_off[t] + ((c ^ b_sw[t]) << 4));
+        bl[t] = *reinterpret_cast<const bf16x8*>(smem + b_off[t] + (((4 + c) ^ b_sw[t]) << 4));
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const int ao = a_off[t] + ((c ^ a_sw[t]) << 4);
-        ah[t] = *reinterpret_cast<const bf16x8*>(smem + ao);
-        al[t] = *reinterpret_cast<const bf16x8*>(smem + IMG3A_BYTES + ao);
+        ah[t] = *reinterpret_cast<const bf16x8*>(smem + a_off[t] + ((c ^ a_sw[t]) << 4));
+        al[t] = *reinterpret_cast<const bf16x8*>(smem + a_off[t] + (((4 + c) ^ a_sw[t]) << 4));
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -326,10 +315,9 @@ __global__ __launch_bounds__(256, 2) void gemm3_nt_dma256_kernel(const uint16_t*
     }
   };
 
-  const int ntiles = (int)((K + BK - 1) / BK);
-  const bool tail = (K % BK) != 0;
+  const int ntiles = (int)(Kp / BK);
   for (int kt = 0; kt < ntiles; ++kt) {
-    dma_tile((int64_t)kt * KSTEP, tail && kt + 1 == ntiles);
+    dma_tile(kt);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // the tile has landed for every wave
     compute();
@@ -357,23 +345,24 @@ __global__ __launch_bounds__(256, 2) void gemm3_nt_dma256_kernel(const uint16_t*
 #endif
 }
 
-inline int launch_split(const float* x, const float* scale, int64_t R, int64_t K, uint16_t* hi, uint16_t* lo, hipStream_t st) {
-  int64_t blocks = (R * K + 255) / 256;
+inline int launch_split(const float* x, const float* scale, int64_t R, int64_t K, uint16_t* sp, hipStream_t st) {
+  int64_t blocks = (R * split_kp(K) + 255) / 256;
   const int64_t cap = (int64_t)num_cus() * 16;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, scale, R, K, hi, lo);
+  hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, scale, R, K, sp);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
+// A (M rows), B (N rows): split matrices of K columns (layout above)
 template <class Epi>
-int launch_gemm3_nt(ProfScope& prof, const uint16_t* Ah, const uint16_t* Al, int64_t M, const uint16_t* Bh,
-                    const uint16_t* Bl, int64_t N, int64_t K, const Epi& epi, hipStream_t st) {
+int launch_gemm3_nt(ProfScope& prof, const uint16_t* A, int64_t M, const uint16_t* B, int64_t N, int64_t K, const Epi& epi,
+                    hipStream_t st) {
   const int64_t tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
   SL_REQUIRE(tm * tn < (1ll << 31), "GEMM: too many tiles");
-  SL_REQUIRE(K % 8 == 0, "bf16x3 GEMM: K must be a multiple of 8");
   if (tm * tn == 0) return 0;
+  const int64_t Kp = split_kp(K);
   static const int forced = [] {
     const char* e = getenv("SL_G3_TILE");  // 128: register-staged 128 x 128 tiles, 256: LDS-DMA staged 256 x 128 tiles
     return e ? atoi(e) : 0;
@@ -381,9 +370,9 @@ int launch_gemm3_nt(ProfScope& prof, const uint16_t* Ah, const uint16_t* Al, int
   const int64_t tm3 = (M + BM3 - 1) / BM3;
   const bool big = forced ? forced == 256 : tm3 * tn >= (int64_t)8 * num_cus();
   if (big)
-    SL_LAUNCH(prof, (gemm3_nt_dma256_kernel<Epi>), dim3((unsigned)(tm3 * tn)), dim3(256), 0, st, Ah, Al, Bh, Bl, M, N, K, (int)tn, epi);
+    SL_LAUNCH(prof, (gemm3_nt_dma256_kernel<Epi>), dim3((unsigned)(tm3 * tn)), dim3(256), 0, st, A, B, M, N, Kp, (int)tn, epi);
   else
-    SL_LAUNCH(prof, (gemm3_nt_kernel<Epi>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, Ah, Al, Bh, Bl, M, N, K, (int)tn, epi);
+    SL_LAUNCH(prof, (gemm3_nt_kernel<Epi>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, A, B, M, N, Kp, (int)tn, epi);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
 }

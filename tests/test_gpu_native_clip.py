@@ -51,7 +51,14 @@ def test_primitives_against_torch():
     # split-bf16 operands: hi + lo reconstructs the value to ~2^-17, and the bf16x3 GEMM matches fp32 results
     sp = N.Split.of(x)
     assert ((sp.hi.float() + sp.lo.float()) - x).abs().max().item() <= 2.0 ** -16 * x.abs().max().item()
+    # layout: rows of 2 Kp values, each 32-wide k-tile = one 128-byte line [hi32 | lo32], zero padding up to Kp = 224
+    assert sp.buf.shape == (300, 2 * 224) and sp.buf.view(300, 7, 2, 32)[:, 6, :, 8:].float().abs().max().item() == 0.0
+    hi_ref = x.to(torch.bfloat16)
+    assert torch.equal(sp.hi, hi_ref) and torch.equal(sp.lo, (x - hi_ref.float()).to(torch.bfloat16))
     ws = N.Split.of(w)
+    # any K works now (padding is part of the format): K = 100 is not even a multiple of 8
+    xa, wa = torch.randn(70, 100, device=DEV, generator=g), torch.randn(33, 100, device=DEV, generator=g)
+    assert rel_err(N.linear3(N.Split.of(xa), N.Split.of(wa)), xa @ wa.T) < 1e-5
     assert rel_err(N.linear3(sp, ws, b), ref) < 1e-5
     assert rel_err(N.linear3(sp, ws, b, act=N.SL_ACT_GELU), torch.nn.functional.gelu(ref)) < 1e-5
     out = r.clone()

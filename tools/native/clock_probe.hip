@@ -24,33 +24,23 @@ struct ProbeEpi {
 
 
 static double run(bool zero, bool f32mode, int64_t M, int64_t N, int64_t K) {
-  std::vector<uint16_t> h((size_t)std::max(M, N) * K);
+  // split matrices: rows of 2 K bf16 ([hi32 | lo32] per k-tile); random bit patterns stand in for real operands
+  std::vector<uint16_t> h((size_t)std::max(M, N) * K * 2);
   std::vector<float> hf((size_t)std::max(M, N) * K);
   srand(1);
   for (auto& v : h) v = zero ? 0 : (uint16_t)(0x3c00 + (rand() & 0x3ff) + ((rand() & 1) << 15));
   for (auto& v : hf) v = zero ? 0.f : (float)rand() / RAND_MAX - 0.5f;
-  uint16_t *Ah, *Al, *Bh, *Bl; float *Af, *Bf, *out; unsigned long long* st;
-#ifdef SL_G3_LAYOUT_EXPERIMENT  // hi and lo of a k-tile in one 128-byte line: one buffer of 2 K per row, lo = hi + 32
-  hipMalloc(&Ah, M * K * 4 + 256); hipMalloc(&Bh, N * K * 4 + 256);
-  Al = Ah + 32; Bl = Bh + 32;
-#else
-  hipMalloc(&Ah, M * K * 2); hipMalloc(&Al, M * K * 2); hipMalloc(&Bh, N * K * 2); hipMalloc(&Bl, N * K * 2);
-#endif
+  uint16_t *As, *Bs; float *Af, *Bf, *out; unsigned long long* st;
+  hipMalloc(&As, M * K * 4); hipMalloc(&Bs, N * K * 4);
   hipMalloc(&Af, M * K * 4); hipMalloc(&Bf, N * K * 4);
   hipMalloc(&out, M * N * 4); hipMalloc(&st, 16 * 65536);
-#ifdef SL_G3_LAYOUT_EXPERIMENT
-  hipMemcpy(Ah, h.data(), M * K * 2, hipMemcpyHostToDevice); hipMemcpy(Ah + M * K, h.data(), M * K * 2, hipMemcpyHostToDevice);
-  hipMemcpy(Bh, h.data(), N * K * 2, hipMemcpyHostToDevice); hipMemcpy(Bh + N * K, h.data(), N * K * 2, hipMemcpyHostToDevice);
-#else
-  hipMemcpy(Ah, h.data(), M * K * 2, hipMemcpyHostToDevice); hipMemcpy(Al, h.data(), M * K * 2, hipMemcpyHostToDevice);
-  hipMemcpy(Bh, h.data(), N * K * 2, hipMemcpyHostToDevice); hipMemcpy(Bl, h.data(), N * K * 2, hipMemcpyHostToDevice);
-#endif
+  hipMemcpy(As, h.data(), M * K * 4, hipMemcpyHostToDevice); hipMemcpy(Bs, h.data(), N * K * 4, hipMemcpyHostToDevice);
   hipMemcpy(Af, hf.data(), M * K * 4, hipMemcpyHostToDevice); hipMemcpy(Bf, hf.data(), N * K * 4, hipMemcpyHostToDevice);
   ProbeEpi epi{out, N, st};
   sl::ProfScope prof(-1, nullptr, 0.0);
   auto go = [&]() {
     if (f32mode) sl::gemm::launch_gemm_nt(prof, Af, M, Bf, N, K, epi, nullptr);
-    else sl::gemm3::launch_gemm3_nt(prof, Ah, Al, M, Bh, Bl, N, K, epi, nullptr);
+    else sl::gemm3::launch_gemm3_nt(prof, As, M, Bs, N, K, epi, nullptr);
   };
   for (int i = 0; i < 5; ++i) go();
   hipDeviceSynchronize();
@@ -70,15 +60,10 @@ static double run(bool zero, bool f32mode, int64_t M, int64_t N, int64_t K) {
   const double real = ms * 1e-3;
   const double tf = 2.0 * M * N * K * reps / real / 1e12;
   printf("  per-workgroup: %.0f shader cycles, %.2f us  ", cyc / nblk, rt / nblk / 100.0);
-  cyc = cyc; rt = rt / 100e6;
+  rt = rt / 100e6;
   printf("%s %s: %.3f ms/launch, %.1f TFLOP/s algorithmic, shader clock %.0f MHz\n", f32mode ? "f32-mfma" : "bf16x3  ",
          zero ? "zeros " : "random", real / reps * 1e3, tf, cyc / rt / 1e6);
-#ifdef SL_G3_LAYOUT_EXPERIMENT
-  hipFree(Ah); hipFree(Bh);
-#else
-  hipFree(Ah); hipFree(Al); hipFree(Bh); hipFree(Bl);
-#endif
-  hipFree(Af); hipFree(Bf); hipFree(out); hipFree(st);
+  hipFree(As); hipFree(Bs); hipFree(Af); hipFree(Bf); hipFree(out); hipFree(st);
   return tf;
 }
 
