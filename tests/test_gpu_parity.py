@@ -555,9 +555,10 @@ torch.save(outs, sys.argv[1])
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for tile in ("128", "256"):
+    for tile in ("128", "256", "512"):
         out = tmp_path / f"g3_{tile}.pt"
         subprocess.run([sys.executable, "-c", code, str(out), root], check=True, env=dict(os.environ, SL_G3_TILE=tile))
         res[tile] = torch.load(out)
-    for a, b in zip(res["128"], res["256"]):
-        assert torch.equal(a, b), tuple(a.shape)
+    for other in ("256", "512"):
+        for a, b in zip(res["128"], res[other]):
+            assert torch.equal(a, b), (other, tuple(a.shape))

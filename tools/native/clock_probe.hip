@@ -53,7 +53,7 @@ static double run(bool zero, bool f32mode, int64_t M, int64_t N, int64_t K) {
   float ms = 0; hipEventElapsedTime(&ms, e0, e1);
   const char* tile_env = getenv("SL_G3_TILE");
   const int tile_sel = (!f32mode && tile_env) ? atoi(tile_env) : 128;
-  const int64_t nblk = tile_sel == 256 ? ((M + 255) / 256) * ((N + 127) / 128) : ((M + 127) / 128) * ((N + 127) / 128);
+  const int64_t nblk = tile_sel == 512 ? ((M + 255) / 256) * ((N + 255) / 256) : tile_sel == 256 ? ((M + 255) / 256) * ((N + 127) / 128) : ((M + 127) / 128) * ((N + 127) / 128);
   std::vector<unsigned long long> hs(2 * nblk); hipMemcpy(hs.data(), st, 16 * nblk, hipMemcpyDeviceToHost);
   double cyc = 0, rt = 0;
   for (int64_t b = 0; b < nblk; ++b) { cyc += (double)hs[2 * b]; rt += (double)hs[2 * b + 1]; }
