@@ -555,3 +555,41 @@ def test_denormalization_transform_inverts_normalisation():
     assert torch.allclose(den(norm), img, atol=1e-6)
     assert torch.allclose(den(norm[None].repeat(2, 1, 1, 1)), img[None].repeat(2, 1, 1, 1), atol=1e-6)
     assert torch.allclose(get_denormalization_transform([0.5] * 3, [0.25] * 3)(torch.zeros(3, 2, 2)), torch.full((3, 2, 2), 0.5))
+
+
+# ---- utils.log_setup (reference tests/test_log_setup.py) ------------------------------------------------------------
+def test_setup_colored_logging_levels_env_and_file(monkeypatch, tmp_path, caplog):
+    import logging
+
+    from semanticlens_amd.utils import setup_colored_logging
+    from semanticlens_amd.utils.log_setup import PACKAGE, ColorFormatter
+
+    logger = logging.getLogger(PACKAGE)
+    monkeypatch.delenv("SEMANTICLENS_LOG_LEVEL", raising=False)
+    setup_colored_logging()
+    assert logger.level == logging.INFO
+    with caplog.at_level(logging.INFO, logger=PACKAGE):
+        logger.debug("hidden")
+        logger.info("shown")
+    assert "shown" in caplog.text and "hidden" not in caplog.text
+    setup_colored_logging(log_level="DEBUG")
+    assert logger.level == logging.DEBUG and len(logger.handlers) == 1  # handlers are replaced, not stacked
+    monkeypatch.setenv("SEMANTICLENS_LOG_LEVEL", "WARNING")
+    setup_colored_logging()  # the environment variable wins over the argument
+    assert logger.level == logging.WARNING
+    monkeypatch.delenv("SEMANTICLENS_LOG_LEVEL")
+    log_file = tmp_path / "test.log"
+    setup_colored_logging(file_path=str(log_file))
+    logger.warning("to the file")
+    for h in logger.handlers:
+        h.flush()
+    assert "to the file" in log_file.read_text() and "\\033[" not in log_file.read_text()
+    rec = logging.LogRecord("t", logging.WARNING, "/fake/path.py", 10, "A test warning", (), None)
+    out = ColorFormatter("[%(levelname)s]: %(message)s", use_color=True).format(rec)
+    assert out.startswith(ColorFormatter.COLOR_MAP["WARNING"]) and out.endswith(ColorFormatter.RESET_SEQ) and rec.short_filename == "path.py"
+    assert ColorFormatter("[%(levelname)s]: %(message)s", use_color=False).format(rec) == "[WARNING]: A test warning"
+    setup_colored_logging("nonsense")
+    assert logger.level == logging.INFO
+    for h in list(logger.handlers):
+        logger.removeHandler(h)
+    logger.addHandler(logging.NullHandler())
