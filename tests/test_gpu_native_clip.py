@@ -165,3 +165,25 @@ def test_layernorm_paths(cols):
     sp = N.layernorm(x, gam, bet, 1e-5, out_split=N.Split(77, cols, DEV))
     assert rel_err(sp.hi.float() + sp.lo.float(), want) < 1e-5
     assert rel_err(N.layernorm(x, gam, bet, 1e-5, rows=16, x_row_stride=5 * cols), want[::5]) < 1e-5
+
+
+def test_linear3_random_shapes_against_fp64():
+    """Packed split operands + bf16x3 GEMM on ragged shapes (K not a multiple of 32 / 8, single rows, tile edges),
+    with bias, against an fp64 matmul; also through the split-output form."""
+    rng = np.random.default_rng(123)
+    g = torch.Generator(device=DEV).manual_seed(123)
+    shapes = [(1, 1, 1), (1, 7, 33), (129, 127, 31), (255, 257, 95), (300, 130, 200), (64, 512, 1152), (513, 260, 72)]
+    shapes += [tuple(int(v) for v in rng.integers(1, 400, 3)) for _ in range(12)]
+    for M, Nn, K in shapes:
+        x = torch.randn(M, K, device=DEV, generator=g)
+        w = torch.randn(Nn, K, device=DEV, generator=g)
+        b = torch.randn(Nn, device=DEV, generator=g)
+        ref = (x.double() @ w.double().T + b.double())
+        # three-product split: ~2^-16 relative per product, random signs -> ~2^-16 sqrt(K) absolute for unit-variance data
+        tol = 8 * 2.0 ** -16 * K ** 0.5 + 1e-6
+        got = N.linear3(N.Split.of(x), N.Split.of(w), b)
+        assert (got.double() - ref).abs().max().item() < tol, (M, Nn, K)
+        sp = N.linear3(N.Split.of(x), N.Split.of(w), b, out_split=N.Split(M, Nn, DEV))
+        assert ((sp.hi.float() + sp.lo.float()).double() - ref).abs().max().item() < tol + 2.0 ** -15 * ref.abs().max().item(), (M, Nn, K)
+        if sp.kp != Nn:  # the padding of a split output stays zero (the next GEMM reads it)
+            assert sp.buf.view(M, sp.kp // 32, 2, 32)[:, -1, :, Nn % 32:].float().abs().max().item() == 0.0
