@@ -57,6 +57,16 @@ def parse():
                     help="run the CLIP embed of each batch on the same HIP stream as forward + collect (default: a second "
                          "stream, +6 %% images/s; K1 then shares HBM with the encoder: in-bench roofline fraction 0.737 vs 0.75)")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (exhaustive MIOpen search)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --steps batches PER RANK (the driver's contract); strong: --images samples in TOTAL, sharded "
+                         "over the ranks by distributed.shard_range (north_star: 1.28 M images, >= 6x at 8 GPUs)")
+    ap.add_argument("--images", type=int, default=0, help="--scaling strong: total dataset size (default steps x batch)")
+    ap.add_argument("--pool-batches", type=int, default=0,
+                    help="keep only this many distinct batches resident and cycle through them (ids stay unique); 0 = every "
+                         "batch distinct.  For dataset sizes whose uint8 pixels exceed HBM (1.28 M images = 193 GB)")
+    ap.add_argument("--no-self-check", action="store_true")
+    ap.add_argument("--no-api-leg", action="store_true")
+    ap.add_argument("--api-images", type=int, default=2048, help="raw 500x375 images of the API-path leg")
     return ap.parse_args()
 
 
@@ -111,6 +121,108 @@ def finish_job(cv, embeds, id_start, n_total, world):
         sld.merge_actmax_cache(cv.actmax_cache)
         return {n: sld.gather_concept_db_sharded(embeds, id_start, n_total, cv.get_max_reference(n)) for n in LAYERS}
     return {n: N.gather_rows(embeds, cv.actmax_cache.cache[n].device_state()[1]) for n in LAYERS}
+
+
+@torch.no_grad()
+def self_check(dev, model, fm, args, n=192, B=64):
+    """What the timed region computes, checked against the oracle on a 192-image prefix (ids 0..191, three batches of
+    64 so that queued merges are exercised): the SAME device activations go through (i) the product's hooks
+    (K1 reduce + K3 merge, the tie mode of the timed run) and (ii) the oracle's aggregate + ActMax restatement on the
+    host; top-k values and ids must be bit-equal, and the gathered concept_db (K5) must equal the oracle's gather of
+    the device embeddings.  Raises on any difference."""
+    import numpy as np
+
+    import oracle  # the checker — never on the product path
+
+    cv = make_cv(model, n, args.k, args.tie_mode)
+    raw = {name: [] for name in LAYERS}
+    taps = [getattr(model, name).register_forward_hook(lambda m, i, o, name=name: raw[name].append(o.detach().cpu().numpy()))
+            for name in LAYERS]
+    batches = [synth.synth_images_u8(torch.arange(s, s + B, device=dev)) for s in range(0, n, B)]
+    try:
+        embeds = run_steps(cv, fm, batches, 0, n)
+    finally:
+        for h in taps:
+            h.remove()
+    db = finish_job(cv, embeds, 0, n, 1)
+    torch.cuda.synchronize()
+    mode = oracle.MODE_TOTAL if args.tie_mode == "total" else oracle.MODE_ATEN
+    emb_host = embeds.cpu().numpy()
+    for name in LAYERS:
+        ref = None
+        for step, act in enumerate(raw[name]):
+            a = oracle.agg_conv(act, "max")
+            if ref is None:
+                ref = oracle.ActMaxOracle(args.k, a.shape[1], mode)
+            ref.update(a, np.arange(step * B, step * B + a.shape[0]))
+        am = cv.actmax_cache.cache[name]
+        got_v = am.activations.view(torch.int16).numpy().view(np.uint16)
+        if not np.array_equal(got_v, ref.vals):
+            raise AssertionError(f"self-check: top-k values of {name} differ from the oracle")
+        if not np.array_equal(am.sample_ids.numpy(), ref.ids):
+            raise AssertionError(f"self-check: top-k ids of {name} differ from the oracle")
+        if not np.array_equal(db[name].cpu().numpy(), oracle.gather_rows(emb_host, ref.ids)):
+            raise AssertionError(f"self-check: concept_db of {name} differs from the oracle's gather")
+    return "ok"
+
+
+class _Rows(torch.utils.data.Dataset):
+    """In-memory dataset over the first axis of a host tensor (what a user's Dataset hands the reference's loops)."""
+
+    def __init__(self, x, name, with_label):
+        self.x, self.name, self.with_label = x, name, with_label
+
+    def __len__(self):
+        return self.x.shape[0]
+
+    def __getitem__(self, i):
+        return (self.x[i], 0) if self.with_label else self.x[i]
+
+
+@torch.no_grad()
+def api_path_leg(dev, model, fm_base, args):
+    """The path a user runs (activation_based.py:341-433 through `Lens.compute_concept_db`): two host-resident
+    `Dataset`s — normalised 224x224 fp32 samples for the probed model, RAW 500x375 uint8 images for the foundation
+    model — walked by torch DataLoaders, `NativeClip(preprocess=DevicePreprocess(224))` doing resize / crop / normalise
+    on the device (K12), `single_pass=True`, default tie mode ("aten": bit-identical to the reference).  PCIe- and
+    DataLoader-inclusive; never the headline `value`."""
+    from semanticlens_amd.foundation_models import DevicePreprocess
+    from semanticlens_amd.foundation_models.native_clip import NativeClip
+
+    n, B, h, w = args.api_images, args.batch, 375, 500
+    g = torch.Generator(device=dev).manual_seed(5)
+    raw = torch.empty((n, h, w, 3), dtype=torch.uint8)
+    norm = torch.empty((n, 3, 224, 224), dtype=torch.float32)
+    to_model = DevicePreprocess(224, synth.IMAGENET_MEAN, synth.IMAGENET_STD, device=dev)
+    for s in range(0, n, B):
+        e = min(n, s + B)
+        # smooth low-frequency content + noise, so the resample is not a no-op
+        base = torch.rand((e - s, 12, 16, 3), device=dev, generator=g).permute(0, 3, 1, 2)
+        img = torch.nn.functional.interpolate(base, size=(h, w), mode="bilinear", align_corners=False)
+        img = (img * 200 + 55 * torch.rand((e - s, 3, h, w), device=dev, generator=g)).clamp_(0, 255).to(torch.uint8)
+        u8 = img.permute(0, 2, 3, 1).contiguous()
+        raw[s:e] = u8.cpu()
+        norm[s:e] = to_model(u8).cpu()
+    fm = NativeClip(fm_base, gemm="bf16x3", preprocess=DevicePreprocess(224, synth.CLIP_MEAN, synth.CLIP_STD))
+    lens = Lens(fm, device=dev)
+
+    def build(n_use):
+        cv = ActivationComponentVisualizer(
+            model, _Rows(norm[:n_use], f"api-{n_use}", True), _Rows(raw[:n_use].numpy(), "api-fm", False), LAYERS,
+            num_samples=args.k, aggregate_fn=aggregators.aggregate_conv_max, cache_dir=None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        db = lens.compute_concept_db(cv, batch_size=B, single_pass=True)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, db
+
+    build(min(n, 2 * B))  # warm-up
+    dt, db = build(n)
+    assert all(v.shape == (c, args.k, 512) for v, c in zip(db.values(), (512, 1024, 2048)))
+    return {"api_path_images_per_s": n / dt, "images": n, "seconds": dt,
+            "workload": f"Lens.compute_concept_db(cv, batch_size={B}, single_pass=True): host Datasets ({n} normalised "
+                        f"224x224 fp32 samples + raw {w}x{h} uint8 images), DataLoader num_workers=0, device preprocessing "
+                        "(K12), tie_mode='aten', concept_db returned on the host"}
 
 
 def cpu_baseline(args, model_cpu, fm_cpu):
@@ -249,7 +361,7 @@ def probing_leg(dev):
         # matrix cores actually issue.
         "roofline": {"bound": "mfma", "achieved": fl3 / ms3 / 1e9, "peak": MFMA_BF16_PEAK_TFLOPS / 3, "unit": "TFLOP/s",
                      "frac": (fl3 / ms3 / 1e9) / (MFMA_BF16_PEAK_TFLOPS / 3),
-                     "kernel": "gemm3_nt_dma256 (split-bf16 x3 on v_mfma_f32_32x32x16_bf16, 256x128 tiles staged by LDS-DMA, all 12 layers in one launch; fp32-class accuracy)",
+                     "kernel": "gemm3_nt_8phase (split-bf16 x3 on v_mfma_f32_32x32x16_bf16, 256x256 tiles, two staggered wave groups, 16-KB LDS-DMA pieces six ahead, all 12 layers in one launch; fp32-class accuracy)",
                      "mfma_flops_issued_TFLOPs": 3 * fl3 / ms3 / 1e9,
                      "ratio_to_fp32_mfma_peak": (fl3 / ms3 / 1e9) / MFMA_F32_PEAK_TFLOPS,
                      "launches": n3, "avg_ms": ms3 / max(n3, 1)},
@@ -287,15 +399,22 @@ def main():
     OVERLAP = bool(args.overlap)
 
     B, K, W = args.batch, args.steps, args.warmup
-    n_local = K * B
-    n_total = world * n_local
-    id_start = rank * n_local
+    if args.scaling == "strong":  # fixed TOTAL work, contiguous shards (distributed.shard_range), ids global
+        n_total = args.images or K * B
+        id_start, id_stop = sld.shard_range(n_total, rank, world)
+        n_local = id_stop - id_start
+        K = -(-n_local // B)
+    else:  # weak (the driver's contract): K batches per rank
+        n_local = K * B
+        n_total = world * n_local
+        id_start = rank * n_local
     model = synth.resnet50().to(dev)
-    fm = synth.SyntheticClip(device=dev)
+    fm_base = synth.SyntheticClip(device=dev)
+    fm = fm_base
     if args.fm != "torch":
         from semanticlens_amd.foundation_models.native_clip import NativeClip
 
-        fm = NativeClip(fm, gemm="bf16x3" if args.fm == "native" else "f32")
+        fm = NativeClip(fm_base, gemm="bf16x3" if args.fm == "native" else "f32")
     Lens(fm, device=dev)
 
     # ---- warm-up on throw-away state (MIOpen kernel selection, allocator, lazy kernel loads) ----
@@ -308,20 +427,34 @@ def main():
         del warm, emb_w, warm_cv
 
     # ---- inputs resident in HBM before the clock starts ------------------------------------------
-    batches = [synth.synth_images_u8(torch.arange(id_start + s * B, id_start + (s + 1) * B, device=dev)) for s in range(K)]
-    cv = make_cv(model, n_total, args.k, args.tie_mode)
-    N.prof_enable(True)
-    N.prof_reset()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    embeds = run_steps(cv, fm, batches, id_start, n_local)
-    concept_db = finish_job(cv, embeds, id_start, n_total, world)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    def batch_ids(s):
+        return torch.arange(id_start + s * B, min(id_start + (s + 1) * B, id_start + n_local), device=dev)
+
+    pool = args.pool_batches if 0 < args.pool_batches < K else K
+    distinct = [synth.synth_images_u8(batch_ids(s)) for s in range(pool)]
+    if pool < K:  # cycle the resident pool; the last (possibly short) batch keeps its own size
+        batches = [distinct[s % pool][: batch_ids(s).numel()] for s in range(K)]
+    else:
+        batches = distinct
+
+    assert n_local > 0, "every rank needs at least one sample (--images >= --gpus)"
+
+    def timed_job(fm_used, batches, n_total, n_local):
+        cv_ = make_cv(model, n_total, args.k, args.tie_mode)
+        N.prof_enable(True)
+        N.prof_reset()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0_ = time.perf_counter()
+        embeds_ = run_steps(cv_, fm_used, batches, id_start, n_local)
+        db_ = finish_job(cv_, embeds_, id_start, n_total, world)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        return time.perf_counter() - t0_, db_
+
+    elapsed, concept_db = timed_job(fm, batches, n_total, n_local)
     red_ms, red_n, red_bytes = N.prof_read(N.SL_PROF_REDUCE)
     mrg_ms, mrg_n, _ = N.prof_read(N.SL_PROF_MERGE)
     gat_ms, gat_n, _ = N.prof_read(N.SL_PROF_GATHER)
@@ -331,6 +464,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert all(v.shape == (c, args.k, 512) for v, c in zip(concept_db.values(), (512, 1024, 2048)))
+    del concept_db
 
     if rank != 0:
         if world > 1:
@@ -345,6 +479,8 @@ def main():
         except Exception:
             traffic = None
     achieved = red_bytes / red_ms / 1e6 if red_ms else None
+    gemm_note = {"native": "split-bf16 x3 on the bf16 matrix cores, fp32 accumulate (fp32-class accuracy, 1e-6 on cosines)",
+                 "native-f32": "fp32-input MFMA", "torch": "hipBLASLt fp32"}[args.fm]
     line = {
         "metric": "images/sec concept-db build",
         "value": n_total / elapsed,
@@ -354,25 +490,38 @@ def main():
         "warmup": W,
         "ms_per_step": elapsed / K * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
             "workload": "BASELINE configs[1]: ResNet-50 (random init) layer2-4, synthetic 224x224 images, "
                         "CLIP ViT-B/32 (random init) embed, aggregate_conv_max",
-            "images_per_gpu": n_local, "batch": B, "num_samples_k": args.k, "tie_mode": args.tie_mode,
+            "images_total": n_total, "images_per_gpu": n_local, "batch": B, "num_samples_k": args.k,
+            # configs[1] names 50k images: fewer steps measure the same per-step rate on a smaller embedding table and a
+            # top-k filter that has not reached its steady-state rejection rate
+            "full_config_size": n_total >= 50000,
+            "distinct_resident_batches": pool,
+            "tie_mode": args.tie_mode,
             "streams": 2 if args.overlap else 1, "layers": LAYERS, "parallelism": f"shard{world}" if world > 1 else "single",
+            "collectives": "torch.distributed (RCCL): one all_gather_into_tensor of the packed top-k states + one "
+                           "all_reduce per layer of the sharded gather" if world > 1 else "none",
             "clip_encoder": {"native": "NativeClip (HIP kernels, split-bf16 x3 GEMMs, fp32-class accuracy)",
                              "native-f32": "NativeClip (HIP kernels, fp32-input MFMA GEMMs)",
                              "torch": "torch module (hipBLASLt fp32)"}[args.fm],
+            "arithmetic": {"collect (K1/K3)": "fp32 max -> bf16 RNE candidates, exact", "probed model": "fp32 (PyTorch/MIOpen)",
+                           "encoder GEMMs": gemm_note},
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS if achieved else None, "traffic": traffic,
+            # `traffic` is NOT measured in this run: PMC counters need their own rocprofv3 passes (tools/pmc_traffic.py)
+            "traffic_source": "profiles/roofline_traffic.json (separate rocprofv3 --pmc passes of this command)" if traffic else None,
             "kernel": "rowreduce (K1, activation spatial-max -> bf16 candidates)",
             "launches": red_n, "avg_launch_us": red_ms / max(red_n, 1) * 1e3,
             "algorithmic_bytes_per_launch": red_bytes / max(red_n, 1),
+            "condition": "in-pipeline: inputs written by the model's last kernel microseconds earlier, encoder running on "
+                         "a second stream" if args.overlap else "in-pipeline, single stream",
         },
         "kernel_time_share": {
             "reduce_ms": red_ms, "merge_ms": mrg_ms, "merge_launches": mrg_n, "gather_ms": gat_ms,
@@ -380,6 +529,20 @@ def main():
             "collect_only_images_per_sec": n_local / ((red_ms + mrg_ms) / 1e3) if red_ms else None,
         },
     }
+    if world == 1 and not args.no_self_check:
+        line["self_check"] = self_check(dev, model, fm, args)
+    if world == 1 and args.fm == "native":
+        # the same job with every encoder GEMM on the fp32-input MFMA path (strict fp32 arithmetic end to end)
+        from semanticlens_amd.foundation_models.native_clip import NativeClip
+
+        few = batches[: min(K, 24)]
+        n_few = sum(b.shape[0] for b in few)
+        dt32, _ = timed_job(NativeClip(fm_base, gemm="f32"), few, n_few, n_few)
+        N.prof_enable(False)
+        line["images_per_s_fp32_gemm"] = {"value": n_few / dt32, "steps": len(few),
+                                          "note": "same step with NativeClip(gemm='f32'): no bf16 operand anywhere"}
+    if world == 1 and not args.no_api_leg:
+        line["api_path"] = api_path_leg(dev, model, fm_base, args)
     if world == 1 and not args.no_probing:
         line["text_probing"] = probing_leg(dev)
         line["text_probing"]["from_prompts"] = probing_end_to_end(fm, dev)

@@ -181,7 +181,7 @@ def template_mean(E, E0, Q: int) -> np.ndarray:
     return out
 
 
-def polysemanticity(V, random_state: int = 123, n_clusters: int = 2) -> np.ndarray:
+def polysemanticity(V, random_state: int = 123, n_clusters: int = 2, return_fallback: bool = False):
     """polysemanticity_score — scores.py:131-185.
 
     The clustering itself lives in a third-party dependency of the reference
@@ -211,6 +211,8 @@ def polysemanticity(V, random_state: int = 123, n_clusters: int = 2) -> np.ndarr
         for i in range(ns):  # scores.py:182-183
             acc += clarity(np.stack([v_not.mean(1), v_not[:, i]], axis=1))
         poly[bad] = 1.0 - acc.astype(np.float64) / ns
+    if return_fallback:  # which rows took the fp32 fallback branch (scores.py:178-184) — tests classify by it
+        return poly, bad
     return poly
 
 

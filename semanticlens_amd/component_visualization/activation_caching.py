@@ -359,62 +359,67 @@ class ActMaxCache(ActCache):
             layer_names=str(list(self.cache.keys())),
         )
 
+    # ---- on-disk cache: one safetensors file per layer, interchangeable with the reference ----
+    # File name  "<aggregation fn>-<n_collect>-<layer>.safetensors"; header keys aggregation_fn_name / n_collect /
+    # n_latents / layer_name (all strings); tensors "activations" (bf16) and "sample_ids" (int64)
+    # (activation_caching.py:434-465).  A cache either matches this instance completely or it is a miss, and a miss is
+    # signalled with FileNotFoundError, which `ActivationComponentVisualizer.run` catches (activation_based.py:331-339).
     def _file_name(self, layer_name: str) -> str:
-        # "<aggregation fn>-<n_collect>-<layer>.safetensors" (activation_caching.py:454-461, 495-501)
-        return "-".join([self.agg_fn_name, str(self.n_collect), layer_name]) + ".safetensors"
+        return f"{self.agg_fn_name}-{self.n_collect}-{layer_name}.safetensors"
+
+    def _header(self, layer_name: str, act_max: ActMax) -> dict[str, str]:
+        return {
+            "aggregation_fn_name": self.agg_fn_name,
+            "n_collect": str(self.n_collect),
+            "n_latents": str(act_max.n_latents),
+            "layer_name": layer_name,
+        }
+
+    def _usable(self, path: Path) -> str | None:
+        """``None`` when ``path`` holds a top-k state collected with this aggregator and ``n_collect``; else why not."""
+        if not path.exists():
+            return "no such file"
+        with safetensors.safe_open(path, framework="pt") as handle:
+            header = handle.metadata() or {}
+        if header.get("aggregation_fn_name") != self.agg_fn_name:
+            return f"aggregated with {header.get('aggregation_fn_name')!r}, this cache uses {self.agg_fn_name!r}"
+        try:
+            stored_k = int(header.get("n_collect"))
+        except (TypeError, ValueError):
+            return f"unreadable n_collect {header.get('n_collect')!r}"
+        if stored_k != self.n_collect:
+            return f"holds the top {stored_k}, this cache collects the top {self.n_collect}"
+        return None
 
     def store(self, directory: Path | str):
-        """One safetensors file per layer, byte-compatible with the reference (activation_caching.py:434-465)."""
-        directory = Path(directory)
-        directory.mkdir(parents=True, exist_ok=True)
-        for layer_name, act_max_instance in self.cache.items():
-            if not act_max_instance.is_setup:
-                logger.warning(f"Skipping layer '{layer_name}' as it has no data.")
-                continue
-            metadata = {
-                "aggregation_fn_name": self.agg_fn_name,
-                "n_collect": str(self.n_collect),
-                "n_latents": str(act_max_instance.n_latents),
-                "layer_name": layer_name,
-            }
-            act_max_instance.store(directory / self._file_name(layer_name), metadata=metadata)
-        logger.info(f"Cache saved successfully to {directory}")
+        """Write every layer that has seen data; layers without data are skipped with a warning."""
+        root = Path(directory)
+        root.mkdir(parents=True, exist_ok=True)
+        for layer_name, act_max in self.cache.items():
+            if act_max.is_setup:
+                act_max.store(root / self._file_name(layer_name), metadata=self._header(layer_name, act_max))
+            else:
+                logger.warning(f"Layer '{layer_name}' has not seen any data; nothing written for it.")
+        logger.info(f"Top-k cache written to {root}")
 
     def load(self, directory: Path | str):
-        """Load every layer's file; any missing/mismatching file raises FileNotFoundError = cache miss
-        (activation_caching.py:467-534)."""
-        directory = Path(directory)
-        if not directory.is_dir():
-            raise FileNotFoundError(f"Cache directory not found: {directory}")
-        expected_agg_fn_name = self.aggregation_fn.__name__
-        logger.info(f"Loading cache for aggregation fn: '{expected_agg_fn_name}'")
-        loaded_count = 0
-        for layer_name in self.layer_names:
-            fpath = directory / self._file_name(layer_name)
-            if not fpath.exists():
-                logger.warning(f"File not found for layer '{layer_name}': {fpath}")
-                raise FileNotFoundError(f"Expected file not found: {fpath}")
-            try:
-                with safetensors.safe_open(fpath, framework="pt") as f:
-                    metadata = f.metadata()
-                    if metadata.get("aggregation_fn_name") != expected_agg_fn_name:
-                        raise ValueError(
-                            f"Mismatch in aggregation function for layer '{layer_name}'. "
-                            f"Expected '{expected_agg_fn_name}', but file has '{metadata.get('aggregation_fn_name')}'."
-                        )
-                    if int(metadata.get("n_collect")) != self.n_collect:
-                        raise ValueError(
-                            f"Mismatch in n_collect for layer '{layer_name}'. "
-                            f"Expected '{self.n_collect}', but file has '{metadata.get('n_collect')}'."
-                        )
-            except ValueError as e:
-                logger.warning(f"Validation failed for layer '{layer_name}': {e}")
-                raise FileNotFoundError(f"Expected file not found: {fpath}")
-            loaded = ActMax.load(fpath)
-            loaded.tie_mode = self.tie_mode
-            self.cache[layer_name] = loaded
-            loaded_count += 1
-        if loaded_count == 0:
-            logger.warning(f"No matching cache files were found and loaded from {directory}")
-        else:
-            logger.info(f"Successfully loaded data for {loaded_count} layer(s) from {directory}")
+        """Replace every layer's state with the one stored under ``directory`` (activation_caching.py:467-534).
+
+        Raises ``FileNotFoundError`` when the directory, or a usable file for ANY of ``layer_names``, is missing.  The
+        files of all layers are validated before the first one is installed, so a miss leaves this cache untouched (the
+        reference installs layers as it goes; after a partial hit its caller would collect on top of the layers it did
+        load)."""
+        root = Path(directory)
+        if not root.is_dir():
+            raise FileNotFoundError(f"Cache directory not found: {root}")
+        paths = {layer_name: root / self._file_name(layer_name) for layer_name in self.layer_names}
+        for layer_name, path in paths.items():
+            problem = self._usable(path)
+            if problem is not None:
+                logger.warning(f"Top-k cache miss for layer '{layer_name}' ({path.name}): {problem}")
+                raise FileNotFoundError(f"Expected file not found: {path}")
+        for layer_name, path in paths.items():
+            state = ActMax.load(path)
+            state.tie_mode = self.tie_mode
+            self.cache[layer_name] = state
+        logger.info(f"Top-k cache: {len(paths)} layer(s) loaded from {root}")

@@ -86,11 +86,38 @@ def all_gather_states(states, group=None):
     return out
 
 
-def merge_actmax_cache(actmax_cache, group=None):
-    """Make every rank's ``ActMaxCache`` hold the global top-k (K4).  Collective call."""
+def _all_reduce_host_ints(values: list[int], op, group, device) -> list[int]:
+    """All-reduce a few Python ints (layer widths, cache-hit flags); device tensor under RCCL, host tensor under gloo."""
+    t = torch.tensor(values, dtype=torch.int64)
+    if not _host_staged(group):
+        t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    dist.all_reduce(t, op=op, group=group)
+    return [int(v) for v in t.cpu().tolist()]
+
+
+def merge_actmax_cache(actmax_cache, group=None, device=None):
+    """Make every rank's ``ActMaxCache`` hold the global top-k (K4).  Collective call.
+
+    A rank whose shard was empty (``N < R``, or a short last shard) never saw a batch, so its ``ActMax`` objects do
+    not know their width: the layer widths are agreed first (one small MAX all-reduce) and such ranks contribute the
+    initial state (values -0.0, ids -1), which loses every comparison."""
     rank = dist.get_rank(group)
-    layers = [name for name in actmax_cache.layer_names if actmax_cache.cache[name].is_setup]
-    states = [actmax_cache.cache[name].device_state() for name in layers]
+    names = list(actmax_cache.layer_names)
+    widths = _all_reduce_host_ints(
+        [actmax_cache.cache[n].n_latents or 0 if actmax_cache.cache[n].is_setup else 0 for n in names],
+        dist.ReduceOp.MAX, group, device)
+    layers = []
+    for name, width in zip(names, widths):
+        if width == 0:  # no rank collected anything for this layer
+            continue
+        am = actmax_cache.cache[name]
+        if not am.is_setup:
+            am.n_latents = width
+            am._setup_tensors()
+        elif am.n_latents != width:
+            raise RuntimeError(f"layer {name!r}: this rank has {am.n_latents} components, another rank {width}")
+        layers.append(name)
+    states = [actmax_cache.cache[name].device_state(device) for name in layers]
     gathered = all_gather_states(states, group)
     world = dist.get_world_size(group)
     others = [r for r in range(world) if r != rank]
@@ -103,13 +130,31 @@ def run_sharded(cv, batch_size: int = 64, num_workers: int = 0, group=None):
     """Sharded version of ``cv.run``: collect this rank's shard, then merge across ranks.
 
     ``cv`` must use ``tie_mode="total"`` (the torch.topk tie order of the reference is defined
-    only for a single sequential stream).
+    only for a single sequential stream).  Cache behaviour follows ``cv.run`` (activation_based.py:309-339): when
+    ``cache_dir`` is set and EVERY rank finds a matching top-k cache it is returned as is; otherwise every rank starts
+    from fresh states (the constructor may already have loaded a cache into ``actmax_cache`` — collecting on top of it
+    would list the same samples twice, K3/K4 never de-duplicate), and rank 0 stores the merged result.
     """
     if cv.actmax_cache.tie_mode != "total":
         raise ValueError("sharded collection requires tie_mode='total'")
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if cv.caching:
+        try:
+            cv.actmax_cache.load(cv.storage_dir)
+            hit = 1
+        except FileNotFoundError:
+            hit = 0
+        if _all_reduce_host_ints([hit], dist.ReduceOp.MIN, group, cv.device)[0]:
+            return cv.actmax_cache.cache
+    for name in cv.layer_names:  # fresh states, whatever the constructor loaded
+        old = cv.actmax_cache.cache[name]
+        cv.actmax_cache.cache[name] = type(old)(n_collect=old.n_collect, tie_mode=old.tie_mode)
     cv._run(batch_size=batch_size, num_workers=num_workers, sample_range=shard_range(len(cv.dataset), rank, world))
-    merge_actmax_cache(cv.actmax_cache, group)
+    merge_actmax_cache(cv.actmax_cache, group, cv.device)
+    if cv.caching:
+        if rank == 0:
+            cv.actmax_cache.store(cv.storage_dir)
+        dist.barrier(group=group)
     return cv.actmax_cache.cache
 
 

@@ -38,10 +38,20 @@ def text_probing(fm, query, aggregated_concept_db, templates=None, batch_size=No
 
 def image_probing(fm, query, aggregated_concept_db):
     """Cosine similarity of an image query (several images are averaged) against the DB (lens.py:124-162)."""
-    with torch.no_grad():
-        query_embed = fm.encode_image(fm.preprocess(query).to(fm.device))
-    query_embed = query_embed.mean(0)[None] if query_embed.shape[0] > 1 else query_embed
-    return _probe(query_embed, aggregated_concept_db)
+    return _probe(_embed_image_probe(fm, query), aggregated_concept_db)
+
+
+@torch.no_grad()
+def _embed_image_probe(fm, query) -> torch.Tensor:
+    """``(1, D)`` probe vector of one image or of a list of images (lens.py:158-160).
+
+    Several images are averaged on the HOST, as the reference does (it moves the ``(n_images, D)`` embeddings to the
+    CPU first): torch's device ``mean`` multiplies by a reciprocal where the CPU one divides, which differs in the last
+    bit; the tensor is a few KB."""
+    embeds = fm.encode_image(fm.preprocess(query).to(fm.device))
+    if embeds.shape[0] > 1:
+        return embeds.cpu().mean(0)[None]
+    return embeds
 
 
 def _encode_texts(fm, texts: list[str], batch_size: int | None = None, progress: bool = False):
@@ -114,20 +124,22 @@ class Lens:
         dataset,model joined by '-'>.safetensors`` (lens.py:308-316).
         """
         if not cv.caching:
-            logger.debug("Caching is not enabled. Computing Concept DB")
             return cv._compute_concept_db(self.fm, **kwargs)
-        fdir = cv.storage_dir / "concept_database" / self.fm.name
-        fdir.mkdir(parents=True, exist_ok=True)
-        fname = "concept_db-" + "-".join(v for k, v in cv.metadata.items() if k not in ["dataset", "model"]) + ".safetensors"
-        fpath = fdir / fname
-        if fpath.exists():
-            logger.debug("Loading concept DB from cache")
-            return load_file(filename=fpath)
-        logger.debug("Computing concept DB and saving to cache")
+        path = self._concept_db_path(cv)
+        if path.exists():
+            logger.debug(f"concept DB read from {path}")
+            return load_file(filename=path)
         concept_db = cv._compute_concept_db(self.fm, **kwargs)
-        save_file(tensors=concept_db, filename=fpath)
-        logger.debug(f"Saved concept DB to cache {fpath}")
+        save_file(tensors=concept_db, filename=path)
+        logger.debug(f"concept DB written to {path}")
         return concept_db
+
+    def _concept_db_path(self, cv):
+        """The cache file of ``cv``'s concept DB under this foundation model; creates its directory."""
+        folder = cv.storage_dir / "concept_database" / self.fm.name
+        folder.mkdir(parents=True, exist_ok=True)
+        tags = [value for key, value in cv.metadata.items() if key not in ("dataset", "model")]
+        return folder / ("concept_db-" + "-".join(tags) + ".safetensors")
 
     def text_probing(self, query, aggregated_concept_db, templates=None, batch_size=None):
         return text_probing(self.fm, query, aggregated_concept_db, templates, batch_size)

@@ -36,7 +36,7 @@ from semanticlens import scores as ref_scores  # noqa: E402
 from semanticlens.component_visualization import aggregators as ref_agg  # noqa: E402
 from semanticlens.component_visualization.activation_based import ActivationComponentVisualizer  # noqa: E402
 from semanticlens.component_visualization.activation_caching import ActMax  # noqa: E402
-from semanticlens.lens import Lens, _embed_text_probes  # noqa: E402
+from semanticlens.lens import Lens, _embed_text_probes, image_probing  # noqa: E402
 
 
 def bf16_bits(t: torch.Tensor) -> np.ndarray:
@@ -288,11 +288,40 @@ def gen_pipeline():
     save("pipeline", **out)
 
 
+# --------------------------------------------------------------------------- 7
+def gen_image_probes():
+    """lens.py:124-162 — one image (no averaging) and several images (mean of their embeddings) against a
+    tensor DB and a dict DB; FakeVLM's integer projection makes the query embedding exact."""
+    out = {}
+    fm = FakeVLM()
+    imgs = make_int_images(3, seed=9)
+    g = torch.Generator().manual_seed(41)
+    db = torch.randn(7, fm.dim, generator=g)
+    db_dict = {"a": torch.randn(5, fm.dim, generator=g), "b": torch.randn(1, fm.dim, generator=g)}
+    out["images"] = imgs.numpy()
+    out["db"] = db.numpy()
+    out["db_a"], out["db_b"] = db_dict["a"].numpy(), db_dict["b"].numpy()
+    for tag, query in (("one", imgs[0]), ("one_list", [imgs[1]]), ("three", [imgs[0], imgs[1], imgs[2]])):
+        out[f"{tag}_tensor"] = image_probing(fm, query, db).numpy()
+        res = image_probing(fm, query, db_dict)
+        out[f"{tag}_a"], out[f"{tag}_b"] = res["a"].numpy(), res["b"].numpy()
+    emb = fm.encode_image(fm.preprocess([imgs[0], imgs[1], imgs[2]]))
+    out["three_query_embed"] = emb.mean(0)[None].numpy()
+    save("image_probes", **out)
+
+
+GENERATORS = {
+    "known_answer": gen_known_answer,
+    "streams": gen_streams,
+    "aggregators": gen_aggregators,
+    "scores": gen_scores,
+    "text_probes": gen_text_probes,
+    "pipeline": gen_pipeline,
+    "image_probes": gen_image_probes,
+}
+
 if __name__ == "__main__":
-    torch.manual_seed(0)
-    gen_known_answer()
-    gen_streams()
-    gen_aggregators()
-    gen_scores()
-    gen_text_probes()
-    gen_pipeline()
+    # `python make_golden.py` regenerates everything; `python make_golden.py image_probes ...` only those named
+    for name in sys.argv[1:] or list(GENERATORS):
+        torch.manual_seed(0)
+        GENERATORS[name]()

@@ -35,6 +35,9 @@ def _worker(rank, world, port, acts, k, out_dir):
             for s in range(start, stop, 16):
                 e = min(stop, s + 16)
                 o.update(acts[name][s:e], np.arange(s, e))
+            if start == stop:  # empty shard: this rank never saw a batch, its ActMax does not know its width
+                cache.cache[name] = ActMax(k, tie_mode="total")
+                continue
             am = ActMax(k, acts[name].shape[1], tie_mode="total")
             am.activations = torch.from_numpy(o.vals.view(np.int16)).view(torch.bfloat16)
             am.sample_ids = torch.from_numpy(o.ids)
@@ -73,6 +76,24 @@ def test_sharded_merge_two_ranks_gloo(tmp_path):
         ref = oracle.ActMaxOracle(k, acts[name].shape[1], oracle.MODE_TOTAL)
         ref.update(acts[name], np.arange(150))
         for r in (0, 1):
+            got = np.load(tmp_path / f"rank{r}.npz")
+            assert np.array_equal(got[f"v_{name}"].view(np.uint16), ref.vals), (name, r)
+            assert np.array_equal(got[f"i_{name}"], ref.ids), (name, r)
+
+
+def test_sharded_merge_with_an_empty_shard_gloo(tmp_path):
+    """N=2 samples over 3 ranks: the last rank's shard is empty — it must still take part in the all-gather (with
+    sentinel states of the agreed width) and end with the global top-k."""
+    import oracle
+
+    rng = np.random.RandomState(1)
+    acts = {"a": rng.rand(2, 6).astype(np.float32), "b": rng.rand(2, 3).astype(np.float32)}
+    k = 4
+    mp.spawn(_worker, args=(3, _free_port(), acts, k, str(tmp_path)), nprocs=3, join=True)
+    for name in ("a", "b"):
+        ref = oracle.ActMaxOracle(k, acts[name].shape[1], oracle.MODE_TOTAL)
+        ref.update(acts[name], np.arange(2))
+        for r in range(3):
             got = np.load(tmp_path / f"rank{r}.npz")
             assert np.array_equal(got[f"v_{name}"].view(np.uint16), ref.vals), (name, r)
             assert np.array_equal(got[f"i_{name}"], ref.ids), (name, r)

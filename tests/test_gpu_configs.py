@@ -130,7 +130,7 @@ def test_config4_polysemanticity_over_a_full_concept_db():
     V[::7, :9] += 2.0 * rng.randn(220, 1, 512).astype(np.float32)  # some clustered components
     got = Lens(synth.SyntheticClip(device=DEV, v_layers=1, t_layers=1), device=DEV).eval_polysemanticity({"stage4": torch.from_numpy(V).to(DEV)})["stage4"]
     assert got.shape == (1536,) and got.dtype == torch.float64
-    sub = np.arange(0, 1536, 24)
-    want = oracle.polysemanticity(V[sub])
-    agree = np.abs(got.cpu().numpy()[sub] - want) <= 1e-5
-    assert agree.mean() >= 0.97, agree.mean()
+    from test_gpu_parity import assert_polysemanticity_matches
+
+    sub = np.arange(0, 1536, 3)  # 512 components through scikit-learn (~4 s); every one must match
+    assert_polysemanticity_matches(got.cpu().numpy()[sub], V[sub], "config4")

@@ -19,15 +19,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _build(tie_mode="total"):
+def _build(tie_mode="total", cache_dir=None, device="cuda:0"):
     from helpers import FakeVLM, TensorPairDataset, make_int_conv_model, make_int_images
     from semanticlens_amd.component_visualization import ActivationComponentVisualizer, aggregators
 
-    model = make_int_conv_model().to("cuda:0")
+    model = make_int_conv_model().to(device)
     ds = TensorPairDataset(make_int_images(47))  # 47: shards of unequal size
-    cv = ActivationComponentVisualizer(model, ds, ds, ["0", "2"], num_samples=6,
+    cv = ActivationComponentVisualizer(model, ds, ds, ["0", "2"], num_samples=6, cache_dir=cache_dir,
                                        aggregate_fn=aggregators.aggregate_conv_max, tie_mode=tie_mode)
-    return cv, FakeVLM().to("cuda:0")
+    return cv, FakeVLM().to(device)
 
 
 def _worker(rank, world, port, out_dir):
@@ -65,6 +65,118 @@ def test_sharded_build_equals_single_process(world, tmp_path):
             assert np.array_equal(got[f"vals_{k}"], cv.actmax_cache.cache[k].activations.view(torch.int16).numpy())
             assert np.array_equal(got[f"db_{k}"], want[k].numpy()), (world, r, k)
             assert np.array_equal(got[f"dbref_{k}"], want[k].numpy()), (world, r, k, "referenced_only")
+
+
+def _cache_worker(rank, world, port, out_dir, cache_dir):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(__file__))
+    from semanticlens_amd import distributed as sld
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cv, fm = _build(cache_dir=cache_dir)  # the constructor loads an existing top-k cache into actmax_cache
+        sld.run_sharded(cv, batch_size=8)
+        np.savez(os.path.join(out_dir, f"cache_r{rank}.npz"),
+                 **{f"ids_{k}": cv.get_max_reference(k).numpy() for k in ("0", "2")},
+                 **{f"vals_{k}": cv.actmax_cache.cache[k].activations.view(torch.int16).numpy() for k in ("0", "2")})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_run_with_cache_dir(tmp_path):
+    """with `cache_dir` set the constructor may already have loaded a top-k cache; the sharded run must
+    neither collect on top of it (duplicate ids) nor skip storing its merged result."""
+    cv, _ = _build()
+    cv.run(batch_size=8)
+    want = {k: (cv.get_max_reference(k).numpy(), cv.actmax_cache.cache[k].activations.view(torch.int16).numpy()) for k in ("0", "2")}
+    cache = tmp_path / "cache"
+    out = tmp_path / "out"
+    out.mkdir()
+
+    def check():
+        for r in range(2):
+            got = np.load(out / f"cache_r{r}.npz")
+            for k in ("0", "2"):
+                assert np.array_equal(got[f"ids_{k}"], want[k][0]), (r, k)
+                assert np.array_equal(got[f"vals_{k}"], want[k][1]), (r, k)
+                ids = got[f"ids_{k}"]
+                assert all(len(set(row[row >= 0])) == (row >= 0).sum() for row in ids), "a sample id is listed twice"
+
+    mp.spawn(_cache_worker, args=(2, _free_port(), str(out), str(cache)), nprocs=2, join=True)  # miss: collect + store
+    check()
+    stored = sorted(p.name for p in cache.rglob("*.safetensors"))
+    assert len(stored) == 2, stored  # rank 0 stored the merged states, one file per layer
+    cv1, _ = _build(cache_dir=str(cache))  # a single-process visualizer reads what the sharded run wrote
+    for k in ("0", "2"):
+        assert np.array_equal(cv1.get_max_reference(k).numpy(), want[k][0])
+    mp.spawn(_cache_worker, args=(2, _free_port(), str(out), str(cache)), nprocs=2, join=True)  # hit on every rank
+    check()
+    # a partial cache (one layer's file missing) is a miss: states loaded by the constructor must not be collected over
+    next(cache.rglob("*-2.safetensors")).unlink()
+    mp.spawn(_cache_worker, args=(2, _free_port(), str(out), str(cache)), nprocs=2, join=True)
+    check()
+
+
+def _bench_line(extra_env, args, nproc):
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(nproc)] + args
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_sharing_one_gpu_over_gloo():
+    """BASELINE configs[2] code path (`bench.py --gpus N`): per-rank collect, packed all-gather, K4 merge, sharded K5
+    gather + all-reduce, max-over-ranks timing — with two ranks on ONE GPU and gloo as the transport."""
+    line = _bench_line({"SL_BENCH_BACKEND": "gloo", "SL_BENCH_SHARE_GPU": "1"}, ["--steps", "3", "--warmup", "1", "--batch", "64"], 2)
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
+    assert line["config"]["images_total"] == 2 * 3 * 64 and line["value"] > 0
+    line = _bench_line({"SL_BENCH_BACKEND": "gloo", "SL_BENCH_SHARE_GPU": "1"},
+                       ["--scaling", "strong", "--images", "500", "--warmup", "1", "--batch", "64"], 2)
+    assert line["scaling"] == "strong" and line["config"]["images_total"] == 500 and line["steps"] == 4
+
+
+def _nccl_worker(rank, world, port, out_dir):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(__file__))
+    from semanticlens_amd import distributed as sld
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        cv, fm = _build(device=dev)
+        db = sld.compute_concept_db_sharded(cv, fm, batch_size=8)
+        np.savez(os.path.join(out_dir, f"nccl_r{rank}.npz"), **{f"db_{k}": v.cpu().numpy() for k, v in db.items()},
+                 **{f"ids_{k}": cv.get_max_reference(k).numpy() for k in db})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the RCCL (nccl backend) branch of distributed.py")
+def test_sharded_build_over_rccl(tmp_path):
+    """One process per GPU over RCCL — runs on the first multi-GPU box that executes the suite."""
+    world = min(torch.cuda.device_count(), 8)
+    cv, fm = _build()
+    want = cv._compute_concept_db(fm, batch_size=8)
+    mp.spawn(_nccl_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        got = np.load(tmp_path / f"nccl_r{r}.npz")
+        for k in ("0", "2"):
+            assert np.array_equal(got[f"ids_{k}"], cv.get_max_reference(k).numpy()), (r, k)
+            assert np.array_equal(got[f"db_{k}"], want[k].numpy()), (r, k)
 
 
 def test_sharded_requires_total_order():

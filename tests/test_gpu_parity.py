@@ -454,6 +454,33 @@ def test_text_probes_golden(golden):
                 assert np.array_equal(emb.cpu().numpy(), g[f"q{nq}_t{nt}_bs{bs}"]), (nq, nt, bs)
 
 
+def test_image_probing_golden(golden):
+    """lens.py:124-162 — a single image is used as is, several images are averaged; tensor and dict DBs."""
+    from helpers import FakeVLM
+    from semanticlens_amd.lens import Lens, image_probing
+
+    g = golden("image_probes")
+    fm = FakeVLM().to(DEV)
+    imgs = torch.from_numpy(g["images"])
+    db = torch.from_numpy(g["db"])
+    db_dict = {"a": torch.from_numpy(g["db_a"]), "b": torch.from_numpy(g["db_b"])}
+    lens = Lens(fm, device=DEV)
+    for tag, query in (("one", imgs[0]), ("one_list", [imgs[1]]), ("three", [imgs[0], imgs[1], imgs[2]])):
+        for where in ("cpu", DEV):  # results come back on the DB's device, like the reference's `_probe`
+            got = image_probing(fm, query, db.to(where))
+            assert got.device.type == torch.device(where).type and got.shape == g[f"{tag}_tensor"].shape
+            np.testing.assert_allclose(got.cpu().numpy(), g[f"{tag}_tensor"], rtol=0, atol=1e-5)
+            res = lens.image_probing(query, {k: v.to(where) for k, v in db_dict.items()})
+            assert list(res) == ["a", "b"]
+            for k in res:
+                assert res[k].shape == g[f"{tag}_{k}"].shape
+                np.testing.assert_allclose(res[k].cpu().numpy(), g[f"{tag}_{k}"], rtol=0, atol=1e-5)
+    # the averaged query embedding itself is bit-equal to the reference's (integer projection, one host division)
+    from semanticlens_amd.lens import _embed_image_probe
+
+    assert np.array_equal(_embed_image_probe(fm, [imgs[0], imgs[1], imgs[2]]).cpu().numpy(), g["three_query_embed"])
+
+
 # ---------------------------------------------------------------------------------------------- K9
 def test_polysemanticity_goldens(golden):
     """scores.py:131-185 incl. the fallback rows (one cluster / a cluster of one sample)."""
@@ -465,12 +492,30 @@ def test_polysemanticity_goldens(golden):
     assert scores.polysemanticity_score(torch.from_numpy(g["P10"])).device.type == "cpu"
 
 
+def assert_polysemanticity_matches(got, V, tag=""):
+    """Every component must reproduce scikit-learn's clustering — no tolerated minority.
+
+    The reference is deterministic (scores.py:167, random_state=123).  Rows scored from the cluster centres are
+    fp64 on both sides: a different clustering moves the score by >> 1e-9, so agreement within 1e-9 shows the same
+    clustering was chosen.  Rows that take the fallback branch (scores.py:178-184) are computed by the reference
+    through the fp32 ``clarity_score``: 1e-6.  Observed on MI355X (tools/k9_rate.py): 100 % of 2 400 components.
+    """
+    want, fallback = oracle.polysemanticity(V, return_fallback=True)
+    diff = np.abs(got - want)
+    print(f"K9 {tag}: {len(want)} components, {int(fallback.sum())} fallback rows, max |diff| centres "
+          f"{diff[~fallback].max() if (~fallback).any() else 0:.2e}, fallback {diff[fallback].max() if fallback.any() else 0:.2e}")
+    bad = np.nonzero((diff > 1e-9) & ~fallback)[0]
+    assert bad.size == 0, (tag, "clustering differs from scikit-learn's for components", bad[:10], diff[bad[:10]])
+    bad = np.nonzero((diff > 1e-6) & fallback)[0]
+    assert bad.size == 0, (tag, "fallback rows differ", bad[:10], diff[bad[:10]])
+
+
 @pytest.mark.parametrize("C,n,D,kind", [(256, 20, 512, "random"), (256, 20, 512, "blobs"), (128, 10, 64, "random"),
-                                        (64, 33, 100, "blobs"), (64, 100, 32, "random"), (96, 20, 1152, "blobs3")])
+                                        (64, 33, 100, "blobs"), (64, 100, 32, "random"), (96, 20, 1152, "blobs3"),
+                                        (512, 20, 512, "weak"), (256, 5, 16, "random"), (128, 3, 8, "random")])
 def test_polysemanticity_vs_sklearn_oracle(C, n, D, kind):
     """The Gram-space restatement of sklearn's KMeans picks the same clustering as sklearn itself
-    (oracle.polysemanticity calls scikit-learn): per-component agreement within 1e-5 must be >= 98 %
-    (fp64 Gram arithmetic vs sklearn's coordinate arithmetic can flip numerical near-ties only)."""
+    (oracle.polysemanticity calls scikit-learn) for EVERY component."""
     rng = np.random.RandomState(C + n + D)
     V = rng.randn(C, n, D).astype(np.float32)
     if kind.startswith("blobs"):
@@ -478,10 +523,11 @@ def test_polysemanticity_vs_sklearn_oracle(C, n, D, kind):
         centers = rng.randn(C, nb, D).astype(np.float32) * 2
         assign = rng.randint(0, nb, size=(C, n))
         V = centers[np.arange(C)[:, None], assign] + 0.5 * V
-    want = oracle.polysemanticity(V)
+    elif kind == "weak":  # barely separated blobs: many competing local optima across the 10 inits
+        centers = rng.randn(C, 2, D).astype(np.float32) * 0.15
+        V = centers[np.arange(C)[:, None], rng.randint(0, 2, size=(C, n))] + V
     got = scores.polysemanticity_score(torch.from_numpy(V).to(DEV)).cpu().numpy()
-    agree = np.abs(got - want) <= 1e-5
-    assert agree.mean() >= 0.98, (kind, agree.mean(), np.abs(got - want).max())
+    assert_polysemanticity_matches(got, V, kind)
     assert np.all(got >= -1e-6) and np.all(got <= 2 + 1e-6)
 
 
@@ -530,8 +576,9 @@ def test_fused_multi_layer_probe_equals_per_layer_similarity():
 
 
 def test_gemm_tile_variants_are_bit_identical(tmp_path):
-    """The 128x128 register-staged and the 256x128 LDS-DMA staged split-bf16 kernels accumulate every output element
-    in the same order: same bits (the variant is latched per process, hence subprocesses)."""
+    """The 128x128 register-staged, the 256x128 LDS-DMA staged, the 256x256 ping-pong and the 256x256 8-phase split-bf16
+    kernels accumulate every output element in the same order: same bits (the variant is latched per process, hence
+    subprocesses).  Forcing a variant sends EVERY shape through it, ragged and tiny ones included."""
     import os
     import subprocess
     import sys
@@ -555,10 +602,10 @@ torch.save(outs, sys.argv[1])
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for tile in ("128", "256", "512"):
+    for tile in ("128", "256", "512", "8"):
         out = tmp_path / f"g3_{tile}.pt"
         subprocess.run([sys.executable, "-c", code, str(out), root], check=True, env=dict(os.environ, SL_G3_TILE=tile))
         res[tile] = torch.load(out)
-    for other in ("256", "512"):
+    for other in ("256", "512", "8"):
         for a, b in zip(res["128"], res[other]):
             assert torch.equal(a, b), (other, tuple(a.shape))
