@@ -369,7 +369,7 @@ def probing_leg(dev):
         "fp32_mfma_mode": {"value": sims / wall1 / 1e6, "unit": "Msim/s", "wall_ms": wall1 * 1e3,
                            "roofline": {"bound": "mfma", "achieved": fl1 / ms1 / 1e9, "peak": MFMA_F32_PEAK_TFLOPS,
                                         "unit": "TFLOP/s", "frac": (fl1 / ms1 / 1e9) / MFMA_F32_PEAK_TFLOPS,
-                                        "kernel": "gemm_nt (v_mfma_f32_32x32x2_f32)", "launches": n1,
+                                        "kernel": "gemm_nt_8phase<f32> (v_mfma_f32_32x32x2_f32, 256x256 tiles, all 12 layers gathered into one launch)", "launches": n1,
                                         "avg_ms": ms1 / max(n1, 1)}},
         "max_abs_diff_between_modes": max_diff,
     }

@@ -125,6 +125,30 @@ struct MultiEpi {
   }
 };
 
+// The same routing for the fp32-MFMA mode, whose operands are not pre-normalised: the per-column value carries the layer
+// and the column's inverse norm, the epilogue scales like CosineEpi (acc * rinv_x[row] * rinv_y[col], same order: the
+// fused probe is bit-identical to layer-by-layer sl_similarity calls).
+struct LayerCol {
+  int layer;
+  float rinv;
+};
+struct MultiCosineEpi {
+  float* out[kMaxFusedLayers];
+  int64_t start[kMaxFusedLayers + 1];
+  int n;
+  const float* ra;
+  const float* rb;
+  __device__ LayerCol column(int64_t col) const {
+    int l = 0;
+    while (l + 1 < n && col >= start[l + 1]) ++l;
+    return LayerCol{l, rb[col]};
+  }
+  __device__ void store(int64_t row, int64_t col, float acc, LayerCol cv) const {
+    const int l = cv.layer;
+    out[l][row * (start[l + 1] - start[l]) + (col - start[l])] = acc * ra[row] * cv.rinv;
+  }
+};
+
 int launch_inv_norm(const float* x, int64_t rows, int64_t cols, float eps, float* out, hipStream_t st) {
   int64_t blocks = (rows + 3) / 4;
   const int64_t cap = (int64_t)num_cus() * 8;
@@ -194,7 +218,11 @@ int cosine_matrix_multi(const float* X, int64_t Q, int64_t K, const float* const
   }
   const bool fast = use_bf16x3() && K >= 64;
   const bool fused = fast && L <= kMaxFusedLayers;
-  const int64_t yrows = fused ? csum : cmax;  // rows of the y scratch (all layers, or one at a time)
+  // fp32-MFMA mode: the layers are gathered into ONE (sum C, K) fp32 operand when that lets the 256 x 256 8-phase kernel
+  // run (rows of whole 128-byte lines, enough tiles to fill the chip): 12 launches of 120 tiles become one of 1440
+  const bool fused_f32 = !fast && L > 1 && L <= kMaxFusedLayers && K % 32 == 0 && K > 0 && ((uintptr_t)X & 15) == 0 &&
+                         gemm8::fits(Q, csum, K * 4) && gemm8::worth_it(Q, csum) && !gemm8::worth_it(Q, cmax);
+  const int64_t yrows = (fused || fused_f32) ? csum : cmax;  // rows of the y scratch (all layers, or one at a time)
   float* rx = (float*)ws;
   float* ry = (float*)(ws + align256_((size_t)Q * 4));
   unsigned char* sp = ws + align256_((size_t)Q * 4) + align256_((size_t)yrows * 4);
@@ -223,6 +251,26 @@ int cosine_matrix_multi(const float* X, int64_t Q, int64_t K, const float* const
     if (Q * off == 0) return 0;
     ProfScope prof(SL_PROF_GEMM, st, 2.0 * (double)Q * (double)off * (double)K);
     return gemm3::launch_gemm3_nt(prof, xs, Q, ys, off, K, epi, st);
+  }
+  if (fused_f32) {
+    MultiCosineEpi epi{};
+    epi.n = 0;
+    epi.ra = rx;
+    epi.rb = ry;
+    float* yall = (float*)sp;  // the split scratch is at least (sum C) x K floats
+    int64_t off = 0;
+    for (int l = 0; l < L; ++l) {
+      if (Cs[l] == 0) continue;
+      if (int rc = launch_inv_norm(Ys[l], Cs[l], K, 1e-12f, ry + off, st)) return rc;
+      SL_CHECK_HIP(hipMemcpyAsync(yall + off * K, Ys[l], (size_t)Cs[l] * K * 4, hipMemcpyDeviceToDevice, st));
+      epi.out[epi.n] = outs[l];
+      epi.start[epi.n] = off;
+      ++epi.n;
+      off += Cs[l];
+    }
+    epi.start[epi.n] = off;
+    ProfScope prof(SL_PROF_GEMM, st, 2.0 * (double)Q * (double)off * (double)K);
+    return gemm::launch_gemm_nt(prof, X, Q, yall, off, K, epi, st);
   }
   for (int l = 0; l < L; ++l) {
     if (Q * Cs[l] == 0) continue;

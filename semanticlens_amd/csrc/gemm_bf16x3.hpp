@@ -11,7 +11,8 @@
 // whole cache line (with separate hi / lo matrices every line was requested twice, by consecutive k-tiles: measured
 // -9 % cycles for the LDS-DMA kernel), and no kernel needs a partial-tile path.
 //
-// Two kernels, same accumulation order per output element (bit-identical results, tests/test_gpu_parity.py):
+// Kernels, all with the same accumulation order per output element (bit-identical results, tests/test_gpu_parity.py);
+// the default for grids of at least half a 256 x 256 tile per CU is the 8-phase kernel of gemm_8phase.hpp:
 //   gemm3_nt_kernel         128 x 128 x 32 tile, 4 waves (2 x 2), wave tile 64 x 64; tiles staged through registers
 //                           into four LDS images (A_hi, A_lo, B_hi, B_lo) with 80-byte rows (conflict-free fragment
 //                           reads); single LDS stage + register prefetch, 40 KB, three workgroups per CU
@@ -21,6 +22,7 @@
 // hardware orders k inside a fragment.
 #pragma once
 #include "common.hpp"
+#include "gemm_8phase.hpp"
 #include <cstdlib>
 
 namespace sl {
@@ -533,343 +535,6 @@ __global__ __launch_bounds__(512, 2) void gemm3_nt_pingpong_kernel(const uint16_
 #endif
 }
 
-// ---- kernel 4: 256 x 256 block tile, 8 waves (2 x 4), two staggered wave groups, 16-KB pieces in a 128-KB ring -------
-// The schedule of the guide's 256^2 8-phase bf16 kernel (cdna_hip_programming.md "The 256^2 8-phase template"),
-// re-derived for split operands.  A *stage* is one 32-wide k-tile of all 512 rows = 512 whole 128-byte [hi32 | lo32]
-// lines = 64 KB (A image, then B image); LDS holds two stages.  A wave owns a 128 x 64 piece of the output (4 x 2
-// MFMA tiles, 128 accumulator registers) and runs a stage in FOUR phases of 12 MFMAs (384 matrix-pipe cycles):
-//   phase p = 2 ih + ks + 1:  row tiles i in {2 ih, 2 ih + 1}, k-step ks of the stage, both column tiles.
-// B fragments of a stage are kept in VGPRs (k-step 1 read in phase 1, k-step 0 in phase 4 of the stage before); A
-// fragments (4 reads) are read per phase.
-// * Wave groups: waves 0-3 (rows 0-127) and 4-7 (rows 128-255) sit one per SIMD each.  Every phase is
-//   [read slot] s_barrier [MFMA slot] s_barrier, and group 1 runs one barrier behind group 0, so between any two
-//   barriers one wave of each SIMD feeds the matrix pipe while the other reads fragments and issues LDS-DMA.
-// * Feed: a stage is four 16-KB *pieces* (B rows 0-127, B rows 128-255, A rows of ih = 0, A rows of ih = 1); a piece
-//   is 16 LDS-DMA instructions of 8 whole lines, two per wave.  Pieces are issued in consumption order, one per phase,
-//   SIX pieces ahead: phase g issues piece g + 6 into the ring slot of piece g - 2, whose last read was in phase
-//   <= g - 1 (B: phase 4 of the stage before and phase 1 of its stage, A(ih): phases 2 ih + 1, 2 ih + 2) and was retired by the lgkmcnt(0) that
-//   precedes that phase's barrier.  5-7 pieces (80-112 KB per CU) are in flight at any time, ~5 phases ~ 2 us of lead:
-//   the depth the 48-KB single-buffer kernel 2 lacks.
-// * Waits: counted, never zero in the steady state.  What phase g + 1 reads must have been waited for in phase g's
-//   read slot, before its barrier (the guide's "read one phase after the wait"): phase 2 of a stage waits vmcnt(8)
-//   (A1 of this stage; four younger pieces may fly), phase 3 vmcnt(6) (B0, B1 of the next stage), phase 4 vmcnt(6)
-//   (A0 of the next stage).  Raw s_barrier only: __syncthreads() would add vmcnt(0) and drain the ring.
-// * LDS image: unpadded 128-byte rows, 16-byte slots XOR-swizzled by (row >> 1) & 7 on the DMA's SOURCE address and on
-//   the fragment read (as kernel 2): conflict-free ds_read_b128.
-// Per output element the products are accumulated in the same order as in kernels 1-3: bit-identical results.
-constexpr int BM5 = 256, BN5 = 256;
-constexpr int IMG5_BYTES = 256 * 128;         // one operand of one stage: 32 KB
-constexpr int STAGE5_BYTES = 2 * IMG5_BYTES;  // A image, B image
-
-template <int N_>
-struct IntC {
-  static constexpr int value = N_;
-};
-
-__device__ __forceinline__ void wait_vm_pieces(int n) {  // at most n pieces (2 loads each) of this wave still in flight
-  switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-  }
-}
-
-// SWZ: 0 = tiles in launch order (row-major), 1 = every XCD gets a contiguous range of tiles, walked in bands of
-// GROUP_M tile rows (neighbouring workgroups of one L2 share A and B panels)
-// ABLATE (measurement only, results are garbage): 1 = no LDS-DMA in the k loop, 2 = no fragment reads, 4 = no barriers,
-// 8 = LDS-DMA issued but never waited for, 16 = LDS-DMA always re-reads stage 0 (cache-hot source),
-// 32 = half of the LDS-DMA instructions, 64 = LDS-DMA of 4 bytes per lane instead of 16 (waits disabled with 8)
-// DMAPOS: 0 = the phase's two LDS-DMA instructions are issued in the read slot, 1 = by the same wave inside its MFMA
-// slot (after the 4th and the 8th MFMA), 2 = after the 2nd and 3rd MFMA
-template <class Epi, int SWZ, int EARLY = 0, int ABLATE = 0, int LOOK = 6, int DMAPOS = 0>
-__global__ __launch_bounds__(512, 2) void gemm3_nt_8phase_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
-                                                                 int64_t M, int64_t N, int64_t Kp, int tiles_m, int tiles_n, Epi epi) {
-  __shared__ __align__(1024) unsigned char smem[2 * STAGE5_BYTES];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7
-  const int wr = w >> 2, wc = w & 3;
-  const int li = lane & 31, lh = lane >> 5;
-  int tile = blockIdx.x;
-  int tm_i, tn_i;
-  if (SWZ == 1) {
-    const int nwg = tiles_m * tiles_n;
-    const int xcd = tile & 7, idx = tile >> 3;
-    const int q = nwg >> 3, r = nwg & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective for any nwg
-    constexpr int GROUP_M = 4;
-    const int band = tile / (GROUP_M * tiles_n);
-    const int first_m = band * GROUP_M;
-    const int rows = tiles_m - first_m < GROUP_M ? tiles_m - first_m : GROUP_M;
-    const int in_band = tile - band * GROUP_M * tiles_n;
-    tm_i = first_m + in_band % rows;
-    tn_i = in_band / rows;
-  } else {
-    tm_i = tile / tiles_n;
-    tn_i = tile % tiles_n;
-  }
-  const int64_t m0 = (int64_t)tm_i * BM5;
-  const int64_t n0 = (int64_t)tn_i * BN5;
-#ifdef SL_GEMM_CLOCKPROBE  // tools/native/clock_probe.hip
-  const unsigned long long probe_c0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
-
-  floatx16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  // ---- LDS-DMA plan.  Piece q of a stage: 0 = B rows 0-127, 1 = B rows 128-255, 2 = A rows {0-63, 128-191} (ih = 0 of
-  // both wave groups), 3 = A rows {64-127, 192-255}.  Wave w moves row groups 2 w and 2 w + 1 (8 rows each) of a piece.
-  // Lane L lands in row L >> 3 of its group, slot L & 7, and fetches chunk (L & 7) ^ ((row >> 1) & 7) of the row's line.
-  int64_t src[4][2];  // element offset of this lane's chunk in the first k-tile
-  int dst[4][2];      // wave-uniform LDS byte offset of the row group inside a stage
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const int rg = w * 2 + g;  // 0..15
-      int row0;
-      if (q < 2) row0 = q * 128 + rg * 8;
-      else row0 = (rg < 8 ? rg * 8 : 128 + (rg - 8) * 8) + (q - 2) * 64;
-      const int row = row0 + (lane >> 3);
-      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-      if (q < 2) {
-        src[q][g] = (n0 + row < N ? n0 + row : N - 1) * 2 * Kp + chunk * 8;  // rows past the edge are clamped (never stored)
-        dst[q][g] = IMG5_BYTES + row0 * 128;
-      } else {
-        src[q][g] = (m0 + row < M ? m0 + row : M - 1) * 2 * Kp + chunk * 8;
-        dst[q][g] = row0 * 128;
-      }
-    }
-  typedef __attribute__((address_space(3))) void lds_void;
-  typedef const __attribute__((address_space(1))) void glb_void;
-  const int npieces = (int)(Kp / 32) * 4;
-  // piece n = 4 stage + q -> ring slot (stage & 1, q)
-  auto issue = [&](int stage, auto Qc, int g_lo = 0, int g_hi = 2) __attribute__((always_inline)) {
-    constexpr int q = decltype(Qc)::value;
-    const uint16_t* base = q < 2 ? B : A;
-    unsigned char* l = smem + (stage & 1) * STAGE5_BYTES;
-#pragma unroll
-    for (int g = g_lo; g < ((ABLATE & 32) ? 1 : g_hi); ++g) {
-      if (ABLATE & 64)
-        __builtin_amdgcn_global_load_lds((glb_void*)(base + src[q][g] + (int64_t)stage * 64), (lds_void*)(l + dst[q][g]), 4, 0, 0);
-      else
-        __builtin_amdgcn_global_load_lds((glb_void*)(base + src[q][g] + ((ABLATE & 16) ? (int64_t)0 : (int64_t)stage * 64)),
-                                         (lds_void*)(l + dst[q][g]), 16, 0, 0);
-    }
-  };
-
-  // ---- fragment addresses: hi chunk of k-step 0 for this lane; k-step 1 is the address ^ 32, the lo half ^ 64
-  int a_addr[4], b_addr[2];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int ar = wr * 128 + t * 32 + li;
-    a_addr[t] = ar * 128 + ((lh ^ ((ar >> 1) & 7)) << 4);
-  }
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int br = wc * 64 + t * 32 + li;
-    b_addr[t] = IMG5_BYTES + br * 128 + ((lh ^ ((br >> 1) & 7)) << 4);
-  }
-  bf16x8 bh[2][2], bl[2][2];  // [ks][j]: B fragments of the whole stage
-  bf16x8 ah[2], al[2];        // A fragments of the current phase
-
-  auto raw_barrier = [&]() __attribute__((always_inline)) {
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(ABLATE & 4)) __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  // one phase; P = 1..4, TAIL: the stage is one of the last two (pieces to issue may not exist, waits are exact)
-  auto phase = [&](int stage, auto Pc, auto Tc) __attribute__((always_inline)) {
-    constexpr int P = decltype(Pc)::value;
-    constexpr bool TAIL = decltype(Tc)::value != 0;
-    constexpr int ih = (P - 1) >> 1, ks = (P - 1) & 1;
-    const unsigned char* buf = smem + (stage & 1) * STAGE5_BYTES;
-    // ---- read slot: A fragments of this phase; the B fragments a stage needs are spread over the two phases whose MFMAs
-    // do not use the registers being refilled (k-step 1 of this stage in phase 1, k-step 0 of the NEXT stage in phase 4):
-    // 8 / 4 / 4 / 8 ds_read_b128 per phase.  (All 12 B + A reads of a stage in phase 1 made that slot LDS-bandwidth
-    // bound: 4 waves x 12 KB = 384 cycles at 128 B/clk, 455 cycles per slot on average instead of 384.)
-    if (P == 1 && !(ABLATE & 2)) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        bh[1][j] = *reinterpret_cast<const bf16x8*>(buf + (b_addr[j] ^ 32));
-        bl[1][j] = *reinterpret_cast<const bf16x8*>(buf + (b_addr[j] ^ 32 ^ 64));
-      }
-    }
-    if (!(ABLATE & 2)) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        ah[t] = *reinterpret_cast<const bf16x8*>(buf + (a_addr[2 * ih + t] ^ (ks * 32)));
-        al[t] = *reinterpret_cast<const bf16x8*>(buf + (a_addr[2 * ih + t] ^ (ks * 32) ^ 64));
-      }
-    } else {  // keep the stale fragments live and opaque so the MFMAs are not folded
-      asm volatile("" : "+v"(ah[0]), "+v"(ah[1]), "+v"(al[0]), "+v"(al[1]));
-    }
-    if (P == 4 && !(ABLATE & 2) && (!TAIL || stage + 1 < (int)(Kp / 32))) {
-      const unsigned char* nbuf = smem + ((stage + 1) & 1) * STAGE5_BYTES;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        bh[0][j] = *reinterpret_cast<const bf16x8*>(nbuf + b_addr[j]);
-        bl[0][j] = *reinterpret_cast<const bf16x8*>(nbuf + (b_addr[j] ^ 64));
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const int g = stage * 4 + P;  // global phase number; issues piece g + LOOK
-    // What phase g + 1 reads must have landed for every wave before this phase's barrier.  `need` = youngest such piece;
-    // pieces need + 1 .. g + LOOK - 1 (issued so far) may stay in flight.
-    if (P == 2 || P == 3 || P == 4) {
-      // P == 2: A1 of this stage (piece g + 1); P == 3: B0, B1 of the next stage (up to piece g + 2);
-      // P == 4: A0 of the next stage (piece g + 2)
-      constexpr int younger = P == 2 ? LOOK - 2 : LOOK - 3;
-      const int need = P == 2 ? g + 1 : g + 2;
-      if (ABLATE & 8) {
-      } else if (!TAIL) {
-        wait_vm_pieces(younger);  // compile-time constant: a single s_waitcnt
-      } else {
-        const int have = npieces - 1 - need;
-        wait_vm_pieces(have < younger ? (have < 0 ? 0 : have) : younger);
-      }
-    }
-    constexpr int q = (P + LOOK) & 3;               // which piece of its stage
-    const int pstage = stage + ((P + LOOK) >> 2);   // and which stage
-    const bool do_issue = !(ABLATE & 1) && (!TAIL || pstage * 4 + q < npieces);
-    if (DMAPOS == 0 && do_issue) issue(pstage, IntC<q>());
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments in registers; this phase's LDS reads are retired
-    raw_barrier();
-    // ---- MFMA slot.  Order: per accumulator still lo*hi, hi*lo, hi*hi (bit-identical to kernels 1-3), but the A operand
-    // changes only four times per phase and dependent MFMAs are two apart.  The closing barrier sits EARLY MFMAs before
-    // the end of the slot: the other group is released while this wave still has work queued on the matrix pipe, so the
-    // barrier's release latency (~70 cycles per slot when it followed the last MFMA) is covered.
-    __builtin_amdgcn_s_setprio(1);
-#define SL_G5_MFMA(a, b, t, j) acc[2 * ih + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[2 * ih + t][j], 0, 0, 0)
-#define SL_G5_DMA(g)                                  \
-  do {                                                \
-    __builtin_amdgcn_sched_barrier(0);                \
-    if (do_issue) issue(pstage, IntC<q>(), g, g + 1); \
-    __builtin_amdgcn_sched_barrier(0);                \
-  } while (0)
-    SL_G5_MFMA(al[0], bh[ks][0], 0, 0);
-    SL_G5_MFMA(al[0], bh[ks][1], 0, 1);
-    if (DMAPOS == 2) SL_G5_DMA(0);
-    SL_G5_MFMA(al[1], bh[ks][0], 1, 0);
-    if (DMAPOS == 2) SL_G5_DMA(1);
-    SL_G5_MFMA(al[1], bh[ks][1], 1, 1);
-    if (DMAPOS == 1) SL_G5_DMA(0);
-    SL_G5_MFMA(ah[0], bl[ks][0], 0, 0);
-    SL_G5_MFMA(ah[0], bl[ks][1], 0, 1);
-    SL_G5_MFMA(ah[0], bh[ks][0], 0, 0);
-    SL_G5_MFMA(ah[0], bh[ks][1], 0, 1);
-    if (DMAPOS == 1) SL_G5_DMA(1);
-    if (EARLY == 4) raw_barrier();
-    SL_G5_MFMA(ah[1], bl[ks][0], 1, 0);
-    if (EARLY == 3) raw_barrier();
-    SL_G5_MFMA(ah[1], bl[ks][1], 1, 1);
-    if (EARLY == 2) raw_barrier();
-    SL_G5_MFMA(ah[1], bh[ks][0], 1, 0);
-    if (EARLY == 1) raw_barrier();
-    SL_G5_MFMA(ah[1], bh[ks][1], 1, 1);
-#undef SL_G5_MFMA
-#undef SL_G5_DMA
-    if (EARLY == 0) {
-      __builtin_amdgcn_s_setprio(0);
-      raw_barrier();
-    } else {
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(0);
-    }
-  };
-  auto run_stage = [&](int stage, auto Tc) __attribute__((always_inline)) {
-    phase(stage, IntC<1>(), Tc);
-    phase(stage, IntC<2>(), Tc);
-    phase(stage, IntC<3>(), Tc);
-    phase(stage, IntC<4>(), Tc);
-  };
-
-  const int ns = (int)(Kp / 32);
-#ifdef SL_GEMM_CLOCKPROBE
-  unsigned long long probe_c1 = 0;
-#endif
-  if (ns > 0) {
-    // prologue ("phase 0"): pieces 0..LOOK, then B0, B1, A0 of stage 0 must have landed
-    static_assert(LOOK >= 3 && LOOK <= 6, "LOOK");
-    issue(0, IntC<0>());
-    issue(0, IntC<1>());
-    issue(0, IntC<2>());
-    issue(0, IntC<3>());
-    if (ns > 1) {
-      if (LOOK >= 4) issue(1, IntC<0>());
-      if (LOOK >= 5) issue(1, IntC<1>());
-      if (LOOK >= 6) issue(1, IntC<2>());
-    }
-    wait_vm_pieces(ns > 1 ? LOOK - 2 : 1);
-    raw_barrier();
-#ifdef SL_GEMM_CLOCKPROBE
-    probe_c1 = __builtin_amdgcn_s_memtime();
-#endif
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {  // B fragments of k-step 0 of stage 0 (later stages: phase 4 of the stage before)
-      bh[0][j] = *reinterpret_cast<const bf16x8*>(smem + b_addr[j]);
-      bl[0][j] = *reinterpret_cast<const bf16x8*>(smem + (b_addr[j] ^ 64));
-    }
-    if (wr == 1) raw_barrier();  // group 1 runs one barrier behind
-    int s = 0;
-    for (; s + 2 <= ns - 2; s += 2) {
-      run_stage(s, IntC<0>());
-      run_stage(s + 1, IntC<0>());
-    }
-    for (; s < ns; ++s) run_stage(s, IntC<1>());
-    if (wr == 0) raw_barrier();
-  }
-#ifdef SL_GEMM_CLOCKPROBE
-  const unsigned long long probe_c2 = __builtin_amdgcn_s_memtime();
-#endif
-
-  // interior tiles (all but the last band / column of tiles) store without per-element predicates: the predicated form
-  // costs ~10 VALU/branch instructions per 4-byte store and made the epilogue 7 % of a tile (VALU-bound, not store-bound)
-  if (m0 + BM5 <= M && n0 + BN5 <= N) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int64_t col = n0 + wc * 64 + j * 32 + li;
-        const float cv = epi.column(col);
-        const int64_t row_base = m0 + wr * 128 + i * 32 + 4 * lh;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) epi.store(row_base + ((r & 3) + 8 * (r >> 2)), col, acc[i][j][r], cv);
-      }
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int64_t col = n0 + wc * 64 + j * 32 + li;
-        const float cv = col < N ? epi.column(col) : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t row = m0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (row < M && col < N) epi.store(row, col, acc[i][j][r], cv);
-        }
-      }
-    }
-  }
-#ifdef SL_GEMM_CLOCKPROBE
-  if (tid == 0) {
-    epi.probe[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - probe_c0;
-    epi.probe[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - probe_r0;
-    epi.probe[131072 + 2 * blockIdx.x] = probe_c1 - probe_c0;      // prologue: first pieces landed
-    epi.probe[131072 + 2 * blockIdx.x + 1] = probe_c2 - probe_c1;  // k loop
-  }
-#endif
-}
-
 inline int launch_split(const float* x, const float* scale, int64_t R, int64_t K, uint16_t* sp, hipStream_t st) {
   int64_t blocks = (R * split_kp(K) + 255) / 256;
   const int64_t cap = (int64_t)num_cus() * 16;
@@ -894,22 +559,17 @@ int launch_gemm3_nt(ProfScope& prof, const uint16_t* A, int64_t M, const uint16_
     const char* e = getenv("SL_G3_TILE");
     return e ? atoi(e) : 0;
   }();
-  static const int min8 = [] {  // kernel 4 from this many 256 x 256 tiles per CU (in percent) upwards
-    const char* e = getenv("SL_G3_MIN8_PCT");
-    return e ? atoi(e) : 50;  // encoder GEMMs (150-600 tiles): ViT-B/32 image encode 9.66 ms without kernel 4, 9.08 at 50 %
-  }();
   const int64_t tm3 = (M + BM3 - 1) / BM3;
-  const int64_t tm5 = (M + BM5 - 1) / BM5, tn5 = (N + BN5 - 1) / BN5;
+  const int64_t tn4 = (N + BN4 - 1) / BN4;
   if (forced == 512) {
-    SL_LAUNCH(prof, (gemm3_nt_pingpong_kernel<Epi>), dim3((unsigned)(tm3 * tn5)), dim3(512), 0, st, A, B, M, N, Kp, (int)tn5, epi);
+    SL_LAUNCH(prof, (gemm3_nt_pingpong_kernel<Epi>), dim3((unsigned)(tm3 * tn4)), dim3(512), 0, st, A, B, M, N, Kp, (int)tn4, epi);
     SL_CHECK_HIP(hipGetLastError());
     return 0;
   }
-  const bool k4 = forced ? forced == 8 : tm5 * tn5 * 100 >= (int64_t)min8 * num_cus();
+  const bool k4 = gemm8::fits(M, N, 4 * Kp) && (forced ? forced == 8 : gemm8::worth_it(M, N));
   const bool k2 = forced ? forced == 256 : tm3 * tn >= (int64_t)8 * num_cus();
-  if (k4)  // XCD-banded tile order, DMA issued inside the MFMA slot
-    SL_LAUNCH(prof, (gemm3_nt_8phase_kernel<Epi, 1, 0, 0, 6, 2>), dim3((unsigned)(tm5 * tn5)), dim3(512), 0, st, A, B, M, N, Kp, (int)tm5,
-              (int)tn5, epi);
+  if (k4)  // gemm_8phase.hpp; a row of a split matrix is 2 Kp bf16 = 4 Kp bytes, one 128-byte line per k-tile
+    return gemm8::launch<gemm8::MODE_BF16X3>(prof, A, M, B, N, 4 * Kp, Kp / 32, epi, st);
   else if (k2)
     SL_LAUNCH(prof, (gemm3_nt_dma256_kernel<Epi>), dim3((unsigned)(tm3 * tn)), dim3(256), 0, st, A, B, M, N, Kp, (int)tn, epi);
   else

@@ -10,7 +10,10 @@
 // The K tail is peeled out of the steady-state loop; rows past the matrix edge are clamped onto the last row
 // (their products land in outputs the epilogue never stores).
 #pragma once
+#include <cstdlib>
+
 #include "common.hpp"
+#include "gemm_8phase.hpp"
 
 namespace sl {
 namespace gemm {
@@ -53,8 +56,8 @@ __device__ inline void store_tile_lds(float* __restrict__ s, int tid, const floa
   }
 }
 
-// Epi: struct with  float column(int64_t col) const  (per-column value, loaded once per 16 rows) and
-//                   void store(int64_t row, int64_t col, float acc, float colval) const
+// Epi: struct with  T column(int64_t col) const  (per-column value — a float or a small default-constructible struct —
+//                   loaded once per 16 rows) and  void store(int64_t row, int64_t col, float acc, T colval) const
 template <bool VEC, class Epi>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, const float* __restrict__ B, int64_t M,
                                                        int64_t N, int64_t K, int tiles_n, Epi epi) {
@@ -172,7 +175,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int64_t col = n0 + wn * 64 + j * 32 + li;
-      const float cv = col < N ? epi.column(col) : 0.f;
+      decltype(epi.column(col)) cv{};  // float, or a small struct (cosine.hip MultiCosineEpi)
+      if (col < N) cv = epi.column(col);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -195,6 +199,14 @@ int launch_gemm_nt(ProfScope& prof, const float* A, int64_t M, const float* B, i
   SL_REQUIRE(tm * tn < (1ll << 31), "GEMM: too many tiles");
   if (tm * tn == 0) return 0;
   const bool vec = (K % 4 == 0) && (((uintptr_t)A | (uintptr_t)B) & 15) == 0;
+  // Large grids whose rows are whole 128-byte lines: the 256 x 256 8-phase kernel (gemm_8phase.hpp), same bits.
+  // SL_F32_TILE=128 / 8 forces one of the two (tests).
+  static const int forced = [] {
+    const char* e = getenv("SL_F32_TILE");
+    return e ? atoi(e) : 0;
+  }();
+  if (vec && K % 32 == 0 && K > 0 && gemm8::fits(M, N, K * 4) && (forced ? forced == 8 : gemm8::worth_it(M, N)))
+    return gemm8::launch<gemm8::MODE_F32>(prof, A, M, B, N, K * 4, K / 32, epi, st);
   if (vec)
     SL_LAUNCH(prof, (gemm_nt_kernel<true, Epi>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, A, B, M, N, K, (int)tn, epi);
   else

@@ -569,6 +569,15 @@ def test_fused_multi_layer_probe_equals_per_layer_similarity():
                     assert torch.equal(o, N.similarity(q, y)), (mode, y.shape)
                     ref = oracle.similarity(q.cpu().numpy(), y.cpu().numpy())
                     assert np.abs(o.cpu().numpy() - ref).max() < 1e-5
+        # large enough that the fp32 mode gathers the layers into one operand for the 256 x 256 8-phase kernel
+        # (16 x 13 tiles fused; no single layer would fill half the chip) — still bit-identical to layer by layer
+        q2 = torch.randn(4096, 256, device=DEV)
+        ys2 = [torch.randn(c, 256, device=DEV) for c in (768, 1024, 1300, 5)]
+        for mode in ("bf16x3", "f32"):
+            N.set_gemm_mode(mode)
+            for y, o in zip(ys2, N.similarity_multi(q2, ys2)):
+                assert torch.equal(o, N.similarity(q2, y)), (mode, y.shape)
+                assert np.abs(o.cpu().numpy() - oracle.similarity(q2.cpu().numpy(), y.cpu().numpy())).max() < 1e-5
     finally:
         N.set_gemm_mode(None)
     # a layer that would hit a shape quirk makes the native call decline (the caller goes layer by layer)
@@ -609,3 +618,12 @@ torch.save(outs, sys.argv[1])
     for other in ("256", "512", "8"):
         for a, b in zip(res["128"], res[other]):
             assert torch.equal(a, b), (other, tuple(a.shape))
+    # the fp32-MFMA mode has two tile variants too (128 x 128 register-staged, 256 x 256 8-phase): same bits
+    f32 = {}
+    for tile in ("128", "8"):
+        out = tmp_path / f"f32_{tile}.pt"
+        subprocess.run([sys.executable, "-c", code, str(out), root], check=True,
+                       env=dict(os.environ, SL_GEMM_MODE="f32", SL_F32_TILE=tile))
+        f32[tile] = torch.load(out)
+    for a, b in zip(f32["128"], f32["8"]):
+        assert torch.equal(a, b), ("f32", tuple(a.shape))

@@ -11,6 +11,7 @@
 #include <random>
 #include <vector>
 #include "gemm_bf16x3.hpp"
+#include "gemm_f32.hpp"
 
 namespace sl {
 void set_error(const char*, ...) {}
@@ -60,36 +61,28 @@ int main(int argc, char** argv) {
 
   const int64_t tm3 = (M + 255) / 256, tn = (N + 127) / 128, tn5 = (N + 255) / 256;
   struct Variant { const char* name; int id; };
-  std::vector<Variant> vs = {{"dma256 (kernel 2)", 0}, {"pingpong (kernel 3)", 1}, {"8phase early0", 2}, {"8phase xcd early0", 3},
-                             {"8phase dma in M (4,8)", 18}, {"8phase dma in M (2,3)", 19}, {"ablate: no dma", 7}};
-  const size_t n_checked = 6;  // variants after this index compute garbage on purpose
+  std::vector<Variant> vs = {{"bf16x3 dma256 (k2)", 0}, {"bf16x3 pingpong (k3)", 1}, {"bf16x3 8phase", 2}, {"bf16x3 8phase no-dma", 3},
+                             {"f32 128x128", 4}, {"f32 8phase", 5}};
+  const size_t n_checked = 3;  // bf16x3 variants compared bit for bit against kernel 2 (f32: compared with each other below)
 #ifdef SL_GEMM_CLOCKPROBE
   unsigned long long* probe; CK(hipMalloc(&probe, 8 * 4 * 131072)); CK(hipMemset(probe, 0, 8 * 4 * 131072));
 #endif
+  const int64_t tm1 = (M + 127) / 128, tn1 = (N + 127) / 128;
+  const int64_t grid8 = tm3 * tn5;
   auto launch = [&](int id, float* out) {
 #ifdef SL_GEMM_CLOCKPROBE
     PlainEpi epi{out, N, probe};
 #else
     PlainEpi epi{out, N};
 #endif
+    const unsigned char *bA = (const unsigned char*)sA, *bB = (const unsigned char*)sB;
     switch (id) {
       case 0: hipLaunchKernelGGL((gemm3_nt_dma256_kernel<PlainEpi>), dim3((unsigned)(tm3 * tn)), dim3(256), 0, nullptr, sA, sB, M, N, Kp, (int)tn, epi); break;
       case 1: hipLaunchKernelGGL((gemm3_nt_pingpong_kernel<PlainEpi>), dim3((unsigned)(tm3 * tn5)), dim3(512), 0, nullptr, sA, sB, M, N, Kp, (int)tn5, epi); break;
-      case 2: hipLaunchKernelGGL((gemm3_nt_8phase_kernel<PlainEpi, 0, 0>), dim3((unsigned)(tm3 * tn5)), dim3(512), 0, nullptr, sA, sB, M, N, Kp, (int)tm3, (int)tn5, epi); break;
-      case 3: hipLaunchKernelGGL((gemm3_nt_8phase_kernel<PlainEpi, 1, 0>), dim3((unsigned)(tm3 * tn5)), dim3(512), 0, nullptr, sA, sB, M, N, Kp, (int)tm3, (int)tn5, epi); break;
-      case 7: hipLaunchKernelGGL((gemm3_nt_8phase_kernel<PlainEpi, 1, 0, 1>), dim3((unsigned)(tm3 * tn5)), dim3(512), 0, nullptr, sA, sB, M, N, Kp, (int)tm3, (int)tn5, epi); break;
-      case 8: hipLaunchKernelGGL((gemm3_nt_8phase_kernel<PlainEpi, 1, 0, 2>), dim3((unsigned)(tm3 * tn5)), dim3(512), 0, nullptr, sA, sB, M, N, Kp, (int)tm3, (int)tn5, epi); break;
-      case 9: hipLaunchKernelGGL((gemm3_nt_8phase_kernel<PlainEpi, 1, 0, 4>), dim3((unsigned)(tm3 * tn5)), dim3(512), 0, nullptr, sA, sB, M, N, Kp, (int)tm3, (int)tn5, epi); break;
-      case 11: hipLaunchKernelGGL((gemm3_nt_8phase_kernel<PlainEpi, 1, 0, 8>), dim3((unsigned)(tm3 * tn5)), dim3(512), 0, nullptr, sA, sB, M, N, Kp, (int)tm3, (int)tn5, epi); break;
-      case 12: hipLaunchKernelGGL((gemm3_nt_8phase_kernel<PlainEpi, 1, 0, 16>), dim3((unsigned)(tm3 * tn5)), dim3(512), 0, nullptr, sA, sB, M, N, Kp, (int)tm3, (int)tn5, epi); break;
-      case 13: hipLaunchKernelGGL((gemm3_nt_8phase_kernel<PlainEpi, 1, 0, 0, 5>), dim3((unsigned)(tm3 * tn5)), dim3(512), 0, nullptr, sA, sB, M, N, Kp, (int)tm3, (int)tn5, epi); break;
-      case 14: hipLaunchKernelGGL((gemm3_nt_8phase_kernel<PlainEpi, 1, 0, 0, 4>), dim3((unsigned)(tm3 * tn5)), dim3(512), 0, nullptr, sA, sB, M, N, Kp, (int)tm3, (int)tn5, epi); break;
-      case 15: hipLaunchKernelGGL((gemm3_nt_8phase_kernel<PlainEpi, 1, 0, 0, 3>), dim3((unsigned)(tm3 * tn5)), dim3(512), 0, nullptr, sA, sB, M, N, Kp, (int)tm3, (int)tn5, epi); break;
-      case 16: hipLaunchKernelGGL((gemm3_nt_8phase_kernel<PlainEpi, 1, 0, 8 + 32>), dim3((unsigned)(tm3 * tn5)), dim3(512), 0, nullptr, sA, sB, M, N, Kp, (int)tm3, (int)tn5, epi); break;
-      case 17: hipLaunchKernelGGL((gemm3_nt_8phase_kernel<PlainEpi, 1, 0, 8 + 64>), dim3((unsigned)(tm3 * tn5)), dim3(512), 0, nullptr, sA, sB, M, N, Kp, (int)tm3, (int)tn5, epi); break;
-      case 18: hipLaunchKernelGGL((gemm3_nt_8phase_kernel<PlainEpi, 1, 0, 0, 6, 1>), dim3((unsigned)(tm3 * tn5)), dim3(512), 0, nullptr, sA, sB, M, N, Kp, (int)tm3, (int)tn5, epi); break;
-      case 19: hipLaunchKernelGGL((gemm3_nt_8phase_kernel<PlainEpi, 1, 0, 0, 6, 2>), dim3((unsigned)(tm3 * tn5)), dim3(512), 0, nullptr, sA, sB, M, N, Kp, (int)tm3, (int)tn5, epi); break;
-      case 10: hipLaunchKernelGGL((gemm3_nt_8phase_kernel<PlainEpi, 1, 0, 7>), dim3((unsigned)(tm3 * tn5)), dim3(512), 0, nullptr, sA, sB, M, N, Kp, (int)tm3, (int)tn5, epi); break;
+      case 2: hipLaunchKernelGGL((sl::gemm8::gemm_nt_8phase_kernel<0, PlainEpi>), dim3((unsigned)grid8), dim3(512), 0, nullptr, bA, bB, M, N, 4 * Kp, (int)(Kp / 32), (int)tm3, (int)tn5, epi); break;
+      case 3: hipLaunchKernelGGL((sl::gemm8::gemm_nt_8phase_kernel<0, PlainEpi, true>), dim3((unsigned)grid8), dim3(512), 0, nullptr, bA, bB, M, N, 4 * Kp, (int)(Kp / 32), (int)tm3, (int)tn5, epi); break;
+      case 4: hipLaunchKernelGGL((sl::gemm::gemm_nt_kernel<true, PlainEpi>), dim3((unsigned)(tm1 * tn1)), dim3(256), 0, nullptr, dA, dB, M, N, K, (int)tn1, epi); break;
+      case 5: hipLaunchKernelGGL((sl::gemm8::gemm_nt_8phase_kernel<1, PlainEpi>), dim3((unsigned)grid8), dim3(512), 0, nullptr, (const unsigned char*)dA, (const unsigned char*)dB, M, N, K * 4, (int)(K / 32), (int)tm3, (int)tn5, epi); break;
     }
     CK(hipGetLastError());
   };
@@ -121,6 +114,20 @@ int main(int argc, char** argv) {
       printf("\n");
     }
   }
+  if (K % 32 == 0) {
+    launch(4, out0);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(h0.data(), out0, M * N * 4, hipMemcpyDeviceToHost));
+    for (int rep = 0; rep < 3; ++rep) {
+      CK(hipMemset(out1, 0xff, M * N * 4));
+      launch(5, out1);
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy(h1.data(), out1, M * N * 4, hipMemcpyDeviceToHost));
+      size_t bad = 0;
+      for (size_t i = 0; i < h0.size(); ++i) bad += memcmp(&h0[i], &h1[i], 4) != 0;
+      printf("f32 8phase             run %d: %zu / %zu elements differ from the f32 128x128 kernel\n", rep, bad, h0.size());
+    }
+  }
   // ---- timing: interleaved rounds --------------------------------------------------------------------------------------
   const int reps = 20;
   std::vector<std::vector<double>> tf(vs.size());
@@ -137,18 +144,21 @@ int main(int argc, char** argv) {
       tf[v].push_back(2.0 * M * N * K * reps / (ms * 1e-3) / 1e12);
 #ifdef SL_GEMM_CLOCKPROBE
       if (round == rounds - 1) {  // per-workgroup shader cycles (s_memtime) against the 100 MHz constant clock of the last launch
-        const int64_t nblk = vs[v].id == 0 ? tm3 * tn : tm3 * tn5;
+        if (vs[v].id == 4) continue;
+        const bool k8 = vs[v].id == 2 || vs[v].id == 3 || vs[v].id == 5;
+        const int64_t nblk = vs[v].id == 0 ? tm3 * tn : (k8 ? grid8 : tm3 * tn5);
+        const int64_t ntile = vs[v].id == 0 ? tm3 * tn : tm3 * tn5;
         std::vector<unsigned long long> hs(2 * nblk); CK(hipMemcpy(hs.data(), probe, 16 * nblk, hipMemcpyDeviceToHost));
-        double cyc = 0, rt = 0; for (int64_t b = 0; b < nblk; ++b) { cyc += (double)hs[2 * b]; rt += (double)hs[2 * b + 1]; }
-        const double mfma_cycles = (vs[v].id == 0 ? 0.5 : 1.0) * (double)(Kp / 32) * 8 * 384;  // matrix-pipe cycles per SIMD a workgroup needs
-        printf("%-22s per workgroup: %.0f shader cycles (%.2f us), clock %.0f MHz, MFMA cycles needed per SIMD %.0f -> in-tile duty %.3f%s\n",
-               vs[v].name, cyc / nblk, rt / nblk / 100.0, cyc / rt * 100.0, mfma_cycles, mfma_cycles / (cyc / nblk) * (vs[v].id == 0 ? 2 : 1),
-               vs[v].id == 0 ? " (two workgroups per CU)" : "");
-        if (vs[v].id >= 2) {
+        double cyc = 0, rt = 0, cmax = 0; for (int64_t b = 0; b < nblk; ++b) { cyc += (double)hs[2 * b]; rt += (double)hs[2 * b + 1]; cmax = std::max(cmax, (double)hs[2 * b]); }
+        // matrix-pipe cycles per SIMD one tile needs (a 256 x 128 tile of kernel 2 shares its CU with a second workgroup)
+        const double mfma_cycles = (double)(Kp / 32) * 8 * (vs[v].id == 5 ? 2048 : 384) * (vs[v].id == 0 ? 0.25 : 1.0);
+        printf("%-22s %lld workgroups, %lld tiles: %.0f shader cycles per tile (longest workgroup %.0f), clock %.0f MHz, in-tile matrix-pipe duty %.3f\n",
+               vs[v].name, (long long)nblk, (long long)ntile, cyc / ntile, cmax, cyc / rt * 100.0, mfma_cycles * ntile / cyc);
+        if (k8) {
           std::vector<unsigned long long> hp(2 * nblk); CK(hipMemcpy(hp.data(), probe + 131072, 16 * nblk, hipMemcpyDeviceToHost));
           double pro = 0, loop = 0; for (int64_t b = 0; b < nblk; ++b) { pro += (double)hp[2 * b]; loop += (double)hp[2 * b + 1]; }
-          printf("%-22s   prologue %.0f cycles, k loop %.0f (%.1f per slot; 384 = matrix pipe never idle), epilogue %.0f\n", vs[v].name, pro / nblk,
-                 loop / nblk, loop / nblk / ((double)(Kp / 32) * 8), cyc / nblk - pro / nblk - loop / nblk);
+          printf("%-22s   first tile of a workgroup: prologue %.0f cycles, k loop %.0f (%.1f per slot; %d = matrix pipe never idle)\n", vs[v].name,
+                 pro / nblk, loop / nblk, loop / nblk / ((double)(Kp / 32) * 8), vs[v].id == 5 ? 2048 : 384);
         }
       }
 #endif
@@ -156,8 +166,9 @@ int main(int argc, char** argv) {
   printf("M=%lld N=%lld K=%lld, %d rounds x %d launches, normalised random operands\n", (long long)M, (long long)N, (long long)K, rounds, reps);
   for (size_t v = 0; v < vs.size(); ++v) {
     std::sort(tf[v].begin(), tf[v].end());
-    printf("%-22s TFLOP/s algorithmic: median %.1f  min %.1f  max %.1f   (x3 issued: %.0f, frac of 833: %.3f)\n", vs[v].name,
-           tf[v][tf[v].size() / 2], tf[v].front(), tf[v].back(), 3 * tf[v][tf[v].size() / 2], tf[v][tf[v].size() / 2] / 833.3);
+    const bool f32 = vs[v].id >= 4;
+    printf("%-22s TFLOP/s algorithmic: median %.1f  min %.1f  max %.1f   (frac of %s: %.3f)\n", vs[v].name, tf[v][tf[v].size() / 2],
+           tf[v].front(), tf[v].back(), f32 ? "157.3" : "833.3", tf[v][tf[v].size() / 2] / (f32 ? 157.3 : 833.3));
   }
   return 0;
 }
