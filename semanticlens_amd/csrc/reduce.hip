@@ -305,7 +305,41 @@ __device__ inline float group_allreduce_asm(float v) {
   return v;
 }
 
+// Row-broadcast steps of a wave64 reduction (gfx9 DPP): row_bcast:15 folds the last lane of rows 0 / 2 into rows 1 / 3,
+// row_bcast:31 folds lane 31 into rows 2 and 3.  In-place (rows that are masked out keep their value).  After the
+// within-16 all-reduce plus these, lane 31 (G = 32: and lane 63) / lane 63 (G = 64) holds the group's result — without
+// the two ds_bpermute round trips (~200 dependent cycles per row) that __shfl_xor costs.
+#define SL_DPP_BCAST(name, insn, ctrl, mask)                                                              \
+  __device__ inline float name(float a) {                                                                 \
+    asm("s_nop 1\n\t" insn " %0, %0, %0 " ctrl " row_mask:" mask " bank_mask:0xf" : "+v"(a));            \
+    return a;                                                                                             \
+  }
+SL_DPP_BCAST(max_bc15, "v_max_f32_dpp", "row_bcast:15", "0xa")
+SL_DPP_BCAST(max_bc31, "v_max_f32_dpp", "row_bcast:31", "0xc")
+SL_DPP_BCAST(add_bc15, "v_add_f32_dpp", "row_bcast:15", "0xa")
+SL_DPP_BCAST(add_bc31, "v_add_f32_dpp", "row_bcast:31", "0xc")
+#undef SL_DPP_BCAST
+
+// all-reduce over aligned groups of G lanes whose result every lane of the group needs: DPP within 16 lanes, then for
+// G = 32 / 64 row broadcasts + v_readlane (the value comes back wave-uniform per group)
+template <int G, bool SUMOP>
+__device__ inline float group_allreduce_bcast(float v, int lane) {
+  if constexpr (G <= 16) return group_allreduce_asm<G, SUMOP>(v);
+  v = group_allreduce_asm<16, SUMOP>(v);
+  v = SUMOP ? add_bc15(v) : max_bc15(v);
+  if constexpr (G == 64) {
+    v = SUMOP ? add_bc31(v) : max_bc31(v);
+    return bits_f32((uint32_t)__builtin_amdgcn_readlane((int)f32_bits(v), 63));
+  } else {
+    const float lo = bits_f32((uint32_t)__builtin_amdgcn_readlane((int)f32_bits(v), 31));
+    const float hi = bits_f32((uint32_t)__builtin_amdgcn_readlane((int)f32_bits(v), 63));
+    return lane < 32 ? lo : hi;
+  }
+}
+
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef SL_BIG_U
 #define SL_BIG_U 4
 #endif
@@ -440,8 +474,196 @@ __global__ __launch_bounds__(256) void rowreduce_fast_kernel(const float* __rest
   }
 }
 
+// ---- rowreduce_dma: the same row arithmetic fed through a wave-private LDS ring ----------------------------------
+// rowreduce_fast maps G lanes onto a row and loads the row's 16-byte pieces straight into VGPRs, so a row of 49 (196, 784)
+// floats keeps 13 of 16 (49 of 64, 196 of 256) load lanes busy: ~23 % of every wave-load re-reads a clamped piece, and a
+// cold 103-411 MB input streamed at 5.4-6.1 TB/s.  Here the global side is decoupled from the row structure:
+//   * a *batch* (U tasks = U * 64 / G rows, <= 4 KiB, contiguous in memory) is fetched by up to four LDS-DMA
+//     instructions (global_load_lds_dwordx4, nt): 64 lanes x 16 consecutive bytes each, every lane useful, lanes past
+//     the batch masked off;
+//   * each wave owns TWO slots of exactly one batch each (dynamic LDS: 8 slots + 1 KiB per workgroup), which lets 5-8
+//     workgroups = 20-32 waves share a CU: one batch is in flight while one is reduced; counted `s_waitcnt vmcnt`; no
+//     barrier, the wave reads only what it fetched itself.  (tools/native/stream_lab.hip: a bare read-once stream
+//     reaches 6.6-6.85 TB/s through LDS-DMA, 6.5-6.7 through VGPR loads; occupancy, not ring depth, is what this
+//     kernel responds to: 12 waves x 3 slots 6.06 / 5.50 TB/s on the 411 / 206 MB inputs, 24 waves x 2 slots 6.37 / 5.88);
+//   * lanes then read their row's pieces with ds_read_b128 from the slot — masked / clamped lanes cost LDS bandwidth,
+//     of which the kernel uses ~10 %.
+// Arithmetic, NaN handling, rounding and the output packing are those of rowreduce_fast.
+#ifndef SL_REDUCE_LAB
+#define SL_REDUCE_LAB 0  // tools/native/reduce_lab.hip: 1 = no per-row reduce / store, 2 = no NaN-detector sum (garbage results)
+#endif
+constexpr int kDmaMaxBatch = 4096;  // bytes: four 1-KiB LDS-DMA instructions
+constexpr int kDmaDepth = 2;        // slots per wave: one batch in flight while one is reduced
+constexpr int kDmaLdsPerCu = 160 * 1024;
+
+template <int G, int U, int OP, bool ALIGNED>
+__global__ __launch_bounds__(256) void rowreduce_dma_kernel(const float* __restrict__ x, int64_t R, int S, int slot_bytes,
+                                                             int64_t tail_from, uint16_t* __restrict__ cand,
+                                                             float* __restrict__ outf) {
+  constexpr int RPT = kWave / G;
+  constexpr bool SUMOP = (OP == OP_SUM || OP == OP_ABSSUM);
+  constexpr bool ABS = (OP == OP_ABSMAX || OP == OP_ABSSUM);
+  extern __shared__ __align__(1024) unsigned char smem[];  // 4 waves x kDmaDepth slots of `slot_bytes` + 1 KiB (masked tail)
+  const float fill = SUMOP ? 0.f : -__builtin_huge_valf();
+  const int lane = threadIdx.x & 63;
+  const int li = lane & (G - 1);
+  const int g = lane / G;
+  const int64_t ntask = R / RPT;  // launcher guarantees R % RPT == 0
+  const int64_t nbatch = (ntask + U - 1) / U;
+  const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int npieces = ALIGNED ? S / 4 : (S + 6) / 4;
+  const int nsteps = ALIGNED ? (npieces + G - 1) / G : 1;
+  const int h = ALIGNED ? 0 : ((g * S) & 3);
+  const uint32_t row_byte0 = (uint32_t)(((g * S) >> 2) * 16);
+  const uint32_t task_bytes = (uint32_t)(RPT * S) * 4u;  // multiple of 16
+  const uint32_t batch_bytes = (uint32_t)U * task_bytes;  // <= slot_bytes <= kDmaMaxBatch
+  const int64_t total_bytes = R * (int64_t)S * 4;
+  const int pos0 = li * 4 - h;
+  const bool k0 = (unsigned)(pos0 + 0) < (unsigned)S, k1 = (unsigned)(pos0 + 1) < (unsigned)S;
+  const bool k2 = (unsigned)(pos0 + 2) < (unsigned)S, k3 = (unsigned)(pos0 + 3) < (unsigned)S;
+  unsigned char* ring = smem + wave_in_block * (kDmaDepth * slot_bytes);
+  unsigned char* spare = smem + 4 * kDmaDepth * slot_bytes;
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  const unsigned char* xb = reinterpret_cast<const unsigned char*>(x);
+
+  // batch tb of the tensor -> slot.  ALWAYS four instructions per batch, so the counted waits are compile-time
+  // constants and the loop has no data-dependent branches: lanes past the batch's bytes are masked; an instruction that
+  // would be empty (short batches; the tensor's last batch) keeps lane 0 alive on the batch's first 16 bytes.
+  constexpr int NI = kDmaMaxBatch / 1024;
+  auto issue = [&](int64_t tb, int slot) __attribute__((always_inline)) {
+    const int64_t off = tb * (int64_t)batch_bytes;
+    const int64_t left = total_bytes - off;
+    const uint32_t nb = left < (int64_t)batch_bytes ? (uint32_t)left : batch_bytes;
+    const unsigned char* src = xb + off;
+    unsigned char* d = ring + slot * slot_bytes;
+    // cache policy, wave-uniform per batch: streaming (nt) for bytes that come from HBM, default for the part of a
+    // just-written input that the Infinity Cache still holds (see launch_rowreduce_dma)
+    const bool stream = tb < tail_from;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const uint32_t byte = (uint32_t)i * 1024u + (uint32_t)lane * 16u;
+      const bool in = byte < nb;
+      // an instruction with no byte of the batch left still goes out (lane 0, the batch's first piece) but lands in the
+      // workgroup's spare KiB, not in a slot
+      unsigned char* dst_i = (uint32_t)i * 1024u < nb ? d + i * 1024 : spare;
+      if (in || lane == 0) {
+        if (stream) __builtin_amdgcn_global_load_lds((glb_void*)(src + (in ? byte : 0u)), (lds_void*)dst_i, 16, 0, 2 /* nt */);
+        else __builtin_amdgcn_global_load_lds((glb_void*)(src + (in ? byte : 0u)), (lds_void*)dst_i, 16, 0, 0);
+      }
+    }
+  };
+  auto wait_batches = [&](int younger) __attribute__((always_inline)) {  // at most `younger` batches still in flight
+    switch (younger * NI) {
+#define SL_VMCNT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+      SL_VMCNT_CASE(0) SL_VMCNT_CASE(4) SL_VMCNT_CASE(8) SL_VMCNT_CASE(12) SL_VMCNT_CASE(16) SL_VMCNT_CASE(24)
+#undef SL_VMCNT_CASE
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+  };
+
+  const int64_t nmine = nbatch > wave0 ? (nbatch - wave0 + nwaves - 1) / nwaves : 0;
+  for (int d = 0; d < kDmaDepth - 1; ++d)
+    if (d < nmine) issue(wave0 + d * nwaves, d);
+  for (int64_t it = 0; it < nmine; ++it) {
+    const int64_t tb = wave0 + it * nwaves;
+    const int slot = (int)(it % kDmaDepth);
+    if (it + (kDmaDepth - 1) < nmine) {
+      issue(tb + (kDmaDepth - 1) * nwaves, (int)((it + kDmaDepth - 1) % kDmaDepth));
+      wait_batches(kDmaDepth - 1);  // a constant: one s_waitcnt
+    } else {
+      wait_batches(0);  // the last batches of this wave: drain
+    }
+    const unsigned char* sl_ = ring + slot * slot_bytes;
+    const int64_t task0 = tb * U;
+    int nu = U;
+    if (task0 + U > ntask) nu = (int)(ntask - task0);
+    float m[U], sum[U];
+    f32x2 sum2[U];  // two partial sums per task, added with one v_pk_add_f32 per half piece
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      m[u] = fill;
+      sum2[u] = f32x2{0.f, 0.f};
+    }
+    for (int step = 0; step < nsteps; ++step) {
+      const int q = step * G + li;
+      uint32_t off;
+      bool piece_ok = true;
+      if constexpr (ALIGNED) {
+        piece_ok = q < npieces;
+        off = row_byte0 + (uint32_t)(piece_ok ? q : npieces - 1) * 16u;
+      } else {
+        off = row_byte0 + (uint32_t)(li < npieces ? li : npieces - 1) * 16u;
+      }
+      f32x4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const f32x4*>(sl_ + (uint32_t)u * task_bytes + off);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float e0 = v[u][0], e1 = v[u][1], e2 = v[u][2], e3 = v[u][3];
+        if constexpr (ABS) {
+          e0 = __builtin_fabsf(e0); e1 = __builtin_fabsf(e1); e2 = __builtin_fabsf(e2); e3 = __builtin_fabsf(e3);
+        }
+        if constexpr (!ALIGNED) {
+          e0 = k0 ? e0 : fill; e1 = k1 ? e1 : fill; e2 = k2 ? e2 : fill; e3 = k3 ? e3 : fill;
+        }
+        if constexpr (SUMOP) {
+          if constexpr (ALIGNED) {
+            e0 = piece_ok ? e0 : 0.f; e1 = piece_ok ? e1 : 0.f; e2 = piece_ok ? e2 : 0.f; e3 = piece_ok ? e3 : 0.f;
+          }
+          sum2[u] += f32x2{e0, e1} + f32x2{e2, e3};
+        } else {
+          m[u] = v_max3(v_max3(m[u], e0, e1), e2, e3);
+          if (!(SL_REDUCE_LAB & 2)) sum2[u] += f32x2{e0, e1} + f32x2{e2, e3};  // NaN detector only
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) sum[u] = sum2[u][0] + sum2[u][1];
+    // every ds_read of the slot has returned before a later iteration's DMA may overwrite it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (SL_REDUCE_LAB & 1) {  // measurement only: no per-row reduction, no stores
+      float t = 0.f;
+#pragma unroll
+      for (int u = 0; u < U; ++u) t += m[u] + sum[u];
+      if (t == 12345.f && outf) outf[0] = t;
+      continue;
+    }
+    float r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if constexpr (SUMOP) {
+        r[u] = group_allreduce_bcast<G, true>(sum[u], lane) / (float)S;
+      } else {
+        r[u] = group_allreduce_bcast<G, false>(m[u], lane);
+        const bool row_ok = u < nu;
+        // rows of a short last batch read stale slot bytes: their sums are ignored (row_ok)
+        if (__builtin_expect(__any(row_ok && sum[u] != sum[u]), 0)) {
+          const float sred = group_allreduce_f<G, true>(sum[u]);
+          bool nan = false;
+          if (row_ok && sred != sred) {
+            const float* rowp = x + ((task0 + u) * RPT + g) * (int64_t)S;
+            for (int i = li; i < S; i += G) nan |= (rowp[i] != rowp[i]);
+          }
+          const float f = group_allreduce_f<G, false>(nan ? 1.f : 0.f);
+          if (f > 0.f) r[u] = bits_f32(0x7FC00000u);
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < U; p += G) {
+      float sel = r[p];
+#pragma unroll
+      for (int u = p + 1; u < U && u < p + G; ++u) sel = (li == u - p) ? r[u] : sel;
+      const int uu = p + li;
+      if (li < G && uu < nu) store_outputs(sel, (task0 + uu) * RPT + g, cand, outf);
+    }
+  }
+}
+
 // streaming (read-once) 16-byte load with the nt cache policy, like the buffer loads of rowreduce_fast
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ inline float4 nt_load4(const float* p) {
   const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
   return make_float4(v[0], v[1], v[2], v[3]);
@@ -596,6 +818,58 @@ void launch_rowreduce_fast(ProfScope& prof, const float* x, int64_t R, int S, ui
   }
 }
 
+template <int G, int U, int OP, bool ALIGNED>
+void launch_rowreduce_dma(ProfScope& prof, const float* x, int64_t R, int S, uint16_t* cand, float* outf, hipStream_t st) {
+  constexpr int RPT = kWave / G;
+  const int64_t nbatch = (R / RPT + U - 1) / U;
+  const int slot = U * RPT * S * 4;                       // one batch, a multiple of 16 bytes
+  const int lds = 4 * kDmaDepth * slot + 1024;            // + 1 KiB: the masked tail of the last slot's last instruction
+  int per_cu = kDmaLdsPerCu / lds;
+  if (per_cu > 8) per_cu = 8;                             // 32 waves per CU
+  int64_t blocks = (nbatch + 3) / 4;
+  const int64_t cap = (int64_t)num_cus() * per_cu;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  // Cache policy of the stream (same rule and knobs as launch_rowreduce_fast).  A cold input streams best with nt (6.3 vs
+  // 5.8 TB/s on 411 MB).  Inside a model the input was written by the previous kernel microseconds ago: what still sits
+  // (dirty) in the 256 MiB Infinity Cache reads faster with the default policy, and nt on it LOSES (in-bench average
+  // 5.0 TB/s all-nt vs 5.9 mixed).  The kernel cannot know its producer; the rule assumes the common case (a hook
+  // on the layer that just ran) and both thresholds are process-wide knobs: SL_NT_MIN_BYTES (inputs below it are read
+  // with the default policy; default 256 MiB) and SL_REDUCE_TAIL_MB (the last so many MB of a larger input likewise;
+  // default 240; 0 = all nt, the right setting for inputs known to be cold).
+  static const int64_t nt_min_bytes = [] {
+    const char* e = getenv("SL_NT_MIN_BYTES");
+    return e ? (int64_t)atoll(e) : (int64_t)256 << 20;
+  }();
+  static const int64_t tail_bytes = [] {
+    const char* e = getenv("SL_REDUCE_TAIL_MB");
+    return (e ? (int64_t)atoll(e) : (int64_t)240) << 20;
+  }();
+  const int64_t bytes = R * (int64_t)S * 4;
+  int64_t tail_from = 0;  // batches from here on use the default policy
+  if (bytes >= nt_min_bytes) tail_from = tail_bytes > 0 ? (bytes > tail_bytes ? (bytes - tail_bytes) / slot : 0) : INT64_MAX;
+  SL_LAUNCH(prof, (rowreduce_dma_kernel<G, U, OP, ALIGNED>), dim3((unsigned)blocks), dim3(256), (size_t)lds, st, x, R, S, slot,
+            tail_from, cand, outf);
+}
+
+// U = tasks per batch (<= 4) so that a batch is at most 4 KiB; false when a task alone is larger
+template <int G, int OP, bool ALIGNED>
+bool try_rowreduce_dma(ProfScope& prof, const float* x, int64_t R, int S, uint16_t* cand, float* outf, hipStream_t st) {
+  static const bool enabled = [] {
+    const char* e = getenv("SL_REDUCE_DMA");  // 0: always the VGPR-load kernels (A/B measurements)
+    return !(e && atoi(e) == 0);
+  }();
+  constexpr int RPT = kWave / G;
+  const int64_t task_bytes = (int64_t)RPT * S * 4;
+  if (!enabled || task_bytes > kDmaMaxBatch || R * (int64_t)S * 4 < (8ll << 20)) return false;  // small inputs: launch-bound either way
+  const int u = (int)(kDmaMaxBatch / task_bytes);
+  if (u >= 4) launch_rowreduce_dma<G, 4, OP, ALIGNED>(prof, x, R, S, cand, outf, st);
+  else if (u == 3) launch_rowreduce_dma<G, 3, OP, ALIGNED>(prof, x, R, S, cand, outf, st);
+  else if (u == 2) launch_rowreduce_dma<G, 2, OP, ALIGNED>(prof, x, R, S, cand, outf, st);
+  else launch_rowreduce_dma<G, 1, OP, ALIGNED>(prof, x, R, S, cand, outf, st);
+  return true;
+}
+
 template <int OP>
 void dispatch_rowreduce(ProfScope& prof, const float* x, int64_t R, int S, uint16_t* cand, float* outf, hipStream_t st) {
   // pieces needed for a row window: up to (S + 6) / 4
@@ -603,18 +877,27 @@ void dispatch_rowreduce(ProfScope& prof, const float* x, int64_t R, int S, uint1
   // fast path A: rows are whole 16-byte pieces
   if (S % 4 == 0 && S >= 16 && (int64_t)S * 64 * 4 * 8 < (1ll << 31)) {
     const int np = S / 4;
-    if (np <= 4 && R % 16 == 0) return launch_rowreduce_fast<4, 8, OP, true>(prof, x, R, S, cand, outf, st);
-    if (np <= 8 && R % 8 == 0) return launch_rowreduce_fast<8, 8, OP, true>(prof, x, R, S, cand, outf, st);
-    if (np <= 16 && R % 4 == 0) return launch_rowreduce_fast<16, 8, OP, true>(prof, x, R, S, cand, outf, st);
-    if (np <= 32 && R % 2 == 0) return launch_rowreduce_fast<32, 8, OP, true>(prof, x, R, S, cand, outf, st);
-    if (np <= 64) return launch_rowreduce_fast<64, 8, OP, true>(prof, x, R, S, cand, outf, st);
-    return launch_rowreduce_fast<64, 4, OP, true>(prof, x, R, S, cand, outf, st);
+#define SL_ROWREDUCE(G_, U_, AL_)                                                          \
+  do {                                                                                     \
+    if (try_rowreduce_dma<G_, OP, AL_>(prof, x, R, S, cand, outf, st)) return;             \
+    return launch_rowreduce_fast<G_, U_, OP, AL_>(prof, x, R, S, cand, outf, st);          \
+  } while (0)
+    // LDS-DMA path: lanes read from LDS, where clamped lanes are free, so four rows share a task (G = 16, up to four
+    // steps per row) and their DPP reductions run in the same instructions
+    if (np > 4 && np <= 64 && R % 4 == 0 && try_rowreduce_dma<16, OP, true>(prof, x, R, S, cand, outf, st)) return;
+    if (np <= 4 && R % 16 == 0) SL_ROWREDUCE(4, 8, true);
+    if (np <= 8 && R % 8 == 0) SL_ROWREDUCE(8, 8, true);
+    if (np <= 16 && R % 4 == 0) SL_ROWREDUCE(16, 8, true);
+    if (np <= 32 && R % 2 == 0) SL_ROWREDUCE(32, 8, true);
+    if (np <= 64) SL_ROWREDUCE(64, 8, true);
+    SL_ROWREDUCE(64, 4, true);
   }
   // fast path B: short unaligned rows (e.g. 7x7 = 49 floats), >= 4 rows per wave-load
   if (S % 4 != 0 && need <= 16) {
-    if (need <= 4 && R % 16 == 0) return launch_rowreduce_fast<4, 8, OP, false>(prof, x, R, S, cand, outf, st);
-    if (need <= 8 && R % 8 == 0) return launch_rowreduce_fast<8, 8, OP, false>(prof, x, R, S, cand, outf, st);
-    if (R % 4 == 0) return launch_rowreduce_fast<16, 8, OP, false>(prof, x, R, S, cand, outf, st);
+    if (need <= 4 && R % 16 == 0) SL_ROWREDUCE(4, 8, false);
+    if (need <= 8 && R % 8 == 0) SL_ROWREDUCE(8, 8, false);
+    if (R % 4 == 0) SL_ROWREDUCE(16, 8, false);
+#undef SL_ROWREDUCE
   }
   if (need <= 4) launch_rowreduce<4, 8, OP>(prof, x, R, S, cand, outf, st);
   else if (need <= 8) launch_rowreduce<8, 8, OP>(prof, x, R, S, cand, outf, st);

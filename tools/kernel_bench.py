@@ -110,7 +110,7 @@ def bench_preprocess(B, h, w, S=224, cpu_images=16):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
-    ap.add_argument("--only", default=None, help="run one family: preprocess | gemm")
+    ap.add_argument("--only", default=None, help="run one family: preprocess | gemm | reduce")
     args = ap.parse_args()
     out = []
     if args.only == "gemm":
@@ -120,6 +120,12 @@ def main():
     if args.only == "preprocess":
         for B, h, w in ((256, 500, 375), (256, 375, 500), (256, 224, 224), (64, 1200, 1600)):
             print(json.dumps(("preprocess", bench_preprocess(B, h, w))), flush=True)
+        return
+    if args.only == "reduce":
+        for s in ((256, 512, 28, 28), (256, 1024, 14, 14), (256, 2048, 7, 7), (64, 2048, 7, 7), (256, 192, 56, 56), (256, 384, 28, 28), (256, 1536, 7, 7)):
+            print(json.dumps(("reduce_max", bench_reduce(*s))), flush=True)
+        print(json.dumps(("reduce_mean", bench_reduce(256, 2048, 7, 7, agg=N.SL_CONV_MEAN))), flush=True)
+        print(json.dumps(("tokens_max", bench_tokens(256, 197, 768))), flush=True)
         return
     shapes = [(256, 512, 28, 28), (256, 1024, 14, 14), (256, 2048, 7, 7), (64, 512, 28, 28), (64, 1024, 14, 14), (64, 2048, 7, 7)]
     if not args.quick:
