@@ -124,9 +124,10 @@ def finish_job(cv, embeds, id_start, n_total, world):
 
 
 @torch.no_grad()
-def self_check(dev, model, fm, args, n=192, B=64):
-    """What the timed region computes, checked against the oracle on a 192-image prefix (ids 0..191, three batches of
-    64 so that queued merges are exercised): the SAME device activations go through (i) the product's hooks
+def self_check(dev, model, fm, args, n=512, B=256):
+    """What the timed region computes, checked against the oracle on a 512-image prefix (ids 0..511, two batches of the
+    bench's own size — other batch sizes would send MIOpen into a fresh kernel search): the SAME device activations go
+    through (i) the product's hooks
     (K1 reduce + K3 merge, the tie mode of the timed run) and (ii) the oracle's aggregate + ActMax restatement on the
     host; top-k values and ids must be bit-equal, and the gathered concept_db (K5) must equal the oracle's gather of
     the device embeddings.  Raises on any difference."""
@@ -164,6 +165,41 @@ def self_check(dev, model, fm, args, n=192, B=64):
         if not np.array_equal(db[name].cpu().numpy(), oracle.gather_rows(emb_host, ref.ids)):
             raise AssertionError(f"self-check: concept_db of {name} differs from the oracle's gather")
     return "ok"
+
+
+@torch.no_grad()
+def reduce_cold_leg(dev, B):
+    """K1 alone on COLD inputs at the three layer shapes (kernel-only; inputs rotated through > 1.2 GB so that the 256 MiB
+    Infinity Cache cannot serve them; read-once cache policy, as for any input that was not written a moment ago).  The
+    headline `roofline` is the in-pipeline number; this is what the same kernel does when its input comes from HBM."""
+    out = {}
+    N.set_reduce_policy(0, 0)
+    try:
+        for name, (C, H) in zip(LAYERS, ((512, 28), (1024, 14), (2048, 7))):
+            nbytes = B * C * H * H * 4
+            copies = max(2, (1200 << 20) // nbytes + 1)
+            xs = [torch.rand(B, C, H, H, device=dev) for _ in range(copies)]
+            cand = torch.empty((B, C), dtype=torch.bfloat16, device=dev)
+            for x in xs:
+                N.reduce_conv(x, N.SL_CONV_MAX, cand, None)
+            torch.cuda.synchronize()
+            N.prof_enable(True)
+            N.prof_reset()
+            for _ in range(3):
+                for x in xs:
+                    N.reduce_conv(x, N.SL_CONV_MAX, cand, None)
+            torch.cuda.synchronize()
+            ms, launches, nb = N.prof_read(N.SL_PROF_REDUCE)
+            N.prof_enable(False)
+            out[name] = {"GB/s": nb / ms / 1e6, "frac": nb / ms / 1e6 / HBM_PEAK_GBPS, "avg_launch_us": ms / launches * 1e3,
+                         "bytes_per_launch": nbytes}
+            del xs
+    finally:
+        N.set_reduce_policy(None, None)
+    tot_b = sum(v["bytes_per_launch"] for v in out.values())
+    tot_t = sum(v["bytes_per_launch"] / v["GB/s"] for v in out.values())
+    out["all_layers"] = {"GB/s": tot_b / tot_t, "frac": tot_b / tot_t / HBM_PEAK_GBPS}
+    return out
 
 
 class _Rows(torch.utils.data.Dataset):
@@ -531,6 +567,8 @@ def main():
     }
     if world == 1 and not args.no_self_check:
         line["self_check"] = self_check(dev, model, fm, args)
+    if world == 1:
+        line["roofline"]["cold_inputs"] = reduce_cold_leg(dev, B)
     if world == 1 and args.fm == "native":
         # the same job with every encoder GEMM on the fp32-input MFMA path (strict fp32 arithmetic end to end)
         from semanticlens_amd.foundation_models.native_clip import NativeClip

@@ -76,6 +76,14 @@ int sl_device_count(void);
 int sl_reduce_conv(const void* d_act, int dtype, int64_t B, int64_t C, int64_t S, int64_t sb, int64_t sc,
                    int64_t ss, int agg, uint16_t* d_cand_bf16, float* d_out_f32, void* stream);
 
+/* Cache policy of K1's row streams, process-wide.  A COLD input streams best with the read-once (nt) policy; an input the
+ * previous kernel on the stream wrote microseconds ago is partly still in the 256 MiB Infinity Cache and reads faster
+ * with the default policy.  Inputs smaller than nt_min_bytes are read with the default policy; of larger ones the last
+ * tail_bytes likewise, the rest with nt.  Defaults (also: environment SL_NT_MIN_BYTES, SL_REDUCE_TAIL_MB in MiB):
+ * 256 MiB / 240 MiB, i.e. "the input was just produced" — what a forward hook sees.  (0, 0) = everything nt, for
+ * inputs known to be cold; negative values restore the defaults. */
+int sl_set_reduce_policy(int64_t nt_min_bytes, int64_t tail_bytes);
+
 /* ---- K2: token reduce of a transformer activation ---------------------------------------
  * Replaces aggregators.py:114,141,168,195,242.  d_act: (B,T,F), strides (sb,st,sf).
  * `pos` is used by SL_TOK_TOKEN only (python-style negative index allowed). */

@@ -53,6 +53,7 @@ SIGNATURES = {
     "sl_similarity": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "sl_similarity_ws_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "sl_set_gemm_mode": (_int, [_int]),
+    "sl_set_reduce_policy": (_int, [_i64, _i64]),
     "sl_similarity_multi": (_int, [_vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _sz, _vp]),
     "sl_similarity_multi_ws_bytes": (_sz, [_i64, _i64, _vp, _int]),
     "sl_clarity": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
@@ -291,6 +292,13 @@ def similarity(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         rc = lib().sl_similarity(_ptr(xd), xr, xc, _ptr(yd), yr, yc, _ptr(out), _ptr(ws), nbytes, _stream(xd))
     _check(rc, "sl_similarity")
     return out
+
+
+def set_reduce_policy(nt_min_bytes: int | None = None, tail_bytes: int | None = None):
+    """Cache policy of K1's row streams (include/semanticlens_amd.h ``sl_set_reduce_policy``): ``(0, 0)`` reads everything
+    with the read-once policy (cold inputs), ``None`` restores the defaults (inputs just written by the previous kernel)."""
+    _check(lib().sl_set_reduce_policy(-1 if nt_min_bytes is None else int(nt_min_bytes),
+                                      -1 if tail_bytes is None else int(tail_bytes)), "sl_set_reduce_policy")
 
 
 def set_gemm_mode(mode: str | None):

@@ -26,6 +26,30 @@ namespace {
 
 enum Op : int { OP_MAX = 0, OP_SUM = 1, OP_ABSMAX = 2, OP_ABSSUM = 3 };
 
+// ---- cache policy of the row-reduce streams (sl_set_reduce_policy; environment SL_NT_MIN_BYTES / SL_REDUCE_TAIL_MB) ----
+// A COLD input streams best with the nt (read-once) policy: 6.4 vs 5.9 TB/s on 411 MB.  Inside a model the input was
+// written by the previous kernel microseconds ago; what still sits (dirty) in the 256 MiB Infinity Cache reads faster
+// with the default policy and nt on it LOSES (in-bench average 5.0 TB/s all-nt vs 5.9 mixed).  The kernel cannot know
+// its producer, so the default assumes the common case — a forward hook on the layer that just ran: inputs below
+// `nt_min_bytes` (default 256 MiB) are read with the default policy; of larger ones the last `tail_bytes` (default
+// 240 MiB: what the cache still holds) likewise and the head with nt.  tail_bytes = 0 and nt_min_bytes = 0 = all nt,
+// the right setting for inputs known to be cold.
+int64_t g_nt_min_bytes = -1, g_tail_bytes = -1;
+int64_t nt_min_bytes_() {
+  if (g_nt_min_bytes < 0) {
+    const char* e = getenv("SL_NT_MIN_BYTES");
+    g_nt_min_bytes = e ? (int64_t)atoll(e) : (int64_t)256 << 20;
+  }
+  return g_nt_min_bytes;
+}
+int64_t tail_bytes_() {
+  if (g_tail_bytes < 0) {
+    const char* e = getenv("SL_REDUCE_TAIL_MB");
+    g_tail_bytes = (e ? (int64_t)atoll(e) : (int64_t)240) << 20;
+  }
+  return g_tail_bytes;
+}
+
 // ---- cross-lane helpers ------------------------------------------------------------------
 template <int CTRL>
 __device__ inline int dpp_i32(int v) {
@@ -791,21 +815,7 @@ void launch_rowreduce_fast(ProfScope& prof, const float* x, int64_t R, int S, ui
     const char* e = getenv("SL_REDUCE_REVERSE");
     return e ? atoi(e) : 0;
   }();
-  // Cache policy of the streaming loads.  nt (read-once) is +4..10 % on inputs that come from HBM.  An input
-  // the producer kernel wrote a moment ago and that fits the 256 MiB Infinity Cache is better read with the
-  // default policy (measured 39.4 vs 41.6 us for 205 MB, 17.4 vs 17.9 us for 103 MB); above that size the
-  // producer's dirty lines are being evicted while we read and nt wins again (80 vs 100 us for 411 MB).
-  static const int64_t nt_min_bytes = [] {
-    const char* e = getenv("SL_NT_MIN_BYTES");
-    return e ? (int64_t)atoll(e) : (int64_t)256 << 20;
-  }();
-  // Above the Infinity Cache size only the head of a just-produced input has been evicted to HBM; its last ~240 MB
-  // are still cached (dirty).  The head is streamed with nt, the tail read with the default policy (in-bench, 411 MB
-  // layer2 output: 78.7 -> ~70 us; a tail above 256 MB loses again, 288 MB is back to the all-nt time).
-  static const int64_t tail_bytes = [] {
-    const char* e = getenv("SL_REDUCE_TAIL_MB");
-    return (e ? (int64_t)atoll(e) : (int64_t)240) << 20;
-  }();
+  const int64_t nt_min_bytes = nt_min_bytes_(), tail_bytes = tail_bytes_();  // cache policy: see the top of this file
   const int64_t bytes = R * (int64_t)S * 4;
   if (bytes >= nt_min_bytes) {
     const int64_t batch_bytes = (int64_t)U * RPT * S * 4;
@@ -830,21 +840,7 @@ void launch_rowreduce_dma(ProfScope& prof, const float* x, int64_t R, int S, uin
   const int64_t cap = (int64_t)num_cus() * per_cu;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  // Cache policy of the stream (same rule and knobs as launch_rowreduce_fast).  A cold input streams best with nt (6.3 vs
-  // 5.8 TB/s on 411 MB).  Inside a model the input was written by the previous kernel microseconds ago: what still sits
-  // (dirty) in the 256 MiB Infinity Cache reads faster with the default policy, and nt on it LOSES (in-bench average
-  // 5.0 TB/s all-nt vs 5.9 mixed).  The kernel cannot know its producer; the rule assumes the common case (a hook
-  // on the layer that just ran) and both thresholds are process-wide knobs: SL_NT_MIN_BYTES (inputs below it are read
-  // with the default policy; default 256 MiB) and SL_REDUCE_TAIL_MB (the last so many MB of a larger input likewise;
-  // default 240; 0 = all nt, the right setting for inputs known to be cold).
-  static const int64_t nt_min_bytes = [] {
-    const char* e = getenv("SL_NT_MIN_BYTES");
-    return e ? (int64_t)atoll(e) : (int64_t)256 << 20;
-  }();
-  static const int64_t tail_bytes = [] {
-    const char* e = getenv("SL_REDUCE_TAIL_MB");
-    return (e ? (int64_t)atoll(e) : (int64_t)240) << 20;
-  }();
+  const int64_t nt_min_bytes = nt_min_bytes_(), tail_bytes = tail_bytes_();  // cache policy: see the top of this file
   const int64_t bytes = R * (int64_t)S * 4;
   int64_t tail_from = 0;  // batches from here on use the default policy
   if (bytes >= nt_min_bytes) tail_from = tail_bytes > 0 ? (bytes > tail_bytes ? (bytes - tail_bytes) / slot : 0) : INT64_MAX;
@@ -959,6 +955,11 @@ int reduce_dispatch(ProfScope& prof, const void* x, int dtype, int64_t B, int64_
 
 int dtype_size(int dtype) { return dtype == SL_F32 ? 4 : 2; }
 
+void set_reduce_policy(int64_t nt_min_bytes, int64_t tail_bytes) {
+  g_nt_min_bytes = nt_min_bytes;
+  g_tail_bytes = tail_bytes;
+}
+
 }  // namespace
 }  // namespace sl
 
@@ -976,6 +977,12 @@ SL_API int sl_reduce_conv(const void* d_act, int dtype, int64_t B, int64_t C, in
   ProfScope prof(SL_PROF_REDUCE, st, (double)B * C * S * dtype_size(dtype));
   if (agg == SL_CONV_MAX) return reduce_dispatch<OP_MAX>(prof, d_act, dtype, B, C, S, sb, sc, ss, 0, S, d_cand_bf16, d_out_f32, st);
   return reduce_dispatch<OP_SUM>(prof, d_act, dtype, B, C, S, sb, sc, ss, 0, S, d_cand_bf16, d_out_f32, st);
+}
+
+SL_API int sl_set_reduce_policy(int64_t nt_min_bytes, int64_t tail_bytes) {
+  // negative = back to the environment / built-in defaults
+  set_reduce_policy(nt_min_bytes < 0 ? -1 : nt_min_bytes, tail_bytes < 0 ? -1 : tail_bytes);
+  return 0;
 }
 
 SL_API int sl_reduce_tokens(const void* d_act, int dtype, int64_t B, int64_t T, int64_t F, int64_t sb, int64_t st_,
