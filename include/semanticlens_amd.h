@@ -45,6 +45,8 @@ extern "C" {
 /* aggregation over H*W of a (B,C,H,W) activation — component_visualization/aggregators.py:38-87 */
 #define SL_CONV_MAX 0  /* aggregate_conv_max  (:64-87)  */
 #define SL_CONV_MEAN 1 /* aggregate_conv_mean (:38-61)  */
+#define SL_CONV_SUM 2  /* plain sum over H*W: zennit-crp's max_target="sum" used by the relevance visualizer
+                          (component_visualization/relevance_based.py:111,140-145) */
 
 /* aggregation over tokens of a (B,T,F) activation — aggregators.py:90-244 */
 #define SL_TOK_MEAN 0    /* aggregate_transformer_mean    (:90-114)  */
@@ -83,6 +85,10 @@ int sl_reduce_conv(const void* d_act, int dtype, int64_t B, int64_t C, int64_t S
  * 256 MiB / 240 MiB, i.e. "the input was just produced" — what a forward hook sees.  (0, 0) = everything nt, for
  * inputs known to be cold; negative values restore the defaults. */
 int sl_set_reduce_policy(int64_t nt_min_bytes, int64_t tail_bytes);
+
+/* Relevance visualizer (relevance_based.py:112, abs_norm=True -> zennit-crp ChannelConcept.reference_sampling):
+ * d_x (B,C) fp32 in place, x[b][:] /= (sum_c |x[b][c]| + eps). */
+int sl_abs_norm_rows(float* d_x, int64_t B, int64_t C, float eps, void* stream);
 
 /* ---- K2: token reduce of a transformer activation ---------------------------------------
  * Replaces aggregators.py:114,141,168,195,242.  d_act: (B,T,F), strides (sb,st,sf).

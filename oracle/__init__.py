@@ -21,7 +21,7 @@ _HERE = Path(__file__).resolve().parent
 _LIB_PATH = _HERE / "_build" / "libsl_oracle.so"
 _lib = None
 
-AGG_CONV = {"max": 0, "mean": 1}
+AGG_CONV = {"max": 0, "mean": 1, "sum": 2}
 AGG_TOK = {"mean": 0, "absmean": 1, "max": 2, "absmax": 3, "token": 4}
 MODE_ATEN = 0
 MODE_TOTAL = 1
@@ -87,6 +87,13 @@ def agg_conv(x, agg: str) -> np.ndarray:
     out = np.empty((B, C), dtype=np.float32)
     lib().orc_agg_conv(_p(x), _I(B), _I(C), _I(S), ctypes.c_int(AGG_CONV[agg]), _p(out))
     return out
+
+
+def abs_norm_rows(x, eps: float = 1e-10) -> np.ndarray:
+    """zennit-crp ``abs_norm``: rows of a (B, C) matrix divided by ``|row|.sum() + eps`` (sl_oracle.cpp::orc_abs_norm_rows)."""
+    x = _f32(x).copy()
+    lib().orc_abs_norm_rows(_p(x), _I(x.shape[0]), _I(x.shape[1]), ctypes.c_float(eps))
+    return x
 
 
 def agg_tokens(x, agg: str, pos: int = 0) -> np.ndarray:

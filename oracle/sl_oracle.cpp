@@ -95,10 +95,23 @@ ORC_API void orc_agg_conv(const float* x, int64_t B, int64_t C, int64_t S, int a
       }
       out[r] = nan ? std::numeric_limits<float>::quiet_NaN() : m;
     } else {
+      // agg 1: mean; agg 2: plain sum (zennit-crp ChannelConcept.reference_sampling, max_target="sum", which the
+      // reference's relevance visualizer configures: relevance_based.py:111,123-129)
       double s = 0.0;
       for (int64_t i = 0; i < S; ++i) s += (double)p[i];
-      out[r] = (float)(s / (double)S);
+      out[r] = agg == 2 ? (float)s : (float)(s / (double)S);
     }
+  }
+}
+
+// crp ChannelConcept.reference_sampling with abs_norm=True: rel / (|rel|.sum(-1) + 1e-10) per sample, in fp32
+// (the sum over channels in float64 then rounded: exact for the integer-valued test data).
+ORC_API void orc_abs_norm_rows(float* x, int64_t B, int64_t C, float eps) {
+  for (int64_t b = 0; b < B; ++b) {
+    double s = 0.0;
+    for (int64_t c = 0; c < C; ++c) s += std::fabs((double)x[b * C + c]);
+    const float tot = (float)s + eps;
+    for (int64_t c = 0; c < C; ++c) x[b * C + c] = x[b * C + c] / tot;
   }
 }
 

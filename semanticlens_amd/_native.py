@@ -18,7 +18,7 @@ LIB_PATH = _PKG / "lib" / "libsemanticlens_hip.so"
 
 # enums of include/semanticlens_amd.h
 SL_F32, SL_F16, SL_BF16 = 0, 1, 2
-SL_CONV_MAX, SL_CONV_MEAN = 0, 1
+SL_CONV_MAX, SL_CONV_MEAN, SL_CONV_SUM = 0, 1, 2
 SL_TOK_MEAN, SL_TOK_ABSMEAN, SL_TOK_MAX, SL_TOK_ABSMAX, SL_TOK_TOKEN = 0, 1, 2, 3, 4
 SL_TIES_TOTAL, SL_TIES_ATEN = 0, 1
 SL_MAX_SLOTS = 16
@@ -54,6 +54,7 @@ SIGNATURES = {
     "sl_similarity_ws_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "sl_set_gemm_mode": (_int, [_int]),
     "sl_set_reduce_policy": (_int, [_i64, _i64]),
+    "sl_abs_norm_rows": (_int, [_vp, _i64, _i64, ctypes.c_float, _vp]),
     "sl_similarity_multi": (_int, [_vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _sz, _vp]),
     "sl_similarity_multi_ws_bytes": (_sz, [_i64, _i64, _vp, _int]),
     "sl_clarity": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
@@ -168,6 +169,15 @@ def reduce_conv(x: torch.Tensor, agg: int, cand: torch.Tensor | None, out_f32: t
     with torch.cuda.device(x.device):
         rc = lib().sl_reduce_conv(_ptr(x), _dtype_code(x), B, C, H * W, sb, sc, ss, agg, _ptr(cand), _ptr(out_f32), _stream(x))
     _check(rc, "sl_reduce_conv")
+
+
+def abs_norm_rows(x: torch.Tensor, eps: float = 1e-10) -> torch.Tensor:
+    """In place on a contiguous (B, C) fp32 device tensor: ``x[b] /= x[b].abs().sum() + eps`` (the relevance visualizer's
+    ``abs_norm``)."""
+    assert x.is_cuda and x.ndim == 2 and x.dtype == torch.float32 and x.is_contiguous()
+    with torch.cuda.device(x.device):
+        _check(lib().sl_abs_norm_rows(_ptr(x), x.shape[0], x.shape[1], float(eps), _stream(x)), "sl_abs_norm_rows")
+    return x
 
 
 def reduce_tokens(x: torch.Tensor, agg: int, pos: int, cand: torch.Tensor | None, out_f32: torch.Tensor | None):

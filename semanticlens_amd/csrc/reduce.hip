@@ -163,7 +163,7 @@ __device__ inline float group_allreduce_f(float v) {
 // (total & 3) floats are masked out of the vector loads and added by scalar loads to the rows that
 // own them (up to three rows when S < 4).
 template <int G, int U, int OP, bool TAIL>
-__global__ __launch_bounds__(256) void rowreduce_kernel(const float* __restrict__ x, int64_t R, int S,
+__global__ __launch_bounds__(256) void rowreduce_kernel(const float* __restrict__ x, int64_t R, int S, float denom,
                                                          uint16_t* __restrict__ cand, float* __restrict__ outf) {
   constexpr int RPT = kWave / G;
   constexpr bool SUMOP = (OP == OP_SUM || OP == OP_ABSSUM);
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void rowreduce_kernel(const float* __restrict_
       }
       float r;
       if constexpr (SUMOP) {
-        r = group_allreduce_f<G, true>(sum[u]) / (float)S;  // torch: sum / n
+        r = group_allreduce_f<G, true>(sum[u]) / denom;  // torch: sum / n (denom = 1: plain sum)
       } else {
         r = group_allreduce_f<G, false>(m[u]);
         const float sred = group_allreduce_f<G, true>(sum[u]);
@@ -372,7 +372,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #endif
 
 template <int G, int U, int OP, bool ALIGNED, int AUX>
-__global__ __launch_bounds__(256) void rowreduce_fast_kernel(const float* __restrict__ x, int64_t R, int S,
+__global__ __launch_bounds__(256) void rowreduce_fast_kernel(const float* __restrict__ x, int64_t R, int S, float denom,
                                                               uint16_t* __restrict__ cand,
                                                               float* __restrict__ outf, int reverse, int64_t tail_from) {
   constexpr int RPT = kWave / G;
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void rowreduce_fast_kernel(const float* __rest
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if constexpr (SUMOP) {
-        r[u] = group_allreduce_asm<G, true>(sum[u]) / (float)S;  // torch: sum / n
+        r[u] = group_allreduce_asm<G, true>(sum[u]) / denom;  // torch: sum / n (denom = 1: plain sum)
       } else {
         r[u] = group_allreduce_asm<G, false>(m[u]);
         // any lane of the wave saw a NaN sum (a NaN, or +inf and -inf)?  Rare: re-scan those rows exactly.
@@ -521,7 +521,7 @@ constexpr int kDmaDepth = 2;        // slots per wave: one batch in flight while
 constexpr int kDmaLdsPerCu = 160 * 1024;
 
 template <int G, int U, int OP, bool ALIGNED>
-__global__ __launch_bounds__(256) void rowreduce_dma_kernel(const float* __restrict__ x, int64_t R, int S, int slot_bytes,
+__global__ __launch_bounds__(256) void rowreduce_dma_kernel(const float* __restrict__ x, int64_t R, int S, float denom, int slot_bytes,
                                                              int64_t tail_from, uint16_t* __restrict__ cand,
                                                              float* __restrict__ outf) {
   constexpr int RPT = kWave / G;
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(256) void rowreduce_dma_kernel(const float* __restr
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if constexpr (SUMOP) {
-        r[u] = group_allreduce_bcast<G, true>(sum[u], lane) / (float)S;
+        r[u] = group_allreduce_bcast<G, true>(sum[u], lane) / denom;
       } else {
         r[u] = group_allreduce_bcast<G, false>(m[u], lane);
         const bool row_ok = u < nu;
@@ -789,7 +789,7 @@ __global__ __launch_bounds__(256) void generic_reduce_kernel(const void* __restr
 }
 
 template <int G, int U, int OP>
-void launch_rowreduce(ProfScope& prof, const float* x, int64_t R, int S, uint16_t* cand, float* outf, hipStream_t st) {
+void launch_rowreduce(ProfScope& prof, const float* x, int64_t R, int S, float denom, uint16_t* cand, float* outf, hipStream_t st) {
   constexpr int RPT = kWave / G;
   const int64_t ntasks = (R + RPT - 1) / RPT;
   const int64_t nbatch = (ntasks + U - 1) / U;
@@ -798,13 +798,13 @@ void launch_rowreduce(ProfScope& prof, const float* x, int64_t R, int S, uint16_
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   if ((R * (int64_t)S) % 4 == 0)
-    SL_LAUNCH(prof, (rowreduce_kernel<G, U, OP, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, R, S, cand, outf);
+    SL_LAUNCH(prof, (rowreduce_kernel<G, U, OP, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, R, S, denom, cand, outf);
   else
-    SL_LAUNCH(prof, (rowreduce_kernel<G, U, OP, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, R, S, cand, outf);
+    SL_LAUNCH(prof, (rowreduce_kernel<G, U, OP, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, R, S, denom, cand, outf);
 }
 
 template <int G, int U, int OP, bool ALIGNED>
-void launch_rowreduce_fast(ProfScope& prof, const float* x, int64_t R, int S, uint16_t* cand, float* outf, hipStream_t st) {
+void launch_rowreduce_fast(ProfScope& prof, const float* x, int64_t R, int S, float denom, uint16_t* cand, float* outf, hipStream_t st) {
   constexpr int RPT = kWave / G;
   const int64_t nbatch = (R / RPT + U - 1) / U;
   int64_t blocks = (nbatch + 3) / 4;
@@ -821,15 +821,15 @@ void launch_rowreduce_fast(ProfScope& prof, const float* x, int64_t R, int S, ui
     const int64_t batch_bytes = (int64_t)U * RPT * S * 4;
     const int64_t tail_from = tail_bytes > 0 ? (bytes > tail_bytes ? (bytes - tail_bytes) / batch_bytes : 0) : INT64_MAX;
     SL_LAUNCH(prof, (rowreduce_fast_kernel<G, U, OP, ALIGNED, SL_LOAD_AUX>), dim3((unsigned)blocks), dim3(256), 0, st, x, R, S,
-              cand, outf, reverse, tail_from);
+              denom, cand, outf, reverse, tail_from);
   } else {
-    SL_LAUNCH(prof, (rowreduce_fast_kernel<G, U, OP, ALIGNED, 0>), dim3((unsigned)blocks), dim3(256), 0, st, x, R, S, cand,
-              outf, reverse, (int64_t)INT64_MAX);
+    SL_LAUNCH(prof, (rowreduce_fast_kernel<G, U, OP, ALIGNED, 0>), dim3((unsigned)blocks), dim3(256), 0, st, x, R, S, denom,
+              cand, outf, reverse, (int64_t)INT64_MAX);
   }
 }
 
 template <int G, int U, int OP, bool ALIGNED>
-void launch_rowreduce_dma(ProfScope& prof, const float* x, int64_t R, int S, uint16_t* cand, float* outf, hipStream_t st) {
+void launch_rowreduce_dma(ProfScope& prof, const float* x, int64_t R, int S, float denom, uint16_t* cand, float* outf, hipStream_t st) {
   constexpr int RPT = kWave / G;
   const int64_t nbatch = (R / RPT + U - 1) / U;
   const int slot = U * RPT * S * 4;                       // one batch, a multiple of 16 bytes
@@ -844,13 +844,13 @@ void launch_rowreduce_dma(ProfScope& prof, const float* x, int64_t R, int S, uin
   const int64_t bytes = R * (int64_t)S * 4;
   int64_t tail_from = 0;  // batches from here on use the default policy
   if (bytes >= nt_min_bytes) tail_from = tail_bytes > 0 ? (bytes > tail_bytes ? (bytes - tail_bytes) / slot : 0) : INT64_MAX;
-  SL_LAUNCH(prof, (rowreduce_dma_kernel<G, U, OP, ALIGNED>), dim3((unsigned)blocks), dim3(256), (size_t)lds, st, x, R, S, slot,
-            tail_from, cand, outf);
+  SL_LAUNCH(prof, (rowreduce_dma_kernel<G, U, OP, ALIGNED>), dim3((unsigned)blocks), dim3(256), (size_t)lds, st, x, R, S, denom,
+            slot, tail_from, cand, outf);
 }
 
 // U = tasks per batch (<= 4) so that a batch is at most 4 KiB; false when a task alone is larger
 template <int G, int OP, bool ALIGNED>
-bool try_rowreduce_dma(ProfScope& prof, const float* x, int64_t R, int S, uint16_t* cand, float* outf, hipStream_t st) {
+bool try_rowreduce_dma(ProfScope& prof, const float* x, int64_t R, int S, float denom, uint16_t* cand, float* outf, hipStream_t st) {
   static const bool enabled = [] {
     const char* e = getenv("SL_REDUCE_DMA");  // 0: always the VGPR-load kernels (A/B measurements)
     return !(e && atoi(e) == 0);
@@ -859,15 +859,15 @@ bool try_rowreduce_dma(ProfScope& prof, const float* x, int64_t R, int S, uint16
   const int64_t task_bytes = (int64_t)RPT * S * 4;
   if (!enabled || task_bytes > kDmaMaxBatch || R * (int64_t)S * 4 < (8ll << 20)) return false;  // small inputs: launch-bound either way
   const int u = (int)(kDmaMaxBatch / task_bytes);
-  if (u >= 4) launch_rowreduce_dma<G, 4, OP, ALIGNED>(prof, x, R, S, cand, outf, st);
-  else if (u == 3) launch_rowreduce_dma<G, 3, OP, ALIGNED>(prof, x, R, S, cand, outf, st);
-  else if (u == 2) launch_rowreduce_dma<G, 2, OP, ALIGNED>(prof, x, R, S, cand, outf, st);
-  else launch_rowreduce_dma<G, 1, OP, ALIGNED>(prof, x, R, S, cand, outf, st);
+  if (u >= 4) launch_rowreduce_dma<G, 4, OP, ALIGNED>(prof, x, R, S, denom, cand, outf, st);
+  else if (u == 3) launch_rowreduce_dma<G, 3, OP, ALIGNED>(prof, x, R, S, denom, cand, outf, st);
+  else if (u == 2) launch_rowreduce_dma<G, 2, OP, ALIGNED>(prof, x, R, S, denom, cand, outf, st);
+  else launch_rowreduce_dma<G, 1, OP, ALIGNED>(prof, x, R, S, denom, cand, outf, st);
   return true;
 }
 
 template <int OP>
-void dispatch_rowreduce(ProfScope& prof, const float* x, int64_t R, int S, uint16_t* cand, float* outf, hipStream_t st) {
+void dispatch_rowreduce(ProfScope& prof, const float* x, int64_t R, int S, float denom, uint16_t* cand, float* outf, hipStream_t st) {
   // pieces needed for a row window: up to (S + 6) / 4
   const int need = (S + 6) / 4;
   // fast path A: rows are whole 16-byte pieces
@@ -875,12 +875,12 @@ void dispatch_rowreduce(ProfScope& prof, const float* x, int64_t R, int S, uint1
     const int np = S / 4;
 #define SL_ROWREDUCE(G_, U_, AL_)                                                          \
   do {                                                                                     \
-    if (try_rowreduce_dma<G_, OP, AL_>(prof, x, R, S, cand, outf, st)) return;             \
-    return launch_rowreduce_fast<G_, U_, OP, AL_>(prof, x, R, S, cand, outf, st);          \
+    if (try_rowreduce_dma<G_, OP, AL_>(prof, x, R, S, denom, cand, outf, st)) return;             \
+    return launch_rowreduce_fast<G_, U_, OP, AL_>(prof, x, R, S, denom, cand, outf, st);          \
   } while (0)
     // LDS-DMA path: lanes read from LDS, where clamped lanes are free, so four rows share a task (G = 16, up to four
     // steps per row) and their DPP reductions run in the same instructions
-    if (np > 4 && np <= 64 && R % 4 == 0 && try_rowreduce_dma<16, OP, true>(prof, x, R, S, cand, outf, st)) return;
+    if (np > 4 && np <= 64 && R % 4 == 0 && try_rowreduce_dma<16, OP, true>(prof, x, R, S, denom, cand, outf, st)) return;
     if (np <= 4 && R % 16 == 0) SL_ROWREDUCE(4, 8, true);
     if (np <= 8 && R % 8 == 0) SL_ROWREDUCE(8, 8, true);
     if (np <= 16 && R % 4 == 0) SL_ROWREDUCE(16, 8, true);
@@ -895,12 +895,12 @@ void dispatch_rowreduce(ProfScope& prof, const float* x, int64_t R, int S, uint1
     if (R % 4 == 0) SL_ROWREDUCE(16, 8, false);
 #undef SL_ROWREDUCE
   }
-  if (need <= 4) launch_rowreduce<4, 8, OP>(prof, x, R, S, cand, outf, st);
-  else if (need <= 8) launch_rowreduce<8, 8, OP>(prof, x, R, S, cand, outf, st);
-  else if (need <= 16) launch_rowreduce<16, 8, OP>(prof, x, R, S, cand, outf, st);
-  else if (need <= 32) launch_rowreduce<32, 8, OP>(prof, x, R, S, cand, outf, st);
-  else if (need <= 64) launch_rowreduce<64, 8, OP>(prof, x, R, S, cand, outf, st);
-  else launch_rowreduce<64, 4, OP>(prof, x, R, S, cand, outf, st);
+  if (need <= 4) launch_rowreduce<4, 8, OP>(prof, x, R, S, denom, cand, outf, st);
+  else if (need <= 8) launch_rowreduce<8, 8, OP>(prof, x, R, S, denom, cand, outf, st);
+  else if (need <= 16) launch_rowreduce<16, 8, OP>(prof, x, R, S, denom, cand, outf, st);
+  else if (need <= 32) launch_rowreduce<32, 8, OP>(prof, x, R, S, denom, cand, outf, st);
+  else if (need <= 64) launch_rowreduce<64, 8, OP>(prof, x, R, S, denom, cand, outf, st);
+  else launch_rowreduce<64, 4, OP>(prof, x, R, S, denom, cand, outf, st);
 }
 
 template <int OP>
@@ -936,12 +936,12 @@ void dispatch_generic(ProfScope& prof, const void* x, int dtype, int64_t B, int6
 // (B, C, S) with strides -> (B, C): reduce over s in [s0, s1).  Picks the fastest legal path.
 template <int OP>
 int reduce_dispatch(ProfScope& prof, const void* x, int dtype, int64_t B, int64_t C, int64_t S, int64_t sb, int64_t sc, int64_t ss,
-                    int64_t s0, int64_t s1, uint16_t* cand, float* outf, hipStream_t st) {
-  const float denom = (float)(s1 - s0);
+                    int64_t s0, int64_t s1, uint16_t* cand, float* outf, hipStream_t st, bool plain_sum = false) {
+  const float denom = plain_sum ? 1.f : (float)(s1 - s0);  // x / 1 is exact: the same kernels give sums
   const bool aligned = ((uintptr_t)x & 15) == 0;
   const bool full = (s0 == 0 && s1 == S);
   if (dtype == SL_F32 && aligned && full && ss == 1 && sc == S && sb == C * S && S < (1 << 28)) {
-    dispatch_rowreduce<OP>(prof, (const float*)x, B * C, (int)S, cand, outf, st);
+    dispatch_rowreduce<OP>(prof, (const float*)x, B * C, (int)S, denom, cand, outf, st);
   } else if (dtype == SL_F32 && aligned && sc == 1 && (C % 4) == 0 && (ss % 4) == 0 && (sb % 4) == 0 &&
              S < (1 << 30)) {
     launch_colreduce<OP>(prof, (const float*)x, B, (int)S, C, sb, ss, (int)s0, (int)s1, denom, cand, outf, st);
@@ -970,13 +970,43 @@ SL_API int sl_reduce_conv(const void* d_act, int dtype, int64_t B, int64_t C, in
   SL_REQUIRE(d_act || B * C * S == 0, "sl_reduce_conv: null activation");
   SL_REQUIRE(dtype >= SL_F32 && dtype <= SL_BF16, "sl_reduce_conv: bad dtype %d", dtype);
   SL_REQUIRE(B >= 0 && C >= 0 && S >= 0, "sl_reduce_conv: negative shape");
-  SL_REQUIRE(agg == SL_CONV_MAX || agg == SL_CONV_MEAN, "sl_reduce_conv: bad agg %d", agg);
+  SL_REQUIRE(agg == SL_CONV_MAX || agg == SL_CONV_MEAN || agg == SL_CONV_SUM, "sl_reduce_conv: bad agg %d", agg);
   SL_REQUIRE(d_cand_bf16 || d_out_f32, "sl_reduce_conv: no output");
   if (B * C == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof(SL_PROF_REDUCE, st, (double)B * C * S * dtype_size(dtype));
   if (agg == SL_CONV_MAX) return reduce_dispatch<OP_MAX>(prof, d_act, dtype, B, C, S, sb, sc, ss, 0, S, d_cand_bf16, d_out_f32, st);
-  return reduce_dispatch<OP_SUM>(prof, d_act, dtype, B, C, S, sb, sc, ss, 0, S, d_cand_bf16, d_out_f32, st);
+  return reduce_dispatch<OP_SUM>(prof, d_act, dtype, B, C, S, sb, sc, ss, 0, S, d_cand_bf16, d_out_f32, st, agg == SL_CONV_SUM);
+}
+
+// x (B,C) fp32 in place: x[b][:] /= (sum_c |x[b][c]| + eps)   (crp ChannelConcept.reference_sampling, abs_norm)
+namespace sl {
+namespace {
+__global__ __launch_bounds__(256) void abs_norm_rows_kernel(float* __restrict__ x, int64_t B, int64_t C, float eps) {
+  __shared__ float s_part[4];
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    float* row = x + b * C;
+    float s = 0.f;
+    for (int64_t c = threadIdx.x; c < C; c += 256) s += __builtin_fabsf(row[c]);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float tot = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]) + eps;
+    for (int64_t c = threadIdx.x; c < C; c += 256) row[c] = row[c] / tot;
+  }
+}
+}  // namespace
+}  // namespace sl
+
+SL_API int sl_abs_norm_rows(float* d_x, int64_t B, int64_t C, float eps, void* stream) {
+  SL_REQUIRE(B >= 0 && C >= 0, "sl_abs_norm_rows: negative shape");
+  if (B * C == 0) return 0;
+  SL_REQUIRE(d_x, "sl_abs_norm_rows: null pointer");
+  int64_t blocks = B < (int64_t)num_cus() * 8 ? B : (int64_t)num_cus() * 8;
+  hipLaunchKernelGGL(abs_norm_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_x, B, C, eps);
+  SL_CHECK_HIP(hipGetLastError());
+  return 0;
 }
 
 SL_API int sl_set_reduce_policy(int64_t nt_min_bytes, int64_t tail_bytes) {
