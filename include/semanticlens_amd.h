@@ -196,6 +196,7 @@ int sl_template_mean(const float* d_E, const float* d_E0, int64_t Q, int64_t T, 
 #define SL_ACT_NONE 0
 #define SL_ACT_GELU 1      /* exact erf GELU (torch.nn.GELU()) */
 #define SL_ACT_QUICKGELU 2 /* x * sigmoid(1.702 x) (OpenAI CLIP checkpoints) */
+#define SL_ACT_GELU_TANH 3 /* tanh approximation (torch gelu(approximate="tanh"); SigLIP towers) */
 /* out = act(x W^T + bias) (+ residual): x (M,K), W (N,K) row-major (torch Linear.weight), bias (N) or
  * NULL, residual (M,ldo) or NULL (may alias out), out row stride ldo >= N.  fp32-input MFMA GEMM.
  * Row scatter (patch embedding): when rows_per_group > 0, row r is written to
@@ -225,6 +226,12 @@ int sl_layernorm(const float* d_x, int64_t rows, int64_t cols, int64_t x_row_str
  * head_dim in {32, 64, 72, 80, 88, 96, 104, 128}; any sequence length (K/V stream through LDS in chunks). */
 int sl_attention(const float* d_qkv, int64_t B, int64_t T, int64_t H, int64_t head_dim, int causal, float* d_out,
                  uint16_t* d_out_split, void* stream);
+/* Attention pooling with one query per head (the MAP head of SigLIP image towers, clip.py:190-211 SigLipV2 /
+ * open_clip attn_pool): out (B, H*head_dim) = softmax(q k_t / sqrt(head_dim)) v over the T tokens of each image.
+ * d_q (H*head_dim) is the projected probe; key row (b, t) is d_kv + (b*T + t) * kv_row_stride, its value row v_offset
+ * elements further.  head_dim: a multiple of 4 up to 128. */
+int sl_attention_pool(const float* d_q, const float* d_kv, int64_t kv_row_stride, int64_t v_offset, int64_t B, int64_t T,
+                      int64_t H, int64_t head_dim, float* d_out, void* stream);
 /* (B,C,Hi,Wi) image -> (B*(Hi/P)*(Wi/P), C*P*P) patch rows, k = c*P*P + py*P + px (Conv2d weight order). */
 int sl_patchify(const float* d_img, int64_t B, int64_t C, int64_t Hi, int64_t Wi, int64_t P, float* d_out,
                 uint16_t* d_out_split, void* stream);

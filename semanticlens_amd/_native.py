@@ -23,7 +23,7 @@ SL_TOK_MEAN, SL_TOK_ABSMEAN, SL_TOK_MAX, SL_TOK_ABSMAX, SL_TOK_TOKEN = 0, 1, 2, 
 SL_TIES_TOTAL, SL_TIES_ATEN = 0, 1
 SL_MAX_SLOTS = 16
 SL_PROF_REDUCE, SL_PROF_MERGE, SL_PROF_GEMM, SL_PROF_GATHER, SL_PROF_SCORES = 0, 1, 2, 3, 4
-SL_ACT_NONE, SL_ACT_GELU, SL_ACT_QUICKGELU = 0, 1, 2
+SL_ACT_NONE, SL_ACT_GELU, SL_ACT_QUICKGELU, SL_ACT_GELU_TANH = 0, 1, 2, 3
 TIE_MODES = {"total": SL_TIES_TOTAL, "aten": SL_TIES_ATEN}
 SL_PP_PLAN_STRIDE = 16
 PP_RESIZE_MODES = {"shortest": 0, "squash": 1}
@@ -67,6 +67,7 @@ SIGNATURES = {
     "sl_layernorm": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, ctypes.c_float, _vp, _vp, _i64, _vp]),
     "sl_attention": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp]),
     "sl_patchify": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "sl_attention_pool": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
     "sl_split_elems": (_sz, [_i64, _i64]),
     "sl_split_bf16": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "sl_linear_bf16x3": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
@@ -521,6 +522,18 @@ def attention(qkv, B, T, H, head_dim, causal, out=None, out_split: Split | None 
         rc = lib().sl_attention(_ptr(qkv), B, T, H, head_dim, 1 if causal else 0, _ptr(out), _split_ptr(out_split), _stream(qkv))
     _check(rc, "sl_attention")
     return out if out is not None else out_split
+
+
+def attention_pool(q, kv, B, T, H, head_dim, out=None):
+    """One query per head against the keys / values of each image: ``q`` (H*head_dim) projected probe, ``kv`` (B*T, 2*W)
+    rows ``[k | v]`` -> ``(B, W)``."""
+    W = H * head_dim
+    if out is None:
+        out = torch.empty((B, W), dtype=torch.float32, device=kv.device)
+    with torch.cuda.device(kv.device):
+        rc = lib().sl_attention_pool(_ptr(q), _ptr(kv), kv.stride(0), W, B, T, H, head_dim, _ptr(out), _stream(kv))
+    _check(rc, "sl_attention_pool")
+    return out
 
 
 def patchify(img, P, out=None, out_split: Split | None = None):

@@ -37,6 +37,8 @@ struct LinearEpi {
     float v = acc + b;
     if constexpr (ACT == SL_ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
     if constexpr (ACT == SL_ACT_QUICKGELU) v = v / (1.f + expf(-1.702f * v));
+    if constexpr (ACT == SL_ACT_GELU_TANH)  // torch gelu(approximate="tanh"): SigLIP's "gelu_pytorch_tanh"
+      v = 0.5f * v * (1.f + tanhf(0.79788456080286535588f * (v + 0.044715f * v * v * v)));
     int64_t orow = row;
     if constexpr (REMAP) {
       const int64_t g = row / rpg, i = row % rpg;
@@ -403,6 +405,25 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
   }
 }
 
+// any patch size (14 x 14 of ViT-L/14 and SigLIP-so400m): one element per thread
+__global__ __launch_bounds__(256) void patchify_scalar_kernel(const float* __restrict__ img, int64_t B, int C, int Hi, int Wi,
+                                                               int P, float* __restrict__ out, uint16_t* __restrict__ osp) {
+  const int gh = Hi / P, gw = Wi / P;
+  const int64_t kdim = (int64_t)C * P * P;
+  const int64_t total = B * gh * gw * kdim;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx / kdim;
+    const int k = (int)(idx % kdim);
+    const int c = k / (P * P), py = (k / P) % P, px = k % P;
+    const int64_t bb = row / (gh * gw);
+    const int pr = (int)(row % (gh * gw));
+    const int gy = pr / gw, gx = pr % gw;
+    const float v = img[((bb * C + c) * Hi + gy * P + py) * (int64_t)Wi + gx * P + px];
+    if (out) out[idx] = v;
+    if (osp) store_split(v, row, k, split_kp(kdim), osp);
+  }
+}
+
 // out[g * gstride + row] = v[:] (+ add[:]) for every group g: the class token row of every image
 __global__ __launch_bounds__(256) void broadcast_row_kernel(const float* __restrict__ v, const float* __restrict__ add,
                                                              int64_t G, int64_t gstride_elems, int N,
@@ -430,6 +451,63 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const float* __restri
   }
 }
 
+// ---- attention pooling with ONE query per head (SigLIP's MAP head: softmax(q k^T / sqrt(d)) v with q = the learned
+// probe, the same for every image).  One wave per (image, head): lanes stride over the T keys, each lane keeps an online
+// softmax (running max, sum, weighted V) of its keys, then the 64 partial states are combined.  K / V rows are read once:
+// HBM/L2-bound, B*T*2*W*4 bytes.
+constexpr int kPoolMaxHd = 128;
+__global__ __launch_bounds__(64) void attention_pool_kernel(const float* __restrict__ q, const float* __restrict__ kv, int64_t ld,
+                                                            int64_t voff, int T, int H, int hd, float scale,
+                                                            float* __restrict__ out) {
+  __shared__ float s_q[kPoolMaxHd];
+  const int lane = threadIdx.x;
+  const int64_t b = blockIdx.x / H;
+  const int h = (int)(blockIdx.x % H);
+  for (int d = lane; d < hd; d += 64) s_q[d] = q[h * hd + d] * scale;
+  __syncthreads();
+  float m = -__builtin_huge_valf(), l = 0.f;
+  float acc[kPoolMaxHd];
+#pragma unroll
+  for (int d = 0; d < kPoolMaxHd; ++d) acc[d] = 0.f;
+  for (int t = lane; t < T; t += 64) {
+    const float* kr = kv + (b * T + t) * ld + h * hd;
+    const float* vr = kr + voff;
+    float s = 0.f;
+    for (int d = 0; d < hd; d += 4) {
+      const float4 k4 = *reinterpret_cast<const float4*>(kr + d);
+      s += s_q[d] * k4.x + s_q[d + 1] * k4.y + s_q[d + 2] * k4.z + s_q[d + 3] * k4.w;
+    }
+    const float mn = fmaxf(m, s);
+    const float corr = __expf(m - mn), p = __expf(s - mn);  // first key: m = -inf -> corr = 0
+    l = l * corr + p;
+#pragma unroll
+    for (int d = 0; d < kPoolMaxHd; d += 4) {
+      if (d < hd) {
+        const float4 v4 = *reinterpret_cast<const float4*>(vr + d);
+        acc[d] = acc[d] * corr + p * v4.x;
+        acc[d + 1] = acc[d + 1] * corr + p * v4.y;
+        acc[d + 2] = acc[d + 2] * corr + p * v4.z;
+        acc[d + 3] = acc[d + 3] * corr + p * v4.w;
+      }
+    }
+    m = mn;
+  }
+  float M = m;
+  for (int off = 32; off > 0; off >>= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
+  const float f = (m == -__builtin_huge_valf()) ? 0.f : __expf(m - M);  // lanes without a key contribute nothing
+  l *= f;
+  for (int off = 32; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
+  const float inv = 1.f / l;
+#pragma unroll
+  for (int d = 0; d < kPoolMaxHd; ++d) {
+    if (d < hd) {
+      float a = acc[d] * f;
+      for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+      if (lane == 0) out[b * (int64_t)H * hd + h * hd + d] = a * inv;
+    }
+  }
+}
+
 int64_t grid_for(int64_t items) {
   int64_t blocks = (items + 255) / 256;
   const int64_t cap = (int64_t)num_cus() * 16;
@@ -446,7 +524,7 @@ SL_API int sl_linear(const float* d_x, int64_t M, int64_t K, const float* d_w, i
                      const float* d_residual, float* d_out, int64_t ldo, int64_t rows_per_group, int64_t group_stride,
                      int64_t row_offset, const float* d_rowadd, void* stream) {
   SL_REQUIRE(M >= 0 && K >= 0 && N >= 0 && ldo >= N, "sl_linear: bad shape");
-  SL_REQUIRE(act >= SL_ACT_NONE && act <= SL_ACT_QUICKGELU, "sl_linear: bad activation %d", act);
+  SL_REQUIRE(act >= SL_ACT_NONE && act <= SL_ACT_GELU_TANH, "sl_linear: bad activation %d", act);
   if (M * N == 0) return 0;
   SL_REQUIRE(d_x && d_w && d_out, "sl_linear: null pointer");
   const bool remap = rows_per_group > 0;
@@ -459,10 +537,12 @@ SL_API int sl_linear(const float* d_x, int64_t M, int64_t K, const float* d_w, i
   if (d_residual) {
     if (act == SL_ACT_NONE) SL_RUN(SL_ACT_NONE, true, false);
     if (act == SL_ACT_GELU) SL_RUN(SL_ACT_GELU, true, false);
+    if (act == SL_ACT_GELU_TANH) SL_RUN(SL_ACT_GELU_TANH, true, false);
     SL_RUN(SL_ACT_QUICKGELU, true, false);
   }
   if (act == SL_ACT_NONE) SL_RUN(SL_ACT_NONE, false, false);
   if (act == SL_ACT_GELU) SL_RUN(SL_ACT_GELU, false, false);
+  if (act == SL_ACT_GELU_TANH) SL_RUN(SL_ACT_GELU_TANH, false, false);
   SL_RUN(SL_ACT_QUICKGELU, false, false);
 #undef SL_RUN
 }
@@ -541,15 +621,34 @@ SL_API int sl_attention(const float* d_qkv, int64_t B, int64_t T, int64_t H, int
   return 0;
 }
 
+SL_API int sl_attention_pool(const float* d_q, const float* d_kv, int64_t kv_row_stride, int64_t v_offset, int64_t B, int64_t T,
+                             int64_t H, int64_t head_dim, float* d_out, void* stream) {
+  SL_REQUIRE(B >= 0 && T >= 1 && H >= 1 && T < (1ll << 31), "sl_attention_pool: bad shape");
+  SL_REQUIRE(head_dim >= 4 && head_dim <= kPoolMaxHd && head_dim % 4 == 0, "sl_attention_pool: head_dim=%lld not a multiple of 4 up to %d",
+             (long long)head_dim, kPoolMaxHd);
+  if (B == 0) return 0;
+  SL_REQUIRE(d_q && d_kv && d_out, "sl_attention_pool: null pointer");
+  SL_REQUIRE(kv_row_stride % 4 == 0 && v_offset % 4 == 0 && (((uintptr_t)d_kv) & 15) == 0, "sl_attention_pool: rows must be 16-byte aligned");
+  SL_REQUIRE(B * H < (1ll << 31), "sl_attention_pool: too many heads");
+  hipLaunchKernelGGL(attention_pool_kernel, dim3((unsigned)(B * H)), dim3(64), 0, (hipStream_t)stream, d_q, d_kv, kv_row_stride, v_offset,
+                     (int)T, (int)H, (int)head_dim, 1.f / sqrtf((float)head_dim), d_out);
+  SL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 SL_API int sl_patchify(const float* d_img, int64_t B, int64_t C, int64_t Hi, int64_t Wi, int64_t P, float* d_out,
                        uint16_t* d_out_split, void* stream) {
-  SL_REQUIRE(B >= 0 && C >= 1 && P >= 4 && P % 4 == 0 && Hi % P == 0 && Wi % P == 0, "sl_patchify: bad geometry");
+  SL_REQUIRE(B >= 0 && C >= 1 && P >= 1 && Hi % P == 0 && Wi % P == 0, "sl_patchify: bad geometry");
   if (B == 0) return 0;
   SL_REQUIRE(d_img && (d_out || d_out_split), "sl_patchify: null pointer");
-  SL_REQUIRE((((uintptr_t)d_img | (uintptr_t)d_out) & 15) == 0 && Wi % 4 == 0, "sl_patchify: needs 16-byte aligned rows");
-  const int64_t total4 = B * C * Hi * Wi / 4;
-  hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)grid_for(total4)), dim3(256), 0, (hipStream_t)stream, d_img, B, (int)C,
-                     (int)Hi, (int)Wi, (int)P, d_out, d_out_split);
+  if (P % 4 == 0 && (((uintptr_t)d_img | (uintptr_t)d_out) & 15) == 0 && Wi % 4 == 0) {  // 16-byte pieces
+    const int64_t total4 = B * C * Hi * Wi / 4;
+    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)grid_for(total4)), dim3(256), 0, (hipStream_t)stream, d_img, B, (int)C,
+                       (int)Hi, (int)Wi, (int)P, d_out, d_out_split);
+  } else {
+    hipLaunchKernelGGL(patchify_scalar_kernel, dim3((unsigned)grid_for(B * C * Hi * Wi)), dim3(256), 0, (hipStream_t)stream, d_img,
+                       B, (int)C, (int)Hi, (int)Wi, (int)P, d_out, d_out_split);
+  }
   SL_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -590,7 +689,7 @@ SL_API int sl_linear_bf16x3(const uint16_t* d_x_split, int64_t M, int64_t K, con
                             int64_t ldo, int64_t rows_per_group, int64_t group_stride, int64_t row_offset,
                             const float* d_rowadd, void* stream) {
   SL_REQUIRE(M >= 0 && K >= 0 && N >= 0 && ldo >= N, "sl_linear_bf16x3: bad shape");
-  SL_REQUIRE(act >= SL_ACT_NONE && act <= SL_ACT_QUICKGELU, "sl_linear_bf16x3: bad activation %d", act);
+  SL_REQUIRE(act >= SL_ACT_NONE && act <= SL_ACT_GELU_TANH, "sl_linear_bf16x3: bad activation %d", act);
   if (M * N == 0) return 0;
   const bool split = d_out_split != nullptr;
   SL_REQUIRE(d_x_split && d_w_split && (d_out || split) && !(d_out && split), "sl_linear_bf16x3: null / ambiguous pointers");
@@ -607,15 +706,18 @@ SL_API int sl_linear_bf16x3(const uint16_t* d_x_split, int64_t M, int64_t K, con
   if (split) {
     if (act == SL_ACT_NONE) SL_RUN3(SL_ACT_NONE, false, false, true);
     if (act == SL_ACT_GELU) SL_RUN3(SL_ACT_GELU, false, false, true);
+    if (act == SL_ACT_GELU_TANH) SL_RUN3(SL_ACT_GELU_TANH, false, false, true);
     SL_RUN3(SL_ACT_QUICKGELU, false, false, true);
   }
   if (d_residual) {
     if (act == SL_ACT_NONE) SL_RUN3(SL_ACT_NONE, true, false, false);
     if (act == SL_ACT_GELU) SL_RUN3(SL_ACT_GELU, true, false, false);
+    if (act == SL_ACT_GELU_TANH) SL_RUN3(SL_ACT_GELU_TANH, true, false, false);
     SL_RUN3(SL_ACT_QUICKGELU, true, false, false);
   }
   if (act == SL_ACT_NONE) SL_RUN3(SL_ACT_NONE, false, false, false);
   if (act == SL_ACT_GELU) SL_RUN3(SL_ACT_GELU, false, false, false);
+  if (act == SL_ACT_GELU_TANH) SL_RUN3(SL_ACT_GELU_TANH, false, false, false);
   SL_RUN3(SL_ACT_QUICKGELU, false, false, false);
 #undef SL_RUN3
 }

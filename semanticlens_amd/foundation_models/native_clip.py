@@ -281,3 +281,197 @@ class _SynthVisual:
         self.conv1, self.class_embedding = m.conv1, m.class_embedding
         self.positional_embedding = m.positional_embedding_v
         self.ln_pre, self.ln_post, self.proj = m.ln_pre, m.ln_post, m.proj_v
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# SigLIP-layout towers (reference: foundation_models/clip.py:190-211 `SigLipV2`; BASELINE configs[3] names SigLIP-so400m)
+# ------------------------------------------------------------------------------------------------------------------
+def _act_code(name: str) -> int:
+    name = (name or "gelu").lower()
+    if "quick" in name:
+        return N.SL_ACT_QUICKGELU
+    if "tanh" in name:
+        return N.SL_ACT_GELU_TANH
+    return N.SL_ACT_GELU
+
+
+class _SigLipBlock:
+    """One pre-LN block of a SigLIP encoder in `_Block`'s field layout.  Source layout: ``layer_norm1``, ``self_attn`` with
+    separate ``q_proj`` / ``k_proj`` / ``v_proj`` / ``out_proj`` Linear layers (packed here into the ``[q | k | v]``
+    in-projection the attention kernel reads), ``layer_norm2``, ``mlp.fc1`` / ``mlp.fc2`` (transformers' ``SiglipEncoderLayer``)."""
+
+    def __init__(self, blk: nn.Module, heads: int, act: int, device, split: bool):
+        a = blk.self_attn
+        self.width = a.q_proj.in_features
+        self.heads = heads
+        self.head_dim = self.width // heads
+        if self.head_dim not in (32, 64, 72, 80, 88, 96, 104, 128) or self.head_dim * heads != self.width:
+            raise ValueError(f"head_dim {self.head_dim} is not supported (32, 64, 72, 80, 88, 96, 104, 128)")
+        self.ln1 = (_f32(blk.layer_norm1.weight, device), _f32(blk.layer_norm1.bias, device), blk.layer_norm1.eps)
+        self.ln2 = (_f32(blk.layer_norm2.weight, device), _f32(blk.layer_norm2.bias, device), blk.layer_norm2.eps)
+        self.w_qkv = torch.cat([_f32(p.weight, device) for p in (a.q_proj, a.k_proj, a.v_proj)], 0).contiguous()
+        self.b_qkv = torch.cat([_f32(p.bias, device) for p in (a.q_proj, a.k_proj, a.v_proj)], 0).contiguous()
+        self.w_o, self.b_o = _f32(a.out_proj.weight, device), _f32(a.out_proj.bias, device)
+        self.w_fc, self.b_fc = _f32(blk.mlp.fc1.weight, device), _f32(blk.mlp.fc1.bias, device)
+        self.w_pr, self.b_pr = _f32(blk.mlp.fc2.weight, device), _f32(blk.mlp.fc2.bias, device)
+        self.act = act
+        if split:
+            self.s_qkv, self.s_o = N.Split.of(self.w_qkv), N.Split.of(self.w_o)
+            self.s_fc, self.s_pr = N.Split.of(self.w_fc), N.Split.of(self.w_pr)
+
+
+class _SigLipStack(_Tower):
+    def __init__(self, layers, heads: int, act: int, device, split: bool):
+        self.split = split
+        self.blocks = [_SigLipBlock(b, heads, act, device, split) for b in layers]
+        self.width = self.blocks[0].width
+        self.heads = heads
+
+
+class NativeSigLipVision:
+    """Image tower: patch embedding WITH bias, learned positions, no class token, non-causal blocks, ``post_layernorm``,
+    then the MAP head: one learned probe attends over all tokens (``sl_attention_pool``), out-projection, and a
+    LayerNorm + MLP residual branch; the pooled token is the image feature (no further projection)."""
+
+    def __init__(self, vm: nn.Module, cfg, device, split: bool):
+        emb = vm.embeddings
+        conv = emb.patch_embedding
+        if conv.kernel_size != conv.stride:
+            raise TypeError("NativeSigLip expects a patch embedding with stride == kernel size")
+        self.patch = conv.kernel_size[0]
+        self.width = conv.out_channels
+        self.w_patch = _f32(conv.weight.reshape(self.width, -1), device)
+        self.b_patch = _f32(conv.bias, device) if conv.bias is not None else None
+        self.pos = _f32(emb.position_embedding.weight, device)  # (n_patches, W)
+        act = _act_code(getattr(cfg, "hidden_act", "gelu_pytorch_tanh"))
+        self.split = split
+        if split:
+            self.s_patch = N.Split.of(self.w_patch)
+        self.tower = _SigLipStack(vm.encoder.layers, cfg.num_attention_heads, act, device, split)
+        ln = vm.post_layernorm
+        self.ln_post = (_f32(ln.weight, device), _f32(ln.bias, device), ln.eps)
+        head = vm.head
+        mha: nn.MultiheadAttention = head.attention
+        W = self.width
+        self.heads = mha.num_heads
+        self.head_dim = W // self.heads
+        wq, wk, wv = mha.in_proj_weight[:W], mha.in_proj_weight[W:2 * W], mha.in_proj_weight[2 * W:]
+        bq, bkv = mha.in_proj_bias[:W], mha.in_proj_bias[W:]
+        # the probe is the same for every image: its query projection is a constant of the model
+        probe = _f32(head.probe.reshape(1, W), device)
+        self.q_probe = N.linear(probe, _f32(wq, device), _f32(bq, device)).reshape(W).contiguous()
+        self.w_kv = torch.cat([_f32(wk, device), _f32(wv, device)], 0).contiguous()  # (2W, W): rows [k | v]
+        self.b_kv = _f32(bkv, device)
+        self.w_ho, self.b_ho = _f32(mha.out_proj.weight, device), _f32(mha.out_proj.bias, device)
+        self.ln_head = (_f32(head.layernorm.weight, device), _f32(head.layernorm.bias, device), head.layernorm.eps)
+        self.w_h1, self.b_h1 = _f32(head.mlp.fc1.weight, device), _f32(head.mlp.fc1.bias, device)
+        self.w_h2, self.b_h2 = _f32(head.mlp.fc2.weight, device), _f32(head.mlp.fc2.bias, device)
+        self.head_act = act
+        if split:
+            self.s_kv = N.Split.of(self.w_kv)
+
+    @torch.no_grad()
+    def __call__(self, img: torch.Tensor) -> torch.Tensor:
+        img = N.to_device(img).to(torch.float32).contiguous()
+        B = img.shape[0]
+        T = (img.shape[2] // self.patch) * (img.shape[3] // self.patch)
+        if T != self.pos.shape[0]:
+            raise ValueError(f"image gives {T} patches, the positional embedding has {self.pos.shape[0]}")
+        W = self.width
+        x = torch.empty((B * T, W), dtype=torch.float32, device=img.device)
+        # patch embedding GEMM (+ bias); its epilogue writes row (b, p) to token row b*T + p and adds pos[p]
+        if self.split:
+            patches = N.patchify(img, self.patch, out_split=N.Split(B * T, self.w_patch.shape[1], img.device))
+            N.linear3(patches, self.s_patch, self.b_patch, out=x, scatter=(T, T, 0), rowadd=self.pos)
+        else:
+            N.linear(N.patchify(img, self.patch), self.w_patch, self.b_patch, out=x, scatter=(T, T, 0), rowadd=self.pos)
+        x = self.tower.forward(x, B, T, causal=False)
+        if self.split:
+            h = N.layernorm(x, *self.ln_post, out_split=N.Split(B * T, W, img.device))
+            kv = N.linear3(h, self.s_kv, self.b_kv)
+        else:
+            kv = N.linear(N.layernorm(x, *self.ln_post), self.w_kv, self.b_kv)
+        pooled = N.attention_pool(self.q_probe, kv, B, T, self.heads, self.head_dim)  # (B, W)
+        res = N.linear(pooled, self.w_ho, self.b_ho)
+        hid = N.linear(N.layernorm(res, *self.ln_head), self.w_h1, self.b_h1, act=self.head_act)
+        return N.linear(hid, self.w_h2, self.b_h2, residual=res, out=res)
+
+
+class NativeSigLipText:
+    """Text tower: token + position embeddings, NON-causal blocks (SigLIP pads to the context length and does not mask),
+    ``final_layer_norm``, the LAST position pooled, then the ``head`` Linear (with bias)."""
+
+    def __init__(self, tm: nn.Module, cfg, device, split: bool):
+        self.table = _f32(tm.embeddings.token_embedding.weight, device)
+        self.pos = _f32(tm.embeddings.position_embedding.weight, device)
+        self.tower = _SigLipStack(tm.encoder.layers, cfg.num_attention_heads, _act_code(getattr(cfg, "hidden_act", "")), device, split)
+        ln = tm.final_layer_norm
+        self.ln_final = (_f32(ln.weight, device), _f32(ln.bias, device), ln.eps)
+        self.w_head, self.b_head = _f32(tm.head.weight, device), _f32(tm.head.bias, device)
+
+    @torch.no_grad()
+    def __call__(self, tokens: torch.Tensor) -> torch.Tensor:
+        tokens = N.to_device(tokens).to(torch.int64).contiguous()
+        B, T = tokens.shape
+        if T > self.pos.shape[0]:
+            raise ValueError(f"{T} tokens exceed the {self.pos.shape[0]} positions of the text tower")
+        x = N.embed_tokens(self.table, tokens, self.pos[:T].contiguous())
+        rows = torch.arange(B, device=tokens.device, dtype=torch.int64) * T + (T - 1)
+        picked = self.tower.forward(x, B, T, causal=False, pool_rows=rows)
+        return N.linear(N.layernorm(picked, *self.ln_final), self.w_head, self.b_head)
+
+
+class NativeSigLip(AbstractVLM):
+    """``AbstractVLM`` running the towers of a SigLIP-layout model on HIP kernels.
+
+    ``base`` is an ``AbstractVLM`` whose ``.model`` follows transformers' ``SiglipModel`` layout (``vision_model`` /
+    ``text_model``; the geometry of SigLIP-so400m — width 1152, head_dim 72, MAP pooling — is what BASELINE configs[3]
+    names).  Tokenizer and host preprocessing stay ``base``'s; ``preprocess`` as for :class:`NativeClip`.  open_clip's own
+    timm-based SigLIP modules use other attribute names and are not mapped (open_clip / timm are absent here, so such a
+    mapping could not be tested)."""
+
+    def __init__(self, base, device=None, gemm: str = "bf16x3", preprocess=None):
+        if gemm not in ("bf16x3", "f32"):
+            raise ValueError("gemm must be 'bf16x3' or 'f32'")
+        model = base.model
+        if not (hasattr(model, "vision_model") and hasattr(model, "text_model") and hasattr(model.vision_model, "head")):
+            raise TypeError("NativeSigLip expects a model with `vision_model` (with a MAP `head`) and `text_model`")
+        dev = torch.device(device) if device is not None else next(model.parameters()).device
+        if dev.type != "cuda":
+            dev = N.default_device()
+        self._device = dev
+        self.base = base
+        base.to(dev)
+        split = gemm == "bf16x3"
+        self.vision = NativeSigLipVision(model.vision_model, model.config.vision_config, dev, split)
+        self.text = NativeSigLipText(model.text_model, model.config.text_config, dev, split)
+        self.name = f"native-{gemm}-" + getattr(base, "name", type(base).__name__)
+        if preprocess == "device":
+            from semanticlens_amd.foundation_models.preprocess import DevicePreprocess
+
+            preprocess = DevicePreprocess.from_transform(base.preprocessor)
+        self._preprocess = preprocess.to(dev) if preprocess is not None else None
+
+    @property
+    def device(self):
+        return self._device
+
+    def to(self, device):
+        if torch.device(device).type != "cuda":
+            raise N.NativeLibraryError("NativeSigLip runs on a HIP device only")
+        return self
+
+    def encode_image(self, img):
+        return self.vision(img)
+
+    def encode_text(self, tokens):
+        return self.text(tokens)
+
+    def preprocess(self, img):
+        if self._preprocess is not None:
+            out = self._preprocess(img)
+            return out.unsqueeze(0) if out.ndim == 3 else out
+        return self.base.preprocess(img)
+
+    def tokenize(self, txt, *args, **kwargs):
+        return self.base.tokenize(txt, *args, **kwargs)

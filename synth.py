@@ -287,3 +287,68 @@ def hash_str(s: str) -> int:
     for ch in s.encode():
         h = ((h ^ ch) * 16777619) & 0xFFFFFFFF
     return h
+
+
+# ------------------------------------------------------------------------------------------------
+# SigLIP-shaped foundation model (transformers' SiglipModel, random init) — BASELINE configs[3] names SigLIP-so400m
+# ------------------------------------------------------------------------------------------------
+SIGLIP_SO400M = dict(width=1152, layers=27, heads=16, mlp=4304, image_size=224, patch=14, ctx=64, vocab=32000)
+SIGLIP_MEAN = SIGLIP_STD = (0.5, 0.5, 0.5)
+
+
+class SyntheticSigLip(AbstractVLM):
+    """Random-init SigLIP behind the ``AbstractVLM`` seam: MAP-pooled image tower without a class token, non-causal text
+    tower pooled at the last position (what ``SigLipV2`` / SigLIP-so400m would be without weights).  ``preprocess`` and
+    ``tokenize`` as for :class:`SyntheticClip` (SigLIP pads with token 1 up to the context length)."""
+
+    def __init__(self, device="cpu", seed: int = 1, width=1152, layers=27, heads=16, mlp=4304, image_size=224, patch=14, ctx=64,
+                 vocab=32000, t_layers=None):
+        from transformers import SiglipConfig, SiglipModel
+
+        torch.manual_seed(seed)
+        common = dict(hidden_size=width, intermediate_size=mlp, num_attention_heads=heads)
+        cfg = SiglipConfig(
+            vision_config=dict(num_hidden_layers=layers, image_size=image_size, patch_size=patch, **common),
+            text_config=dict(num_hidden_layers=t_layers or layers, vocab_size=vocab, max_position_embeddings=ctx, projection_size=width,
+                             bos_token_id=None, eos_token_id=None, pad_token_id=1, **common))
+        self.model = SiglipModel(cfg).eval().to(device)
+        self.ctx, self.vocab = ctx, vocab
+        self.name = f"synthetic-siglip-w{width}-l{layers}"
+
+    @property
+    def device(self):
+        return next(self.model.parameters()).device
+
+    def to(self, device):
+        return self.model.to(device)
+
+    @torch.no_grad()
+    def encode_image(self, img):
+        return self.model.vision_model(pixel_values=img).pooler_output
+
+    @torch.no_grad()
+    def encode_text(self, tokens):
+        return self.model.text_model(input_ids=tokens).pooler_output
+
+    def preprocess(self, img):
+        import numpy as np
+
+        def one(i):
+            if isinstance(i, torch.Tensor):
+                return i
+            return torch.from_numpy(np.asarray(i.convert("RGB"))).permute(2, 0, 1)
+
+        batch = torch.stack([one(i) for i in img]) if isinstance(img, (list, tuple)) else one(img)
+        if batch.ndim == 3:
+            batch = batch.unsqueeze(0)
+        return normalize_u8(batch.to(self.device), SIGLIP_MEAN, SIGLIP_STD)
+
+    def tokenize(self, txt, context_length=None):
+        ctx = context_length or self.ctx
+        if isinstance(txt, str):
+            txt = [txt]
+        out = torch.ones(len(txt), ctx, dtype=torch.int64)  # pad id 1
+        for r, s_ in enumerate(txt):
+            ids = [2 + (hash_str(w) % (self.vocab - 2)) for w in s_.lower().split()][:ctx]
+            out[r, : len(ids)] = torch.tensor(ids, dtype=torch.int64)
+        return out.to(self.device)

@@ -187,3 +187,109 @@ def test_linear3_random_shapes_against_fp64():
         assert ((sp.hi.float() + sp.lo.float()).double() - ref).abs().max().item() < tol + 2.0 ** -15 * ref.abs().max().item(), (M, Nn, K)
         if sp.kp != Nn:  # the padding of a split output stays zero (the next GEMM reads it)
             assert sp.buf.view(M, sp.kp // 32, 2, 32)[:, -1, :, Nn % 32:].float().abs().max().item() == 0.0
+
+
+# ---- SigLIP-layout towers (clip.py:190-211 SigLipV2; BASELINE configs[3]: SigLIP-so400m) ------------------------------
+def test_gelu_tanh_and_attention_pool_primitives():
+    g = torch.Generator(device=DEV).manual_seed(4)
+    x = torch.randn(200, 96, device=DEV, generator=g)
+    w = torch.randn(50, 96, device=DEV, generator=g) * 0.2
+    b = torch.randn(50, device=DEV, generator=g)
+    ref = torch.nn.functional.gelu(x @ w.T + b, approximate="tanh")
+    assert rel_err(N.linear(x, w, b, act=N.SL_ACT_GELU_TANH), ref) < 1e-5
+    assert rel_err(N.linear3(N.Split.of(x), N.Split.of(w), b, act=N.SL_ACT_GELU_TANH), ref) < 1e-5
+    # one query per head over T keys == torch MultiheadAttention with a single query token
+    for B, T, H, hd in ((3, 16, 2, 72), (2, 197, 4, 64), (1, 729, 16, 72), (5, 3, 1, 128)):
+        W = H * hd
+        mha = torch.nn.MultiheadAttention(W, H, batch_first=True).to(DEV)
+        probe = torch.randn(1, 1, W, device=DEV, generator=g)
+        xx = torch.randn(B, T, W, device=DEV, generator=g)
+        want = mha(probe.expand(B, 1, W), xx, xx, need_weights=False)[0][:, 0]
+        wq, wkv = mha.in_proj_weight.detach()[:W], mha.in_proj_weight.detach()[W:]
+        bq, bkv = mha.in_proj_bias.detach()[:W], mha.in_proj_bias.detach()[W:]
+        q = N.linear(probe.reshape(1, W), wq, bq).reshape(W)
+        kv = N.linear(xx.reshape(B * T, W), wkv, bkv)
+        got = N.linear(N.attention_pool(q, kv, B, T, H, hd), mha.out_proj.weight.detach(), mha.out_proj.bias.detach())
+        assert rel_err(got, want) < 1e-5, (B, T, H, hd)
+
+
+@pytest.mark.parametrize("gemm", ["bf16x3", "f32"])
+@pytest.mark.parametrize("geom", [dict(width=144, layers=2, heads=2, mlp=288, image_size=64, patch=16, ctx=16, vocab=1000),
+                                  dict(width=1152, layers=2, heads=16, mlp=4304, image_size=224, patch=14, ctx=64, vocab=32000)])
+def test_native_siglip_matches_the_torch_module(geom, gemm):
+    """MAP-pooled image tower without class token, non-causal text tower pooled at the last position, head_dim 72
+    (second case: the SigLIP-so400m geometry at two layers) against transformers' SiglipModel with the same weights."""
+    from semanticlens_amd.foundation_models.native_clip import NativeSigLip
+
+    base = synth.SyntheticSigLip(device=DEV, seed=3, **geom)
+    fm = NativeSigLip(base, gemm=gemm)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    img = torch.randn(5, 3, geom["image_size"], geom["image_size"], device=DEV, generator=g)
+    want_i = base.encode_image(img)
+    got_i = fm.encode_image(img)
+    assert got_i.shape == want_i.shape == (5, geom["width"])
+    assert rel_err(got_i, want_i) < 2e-5, rel_err(got_i, want_i)
+    tok = base.tokenize(["a photo of a cat", "zebra", "a very long prompt about " + "stripes " * 80, ""])
+    want_t = base.encode_text(tok)
+    got_t = fm.encode_text(tok)
+    assert got_t.shape == want_t.shape == (4, geom["width"])
+    assert rel_err(got_t, want_t) < 2e-5, rel_err(got_t, want_t)
+
+
+def test_config3_end_to_end_vit_probe_siglip_embed_text_probing():
+    """BASELINE configs[3] at reduced depth: ViT-B/16-geometry blocks probed with the token-max aggregator, SigLIP-so400m
+    geometry (two layers) as the foundation model running natively, `text_probing` over 10 000 prompts through the native
+    text tower and the cosine GEMM — against the same pipeline with the torch SigLIP module."""
+    from semanticlens_amd import Lens
+    from semanticlens_amd.component_visualization import ActivationComponentVisualizer, aggregators
+    from semanticlens_amd.foundation_models.native_clip import NativeSigLip
+
+    torch.manual_seed(0)
+
+    class Vit(torch.nn.Module):  # patch embedding + 2 encoder blocks of width 768 over 197 tokens
+        def __init__(self):
+            super().__init__()
+            self.patch = torch.nn.Conv2d(3, 768, 16, 16)
+            self.cls = torch.nn.Parameter(torch.randn(1, 1, 768) * 0.02)
+            self.blocks = torch.nn.ModuleList([synth._Block(768, 12) for _ in range(2)])
+            self.name = "vit-b16-2blocks"
+
+        def forward(self, x):
+            t = torch.cat([self.cls.expand(x.shape[0], 1, 768), self.patch(x).flatten(2).transpose(1, 2)], 1)
+            for b in self.blocks:
+                t = b(t)
+            return t[:, 0]
+
+    n, k = 96, 8
+    u8 = synth.synth_images_u8(torch.arange(n, device=DEV)).cpu()
+
+    class DS(torch.utils.data.Dataset):
+        def __init__(self, mode):
+            self.mode, self.name = mode, f"c3-{n}"
+
+        def __len__(self):
+            return n
+
+        def __getitem__(self, i):
+            if self.mode == "model":
+                return synth.normalize_u8(u8[i:i + 1], synth.IMAGENET_MEAN, synth.IMAGENET_STD)[0], 0
+            return u8[i]
+
+    base = synth.SyntheticSigLip(device=DEV, seed=5, width=1152, layers=2, heads=16, mlp=4304, image_size=224, patch=14, ctx=64)
+    model = Vit().to(DEV).eval()
+    dbs, probes = {}, {}
+    words = ["zebra", "stripe", "wheel", "sky", "grass", "dog", "cat", "red", "round", "metal"]
+    prompts = [f"a photo of a {words[i % 10]} {words[(i // 10) % 10]} {i}" for i in range(10000)]
+    for tag, fm in (("native", NativeSigLip(base)), ("torch", base)):
+        cv = ActivationComponentVisualizer(model, DS("model"), DS("fm"), ["blocks.0", "blocks.1"], num_samples=k,
+                                           aggregate_fn=aggregators.aggregate_transformer_max, tie_mode="aten")
+        lens = Lens(fm, device=DEV)
+        dbs[tag] = lens.compute_concept_db(cv, batch_size=32)
+        agg = {name: v.mean(1) for name, v in dbs[tag].items()}
+        probes[tag] = lens.text_probing(prompts, agg, batch_size=2500)
+    for name in ("blocks.0", "blocks.1"):
+        assert dbs["native"][name].shape == (768, k, 1152)
+        scale = dbs["torch"][name].abs().max().item()
+        assert (dbs["native"][name] - dbs["torch"][name]).abs().max().item() < 1e-4 * scale
+        assert probes["native"][name].shape == (10000, 768)
+        assert (probes["native"][name] - probes["torch"][name]).abs().max().item() < 1e-4  # north_star: cosines within 1e-4
