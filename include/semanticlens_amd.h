@@ -184,6 +184,17 @@ int sl_poly2means(const float* d_V, int64_t C, int64_t n, int64_t D, const int32
                   size_t ws_bytes, void* stream);
 size_t sl_poly2means_ws_bytes(int64_t C, int64_t n, int64_t D);
 
+/* The same for any `n_clusters` in [2, 16] (scores.py:132,167 forwards the argument to scikit-learn) and n <= 1024:
+ * sklearn's k-means++ with 2 + int(ln k) local trials per further centre, Lloyd with relocation of every empty cluster
+ * (ascending cluster id, farthest points first), score = 1 - clarity_score of the k centres.  h_rand is
+ * (n_init, n_clusters - 1, sl_kmeans_trials(n_clusters)) float64: RandomState.uniform draws in sklearn's order.
+ * State lives in the workspace (L2) rather than LDS: the fallback for what sl_poly2means does not cover. */
+int sl_kmeans_trials(int n_clusters);
+int sl_polykmeans(const float* d_V, int64_t C, int64_t n, int64_t D, int n_clusters, const int32_t* h_first_center, int n_init,
+                  const double* h_rand, int replace_empty_clusters, double* d_out, int32_t* d_min_count, void* d_ws,
+                  size_t ws_bytes, void* stream);
+size_t sl_polykmeans_ws_bytes(int64_t C, int64_t n, int64_t D, int n_clusters, int n_init);
+
 /* ---- K10: template-difference mean of text embeddings (lens.py:196-199) ------------------
  * E (Q*T,D) read as "(q t) d", E0 (T,D); out (Q,D) = mean_t(E[q,t] - E0[t]). */
 int sl_template_mean(const float* d_E, const float* d_E0, int64_t Q, int64_t T, int64_t D, float* d_out,

@@ -63,6 +63,9 @@ SIGNATURES = {
     "sl_template_mean": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "sl_poly2means": (_int, [_vp, _i64, _i64, _i64, _vp, _int, _vp, _int, _vp, _vp, _vp, _sz, _vp]),
     "sl_poly2means_ws_bytes": (_sz, [_i64, _i64, _i64]),
+    "sl_kmeans_trials": (_int, [_int]),
+    "sl_polykmeans": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _int, _vp, _int, _vp, _vp, _vp, _sz, _vp]),
+    "sl_polykmeans_ws_bytes": (_sz, [_i64, _i64, _i64, _int, _int]),
     "sl_linear": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "sl_layernorm": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, ctypes.c_float, _vp, _vp, _i64, _vp]),
     "sl_attention": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp]),
@@ -397,8 +400,11 @@ def prof_read(family: int):
 # ------------------------------------------------------------------------------------------------
 # K9
 # ------------------------------------------------------------------------------------------------
-def poly2means(V: torch.Tensor, first_center, rand, replace_empty_clusters: bool = True) -> torch.Tensor:
-    """polysemanticity of V (C,n,D): 2-means per component on the device; float64 (C,) result."""
+POLY2_MAX_N = 128  # sl_poly2means keeps a component's state in LDS; larger n / other k: sl_polykmeans
+
+
+def poly2means(V: torch.Tensor, first_center, rand, replace_empty_clusters: bool = True, n_clusters: int = 2) -> torch.Tensor:
+    """polysemanticity of V (C,n,D): k-means per component on the device; float64 (C,) result."""
     import numpy as np
 
     Vd = _f32c(V)
@@ -410,6 +416,17 @@ def poly2means(V: torch.Tensor, first_center, rand, replace_empty_clusters: bool
     n_init = int(first_center.shape[0])
     out = torch.empty((C,), dtype=torch.float64, device=Vd.device)
     mincnt = torch.empty((C,), dtype=torch.int32, device=Vd.device)
+    if n_clusters != 2 or n > POLY2_MAX_N:
+        nbytes = int(lib().sl_polykmeans_ws_bytes(C, n, D, n_clusters, n_init))
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=Vd.device)
+        with torch.cuda.device(Vd.device):
+            rc = lib().sl_polykmeans(
+                _ptr(Vd), C, n, D, int(n_clusters), first_center.ctypes.data_as(_vp), n_init, rand.ctypes.data_as(_vp),
+                1 if replace_empty_clusters else 0, _ptr(out), _ptr(mincnt), _ptr(ws), nbytes, _stream(Vd),
+            )
+            torch.cuda.current_stream(Vd.device).synchronize()  # the draws were copied from host arrays owned by this call
+        _check(rc, "sl_polykmeans")
+        return out
     nbytes = int(lib().sl_poly2means_ws_bytes(C, n, D))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=Vd.device)
     with torch.cuda.device(Vd.device):

@@ -394,6 +394,374 @@ __global__ __launch_bounds__(64) void kmeans2_kernel(const double* __restrict__ 
   }
 }
 
+// ---- general path: any n_clusters (<= kMaxClusters), n_samples up to kMaxNGeneral ------------------------------------
+// The same restatement with k member sets.  State that does not fit LDS for every (n, k) lives in a per-component
+// slice of the workspace (L2-resident: one wavefront walks it): the centred Gram matrix, sum_{l in S_j} G_il for the
+// current and the next member sets, the k-means++ distance arrays, labels.  LDS holds the per-cluster scalars and a
+// (k x 64) pad of per-lane accumulators.  scikit-learn specifics restated (sklearn/cluster/_kmeans.py, 1.7.2):
+//   * _kmeans_plusplus: n_local_trials = 2 + int(ln k) candidates per further centre, np.searchsorted on the cumulative
+//     closest distances, np.argmin (first minimum) over the candidates' potentials;
+//   * E-step: first minimum of ||c_j||^2 - 2 x_i.c_j; empty clusters take, in ascending cluster id, the points farthest
+//     from their own centre (descending distance) and those points leave their old cluster (_relocate_empty_clusters_dense);
+//   * strict convergence (labels unchanged) / tol = mean(var) * 1e-4 on the summed squared centre shifts / 300 iterations,
+//     a final E-step when not strictly converged, best of n_init by inertia unless _is_same_clustering.
+// Checked against scikit-learn on the host first (a numpy transcription of this kernel: 460 components, k = 2..6, with
+// duplicated points that force relocations — every clustering identical) and on the device by tests/test_gpu_parity.py.
+constexpr int kMaxClusters = 16, kMaxNGeneral = 1024, kMaxTrials = 4;
+
+struct GenWs {  // offsets (in doubles / ints) of one component's slice
+  double *G, *s, *sn, *closest, *cand;  // n*n, k*n, k*n, n, trials*n
+  int *label, *label_old, *member, *best_label, *best_member;
+};
+__host__ __device__ inline size_t gen_ws_doubles(int64_t n, int64_t k) { return (size_t)(n * n + 2 * k * n + n + kMaxTrials * n); }
+__host__ __device__ inline size_t gen_ws_bytes_per_component(int64_t n, int64_t k) {
+  return ((gen_ws_doubles(n, k) * 8 + (size_t)5 * n * 4) + 255) & ~(size_t)255;
+}
+
+__global__ __launch_bounds__(64) void kmeansk_kernel(const double* __restrict__ Hall, int64_t C, int n, int64_t D, int k, int trials,
+                                                      int n_init, const int32_t* __restrict__ first, const double* __restrict__ rnd,
+                                                      int replace_empty, unsigned char* __restrict__ ws_all, size_t ws_stride,
+                                                      double* __restrict__ out, int32_t* __restrict__ min_count) {
+  __shared__ double s_acc[kMaxClusters * kWave];  // per-lane accumulators, one column per lane
+  __shared__ double s_cnt[kMaxClusters], s_W[kMaxClusters], s_ncnt[kMaxClusters], s_nW[kMaxClusters], s_x[kMaxClusters];
+  __shared__ double s_dot[kMaxClusters * kMaxClusters];
+  __shared__ int s_seed[kMaxClusters], s_count[kMaxClusters], s_map[kMaxClusters];
+  const int lane = threadIdx.x;
+  const int64_t c = blockIdx.x;
+  if (c >= C) return;
+  unsigned char* base = ws_all + c * ws_stride;
+  GenWs w;
+  double* p = reinterpret_cast<double*>(base);
+  w.G = p; p += (size_t)n * n;
+  w.s = p; p += (size_t)k * n;
+  w.sn = p; p += (size_t)k * n;
+  w.closest = p; p += n;
+  w.cand = p; p += (size_t)kMaxTrials * n;
+  int* q = reinterpret_cast<int*>(p);
+  w.label = q; q += n;
+  w.label_old = q; q += n;
+  w.member = q; q += n;
+  w.best_label = q; q += n;
+  w.best_member = q; q += n;
+  const double* H = Hall + c * (int64_t)n * n;
+
+  // H -> centred G; r_i kept in w.cand[3n..4n) is not safe (cand is reused): recompute r_i where needed from H
+  double musum = 0.0;
+  for (int i = lane; i < n; i += kWave) {
+    double t = 0.0;
+    for (int j = 0; j < n; ++j) t += H[(size_t)i * n + j];
+    w.closest[i] = t / n;  // r_i, parked until G is built
+    musum += t / n;
+  }
+  const double mu = wave_sum(musum) / n;
+  __syncthreads();
+  double tr = 0.0;
+  for (int i = lane; i < n; i += kWave) {
+    const double ri = w.closest[i];
+    for (int j = 0; j < n; ++j) w.G[(size_t)i * n + j] = H[(size_t)i * n + j] - ri - w.closest[j] + mu;
+    tr += H[(size_t)i * n + i] - 2.0 * ri + mu;
+  }
+  __syncthreads();
+  const double tol = wave_sum(tr) / ((double)n * (double)D) * 1e-4;
+  auto Gd = [&](int i) { return w.G[(size_t)i * n + i]; };
+  auto dist_to = [&](int i, int cc) {
+    double d = Gd(i) + Gd(cc) - 2.0 * w.G[(size_t)i * n + cc];
+    return d > 0.0 ? d : 0.0;
+  };
+  // squared distance of point i to current centre j without the G_ii term
+  auto dpart = [&](const double* sarr, int i, int j) { return s_W[j] - 2.0 * sarr[(size_t)j * n + i] / s_cnt[j]; };
+  // member sets m[] -> sums so[j][i] = sum_{l in S_j} G_il, counts, W_j (into s_ncnt / s_nW)
+  auto subset_stats = [&](const int* m, double* so) {
+    for (int j = lane; j < k; j += kWave) s_count[j] = 0;
+    __syncthreads();
+    for (int i = lane; i < n; i += kWave) atomicAdd(&s_count[m[i]], 1);
+    for (int i0 = 0; i0 < n; i0 += kWave) {
+      const int i = i0 + lane;
+      for (int j = 0; j < k; ++j) s_acc[j * kWave + lane] = 0.0;
+      if (i < n) {
+        const double* Gi = w.G + (size_t)i * n;
+        for (int l = 0; l < n; ++l) s_acc[m[l] * kWave + lane] += Gi[l];
+        for (int j = 0; j < k; ++j) so[(size_t)j * n + i] = s_acc[j * kWave + lane];
+      }
+    }
+    __syncthreads();
+    for (int j = 0; j < k; ++j) {  // W_j = sum_{i in S_j} so[j][i] / |S_j|^2
+      double t = 0.0;
+      for (int i = lane; i < n; i += kWave)
+        if (m[i] == j) t += so[(size_t)j * n + i];
+      t = wave_sum(t);
+      if (lane == 0) {
+        s_ncnt[j] = (double)s_count[j];
+        s_nW[j] = s_count[j] ? t / ((double)s_count[j] * (double)s_count[j]) : 0.0;
+      }
+    }
+    __syncthreads();
+  };
+  auto estep = [&](const double* sarr, int* lab) {
+    for (int i = lane; i < n; i += kWave) {
+      int bj = 0;
+      double bd = dpart(sarr, i, 0);
+      for (int j = 1; j < k; ++j) {
+        const double d = dpart(sarr, i, j);
+        if (d < bd) {
+          bd = d;
+          bj = j;
+        }
+      }
+      lab[i] = bj;
+    }
+    __syncthreads();
+  };
+
+  double best_inertia = 0.0;
+  bool have_best = false;
+  double* s_cur = w.s;
+  double* s_new = w.sn;
+  for (int init = 0; init < n_init; ++init) {
+    // ---- k-means++ ----
+    const int c0 = first[init];
+    if (lane == 0) s_seed[0] = c0;
+    double pot = 0.0;
+    for (int i = lane; i < n; i += kWave) {
+      const double d = dist_to(i, c0);
+      w.closest[i] = d;
+      pot += d;
+    }
+    pot = wave_sum(pot);
+    __syncthreads();
+    for (int cc = 1; cc < k; ++cc) {
+      const double* rv = rnd + ((size_t)init * (k - 1) + (cc - 1)) * trials;
+      int cand[kMaxTrials];
+      for (int t = 0; t < trials; ++t) cand[t] = n;
+      double cs = 0.0;
+      for (int i = 0; i < n; ++i) {  // lane-uniform: searchsorted(cumsum(closest), rand * pot), side='left'
+        cs += w.closest[i];
+        for (int t = 0; t < trials; ++t)
+          if (cand[t] == n && cs >= rv[t] * pot) cand[t] = i;
+      }
+      double pots[kMaxTrials];
+      for (int t = 0; t < trials; ++t) {
+        if (cand[t] >= n) cand[t] = n - 1;
+        double sum = 0.0;
+        for (int i = lane; i < n; i += kWave) {
+          const double d = dist_to(i, cand[t]);
+          const double mn = d < w.closest[i] ? d : w.closest[i];
+          w.cand[(size_t)t * n + i] = mn;
+          sum += mn;
+        }
+        pots[t] = wave_sum(sum);
+      }
+      int b = 0;
+      for (int t = 1; t < trials; ++t)
+        if (pots[t] < pots[b]) b = t;  // np.argmin: first minimum
+      pot = pots[b];
+      __syncthreads();
+      for (int i = lane; i < n; i += kWave) w.closest[i] = w.cand[(size_t)b * n + i];
+      if (lane == 0) s_seed[cc] = cand[b];
+      __syncthreads();
+    }
+    // ---- Lloyd ----
+    for (int j = lane; j < k; j += kWave) {
+      s_cnt[j] = 1.0;
+      s_W[j] = Gd(s_seed[j]);
+    }
+    for (int i = lane; i < n; i += kWave) {
+      for (int j = 0; j < k; ++j) s_cur[(size_t)j * n + i] = w.G[(size_t)i * n + s_seed[j]];
+      w.label_old[i] = -1;
+    }
+    __syncthreads();
+    bool strict = false;
+    for (int it = 0; it < 300; ++it) {
+      estep(s_cur, w.label);
+      for (int j = lane; j < k; j += kWave) s_count[j] = 0;
+      __syncthreads();
+      for (int i = lane; i < n; i += kWave) {
+        w.member[i] = w.label[i];
+        atomicAdd(&s_count[w.label[i]], 1);
+      }
+      __syncthreads();
+      bool any_empty = false;
+      for (int j = 0; j < k; ++j) any_empty |= (s_count[j] == 0);
+      if (any_empty) {  // relocation: lane-uniform and sequential (rare)
+        for (int i = lane; i < n; i += kWave) w.cand[i] = Gd(i) + dpart(s_cur, i, w.label[i]);
+        __syncthreads();
+        for (int j = 0; j < k; ++j) {
+          if (s_count[j] != 0) continue;
+          double bestd = -__builtin_huge_val();
+          int besti = 0;
+          for (int i = 0; i < n; ++i) {
+            const double d = w.cand[i];
+            if (d > bestd) {
+              bestd = d;
+              besti = i;
+            }
+          }
+          __syncthreads();
+          if (lane == 0) {
+            w.member[besti] = j;
+            w.cand[besti] = -__builtin_huge_val();  // taken
+          }
+          __syncthreads();
+        }
+      }
+      subset_stats(w.member, s_new);
+      // centre shift^2 = sum_j W_old + W_new - 2 <c_old, c_new>
+      for (int j = 0; j < k; ++j) {
+        double x = 0.0;
+        for (int i = lane; i < n; i += kWave)
+          if (w.member[i] == j) x += s_cur[(size_t)j * n + i];
+        x = wave_sum(x);
+        if (lane == 0) s_x[j] = x;
+      }
+      __syncthreads();
+      double shift = 0.0;
+      for (int j = 0; j < k; ++j) shift += s_W[j] + s_nW[j] - 2.0 * s_x[j] / (s_cnt[j] * (s_ncnt[j] > 0 ? s_ncnt[j] : 1.0));
+      __syncthreads();
+      {
+        double* t = s_cur;
+        s_cur = s_new;
+        s_new = t;
+      }
+      for (int j = lane; j < k; j += kWave) {
+        s_cnt[j] = s_ncnt[j];
+        s_W[j] = s_nW[j];
+      }
+      int same = 1;
+      for (int i = lane; i < n; i += kWave) same &= (w.label[i] == w.label_old[i]);
+      same = __all(same);
+      __syncthreads();
+      if (same) {
+        strict = true;
+        break;
+      }
+      if (shift <= tol) break;
+      for (int i = lane; i < n; i += kWave) w.label_old[i] = w.label[i];
+      __syncthreads();
+    }
+    if (!strict) estep(s_cur, w.label);
+    double inertia = 0.0;
+    for (int i = lane; i < n; i += kWave) inertia += Gd(i) + dpart(s_cur, i, w.label[i]);
+    inertia = wave_sum(inertia);
+    bool take = !have_best;
+    if (have_best && inertia < best_inertia) {  // _is_same_clustering
+      for (int j = lane; j < k; j += kWave) s_map[j] = -1;
+      __syncthreads();
+      bool same_clu = true;
+      if (lane == 0) {
+        for (int i = 0; i < n && same_clu; ++i) {
+          const int a = w.label[i], b = w.best_label[i];
+          if (s_map[a] == -1) s_map[a] = b;
+          else if (s_map[a] != b) same_clu = false;
+        }
+        s_count[0] = same_clu ? 1 : 0;
+      }
+      __syncthreads();
+      take = s_count[0] == 0;
+      __syncthreads();
+    }
+    if (take) {
+      best_inertia = inertia;
+      have_best = true;
+      for (int i = lane; i < n; i += kWave) {
+        w.best_label[i] = w.label[i];
+        w.best_member[i] = w.member[i];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- scores.py:168-185 on the chosen clustering: 1 - clarity(centres), clarity over the k centre vectors ----
+  // original-space centres c_j = centred centre + mean:  c_j.c_l = g_jl + (R_j - mu) + (R_l - mu) + mu, with
+  // g_jl = sum_{a in S_j} s_l[a] / (n_j n_l) (centred) and R_j = mean_{a in S_j} r_a, r_a = mean_b H_ab
+  subset_stats(w.best_member, s_cur);
+  for (int j = 0; j < k; ++j) {
+    double rj = 0.0;
+    for (int i = lane; i < n; i += kWave) {
+      if (w.best_member[i] == j) {
+        double t = 0.0;
+        for (int b = 0; b < n; ++b) t += H[(size_t)i * n + b];
+        rj += t / n;
+      }
+    }
+    rj = wave_sum(rj);
+    if (lane == 0) s_x[j] = s_ncnt[j] > 0 ? rj / s_ncnt[j] : 0.0;
+  }
+  __syncthreads();
+  for (int j = 0; j < k; ++j)
+    for (int l = 0; l < k; ++l) {
+      double t = 0.0;
+      for (int i = lane; i < n; i += kWave)
+        if (w.best_member[i] == j) t += s_cur[(size_t)l * n + i];
+      t = wave_sum(t);
+      if (lane == 0) {
+        const double g = (s_ncnt[j] > 0 && s_ncnt[l] > 0) ? t / (s_ncnt[j] * s_ncnt[l]) : 0.0;
+        s_dot[j * k + l] = (s_ncnt[j] > 0 && s_ncnt[l] > 0) ? g + (s_x[j] - mu) + (s_x[l] - mu) + mu : 0.0;
+      }
+    }
+  for (int j = lane; j < k; j += kWave) s_count[j] = 0;
+  __syncthreads();
+  for (int i = lane; i < n; i += kWave) atomicAdd(&s_count[w.best_label[i]], 1);
+  __syncthreads();
+  if (lane == 0) {
+    // clarity_score of the centres:  ((mean_j c_j^)^2.sum() - 1/k) / (k - 1) * k,  c^ = c / max(||c||, 1e-12)
+    double inv[kMaxClusters];
+    for (int j = 0; j < k; ++j) {
+      const double n2 = s_dot[j * k + j] > 0 ? s_dot[j * k + j] : 0.0;
+      const double nn = sqrt(n2);
+      inv[j] = 1.0 / (nn > 1e-12 ? nn : 1e-12);
+    }
+    double msq = 0.0;
+    for (int j = 0; j < k; ++j)
+      for (int l = 0; l < k; ++l) msq += s_dot[j * k + l] * inv[j] * inv[l];
+    msq /= (double)k * (double)k;
+    double poly = 1.0 - (msq - 1.0 / k) / (double)(k - 1) * (double)k;
+    int mc = n, distinct = 0;
+    for (int j = 0; j < k; ++j) {
+      if (s_count[j] > 0) ++distinct;
+      mc = s_count[j] < mc ? s_count[j] : mc;
+    }
+    if (distinct < k) mc = 0;  // the reference zero-fills the counts when a label is missing (scores.py:177)
+    if (replace_empty && mc < 2) {
+      const int ns = n < 10 ? n : 10;
+      const double nm = sqrt(mu > 0 ? mu : 0.0);
+      const double im = 1.0 / (nm > 1e-12 ? nm : 1e-12);
+      double acc = 0.0;
+      for (int i = 0; i < ns; ++i) {
+        const double hii = H[(size_t)i * n + i];
+        double ri = 0.0;
+        for (int b = 0; b < n; ++b) ri += H[(size_t)i * n + b];
+        ri /= n;
+        const double ni = sqrt(hii > 0 ? hii : 0.0);
+        const double ii = 1.0 / (ni > 1e-12 ? ni : 1e-12);
+        const double m2 = (mu * im * im + hii * ii * ii + 2.0 * ri * im * ii) / 4.0;
+        acc += (m2 - 0.5) * 2.0;
+      }
+      poly = 1.0 - acc / ns;
+    }
+    out[c] = poly;
+    if (min_count) min_count[c] = mc;
+  }
+}
+
+// Gram matrices for any n (the staged kernel above keeps a register array sized for n <= 128): one thread per pair,
+// rows read from L2.  H[c] = V_c V_c^T in fp64.
+__global__ __launch_bounds__(256) void gram_general_kernel(const float* __restrict__ V, int64_t C, int n, int64_t D,
+                                                            double* __restrict__ H) {
+  const int64_t c = blockIdx.y;
+  const int64_t npairs = (int64_t)n * n;
+  const float* Vc = V + c * (int64_t)n * D;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npairs; p += (int64_t)gridDim.x * 256) {
+    const int i = (int)(p / n), j = (int)(p % n);
+    if (j < i) continue;
+    const float* a = Vc + (int64_t)i * D;
+    const float* b = Vc + (int64_t)j * D;
+    double s = 0.0;
+    for (int64_t d = 0; d < D; ++d) s += (double)a[d] * (double)b[d];
+    H[(c * n + i) * n + j] = s;
+    H[(c * n + j) * n + i] = s;
+  }
+}
+
 size_t kmeans_smem_bytes(int64_t n) { return (size_t)n * n * 8 + (size_t)n * 6 * 8 + (size_t)n * 6 * 4 + 64; }
 
 }  // namespace
@@ -441,6 +809,55 @@ SL_API int sl_poly2means(const float* d_V, int64_t C, int64_t n, int64_t D, cons
     SL_CHECK_HIP(hipFuncSetAttribute((const void*)kmeans2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(kmeans2_kernel, dim3((unsigned)C), dim3(64), smem, st, (const double*)H, C, (int)n, D, dr,
                      replace_empty_clusters, d_out, d_min_count);
+  SL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- any n_clusters / larger n: the general kernel ---------------------------------------------------------------------
+SL_API int sl_kmeans_trials(int n_clusters) { return n_clusters >= 1 ? 2 + (int)log((double)n_clusters) : 0; }
+
+SL_API size_t sl_polykmeans_ws_bytes(int64_t C, int64_t n, int64_t D, int n_clusters, int n_init) {
+  (void)D;
+  if (C < 0 || n < 0 || n_clusters < 1 || n_init < 1) return 0;
+  const size_t draws = (size_t)n_init * 4 + (size_t)n_init * (size_t)(n_clusters > 1 ? n_clusters - 1 : 1) * kMaxTrials * 8;
+  return (size_t)C * (size_t)n * (size_t)n * 8 + (size_t)C * gen_ws_bytes_per_component(n, n_clusters) + ((draws + 255) & ~(size_t)255) + 512;
+}
+
+SL_API int sl_polykmeans(const float* d_V, int64_t C, int64_t n, int64_t D, int n_clusters, const int32_t* h_first_center,
+                         int n_init, const double* h_rand, int replace_empty_clusters, double* d_out, int32_t* d_min_count,
+                         void* d_ws, size_t ws_bytes, void* stream) {
+  SL_REQUIRE(C >= 0 && n >= 0 && D >= 0, "sl_polykmeans: negative shape");
+  if (C == 0) return 0;
+  SL_REQUIRE(n_clusters >= 2 && n_clusters <= kMaxClusters, "sl_polykmeans: n_clusters=%d not in [2, %d]", n_clusters, kMaxClusters);
+  SL_REQUIRE(n >= n_clusters, "sl_polykmeans: n_samples=%lld should be >= n_clusters=%d.", (long long)n, n_clusters);  // sklearn's ValueError
+  SL_REQUIRE(n <= kMaxNGeneral, "sl_polykmeans: n_samples=%lld exceeds the supported maximum %d", (long long)n, kMaxNGeneral);
+  SL_REQUIRE(n_init >= 1 && n_init <= 32, "sl_polykmeans: n_init=%d not in [1, 32]", n_init);
+  SL_REQUIRE(d_V && d_out && h_first_center && h_rand, "sl_polykmeans: null pointer");
+  SL_REQUIRE(d_ws && ws_bytes >= sl_polykmeans_ws_bytes(C, n, D, n_clusters, n_init), "sl_polykmeans: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int trials = sl_kmeans_trials(n_clusters);
+  for (int i = 0; i < n_init; ++i)
+    SL_REQUIRE(h_first_center[i] >= 0 && h_first_center[i] < n, "sl_polykmeans: first centre %d out of range", h_first_center[i]);
+  unsigned char* p = reinterpret_cast<unsigned char*>(((uintptr_t)d_ws + 255) & ~(uintptr_t)255);
+  double* H = reinterpret_cast<double*>(p);
+  p += (size_t)C * n * n * 8;
+  unsigned char* slices = p;
+  const size_t stride = gen_ws_bytes_per_component(n, n_clusters);
+  p += (size_t)C * stride;
+  double* d_rand = reinterpret_cast<double*>(p);
+  const size_t rand_bytes = (size_t)n_init * (n_clusters - 1) * trials * 8;
+  int32_t* d_first = reinterpret_cast<int32_t*>(p + ((rand_bytes + 255) & ~(size_t)255));
+  // the data-independent draws of numpy's RandomState (host) -> device; pageable source: the copy is staged by the runtime
+  SL_CHECK_HIP(hipMemcpyAsync(d_rand, h_rand, rand_bytes, hipMemcpyHostToDevice, st));
+  SL_CHECK_HIP(hipMemcpyAsync(d_first, h_first_center, (size_t)n_init * 4, hipMemcpyHostToDevice, st));
+  {
+    ProfScope prof(SL_PROF_SCORES, st, (double)C * n * D * 4);
+    int64_t bx = ((int64_t)n * n + 255) / 256;
+    if (bx > 64) bx = 64;
+    SL_LAUNCH(prof, gram_general_kernel, dim3((unsigned)bx, (unsigned)C), dim3(256), 0, st, d_V, C, (int)n, D, H);
+  }
+  hipLaunchKernelGGL(kmeansk_kernel, dim3((unsigned)C), dim3(64), 0, st, (const double*)H, C, (int)n, D, n_clusters, trials, n_init,
+                     (const int32_t*)d_first, (const double*)d_rand, replace_empty_clusters, slices, stride, d_out, d_min_count);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -47,35 +47,37 @@ def similarity_score(x, y):
     return N.similarity(x, y).to(x.device)
 
 
-def kmeans_draws(n_samples: int, n_init: int, random_state: int):
-    """The random draws scikit-learn's ``KMeans(n_init, random_state)`` consumes, per init.
+def kmeans_draws(n_samples: int, n_init: int, random_state: int, n_clusters: int = 2):
+    """The random draws scikit-learn's ``KMeans(n_clusters, n_init, random_state)`` consumes, per init.
 
-    ``KMeans.fit`` seeds one ``RandomState(random_state)`` and, for each of the ``n_init`` k-means++
-    seedings with 2 clusters, draws ``choice(n_samples, p=uniform)`` for the first centre and
-    ``uniform(size=2 + int(log(2)))`` for the two candidate second centres
-    (sklearn/cluster/_kmeans.py ``_kmeans_plusplus``).  None of it depends on the data, so the host
-    produces the draws and the device kernel consumes them.
+    ``KMeans.fit`` seeds one ``RandomState(random_state)`` and, for each of the ``n_init`` k-means++ seedings, draws
+    ``choice(n_samples, p=uniform)`` for the first centre and, for every further centre,
+    ``uniform(size=2 + int(log(n_clusters)))`` for its candidates (sklearn/cluster/_kmeans.py ``_kmeans_plusplus``).
+    None of it depends on the data, so the host produces the draws and the device kernel consumes them.
+    Returns ``first (n_init,) int32`` and ``rand (n_init, n_clusters - 1, trials) float64``.
     """
     rs = np.random.RandomState(random_state)
-    weights = np.ones(n_samples, dtype=np.float32)
+    weights = np.ones(n_samples, dtype=np.float64)  # KMeans' sample_weight takes X's dtype: float64 (see oracle)
     p = weights / weights.sum()
+    trials = 2 + int(np.log(n_clusters))
     first = np.empty(n_init, dtype=np.int32)
-    rand = np.empty((n_init, 2), dtype=np.float64)
+    rand = np.empty((n_init, max(n_clusters - 1, 1), trials), dtype=np.float64)
     for i in range(n_init):
         first[i] = rs.choice(n_samples, p=p)
-        rand[i] = rs.uniform(size=2)
+        for c in range(n_clusters - 1):
+            rand[i, c] = rs.uniform(size=trials)
     return first, rand
 
 
 @torch.inference_mode()
 def polysemanticity_score(V, replace_empty_clusters=True, random_state=123, n_clusters=2):
-    """``1 - cos(centre_1, centre_2)`` of a 2-means clustering of each component's samples.
+    """``1 - clarity_score(centres)`` of a k-means clustering of each component's samples (``n_clusters`` = 2 by default:
+    ``1 - cos(centre_1, centre_2)``).
 
-    Reference: scores.py:131-185 (scikit-learn ``KMeans(n_clusters=2, n_init=10, random_state=123)``
-    per component in a Python loop).  Kernel K9 restates that procedure per component on the
-    device; rows whose smaller cluster has fewer than 2 samples use the reference's fallback.
+    Reference: scores.py:131-185 (scikit-learn ``KMeans(n_clusters, n_init=10, random_state=123)`` per component in a
+    Python loop).  Kernel K9 restates that procedure per component on the device for ``n_clusters`` up to 16 and up to
+    1024 samples per component; rows whose smallest cluster has fewer than 2 samples use the reference's fallback.
+    ``n_samples < n_clusters`` raises ``ValueError`` as scikit-learn does.
     """
-    if n_clusters != 2:
-        raise NotImplementedError("the device kernel restates KMeans for n_clusters=2 (the reference's default)")
-    first, rand = kmeans_draws(V.shape[-2], 10, random_state)
-    return N.poly2means(V, first, rand, replace_empty_clusters).to(V.device)
+    first, rand = kmeans_draws(V.shape[-2], 10, random_state, n_clusters)
+    return N.poly2means(V, first, rand, replace_empty_clusters, n_clusters=n_clusters).to(V.device)

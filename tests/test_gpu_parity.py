@@ -492,7 +492,7 @@ def test_polysemanticity_goldens(golden):
     assert scores.polysemanticity_score(torch.from_numpy(g["P10"])).device.type == "cpu"
 
 
-def assert_polysemanticity_matches(got, V, tag=""):
+def assert_polysemanticity_matches(got, V, tag="", n_clusters=2):
     """Every component must reproduce scikit-learn's clustering — no tolerated minority.
 
     The reference is deterministic (scores.py:167, random_state=123).  Rows scored from the cluster centres are
@@ -500,7 +500,7 @@ def assert_polysemanticity_matches(got, V, tag=""):
     clustering was chosen.  Rows that take the fallback branch (scores.py:178-184) are computed by the reference
     through the fp32 ``clarity_score``: 1e-6.  Observed on MI355X (tools/k9_rate.py): 100 % of 2 400 components.
     """
-    want, fallback = oracle.polysemanticity(V, return_fallback=True)
+    want, fallback = oracle.polysemanticity(V, n_clusters=n_clusters, return_fallback=True)
     diff = np.abs(got - want)
     print(f"K9 {tag}: {len(want)} components, {int(fallback.sum())} fallback rows, max |diff| centres "
           f"{diff[~fallback].max() if (~fallback).any() else 0:.2e}, fallback {diff[fallback].max() if fallback.any() else 0:.2e}")
@@ -529,6 +529,27 @@ def test_polysemanticity_vs_sklearn_oracle(C, n, D, kind):
     got = scores.polysemanticity_score(torch.from_numpy(V).to(DEV)).cpu().numpy()
     assert_polysemanticity_matches(got, V, kind)
     assert np.all(got >= -1e-6) and np.all(got <= 2 + 1e-6)
+
+
+@pytest.mark.parametrize("C,n,D,k,kind", [(96, 20, 64, 3, "random"), (96, 20, 64, 4, "blobs"), (64, 12, 16, 5, "random"),
+                                          (64, 30, 8, 3, "blobs"), (48, 8, 4, 6, "dup"), (24, 150, 32, 2, "blobs"),
+                                          (16, 200, 24, 3, "random"), (64, 20, 512, 16, "random")])
+def test_polysemanticity_any_n_clusters_vs_sklearn(C, n, D, k, kind):
+    """scores.py:132,167: `n_clusters` is forwarded to scikit-learn.  The general kernel (any k up to 16, n up to 1024,
+    relocation of several empty clusters, k-means++ with 2 + int(ln k) trials) must pick scikit-learn's clustering for
+    every component; "dup" duplicates points so that empty clusters and the fallback rows occur."""
+    rng = np.random.RandomState(C + n + D + k)
+    V = rng.randn(C, n, D).astype(np.float32)
+    if kind == "blobs":
+        cen = rng.randn(C, k, D).astype(np.float32) * 2
+        V = cen[np.arange(C)[:, None], rng.randint(0, k, size=(C, n))] + 0.4 * V
+    if kind == "dup":
+        V[:, n // 2:] = V[:, : n - n // 2]
+        V[:, :3] = V[:, :1]
+    got = scores.polysemanticity_score(torch.from_numpy(V).to(DEV), n_clusters=k).cpu().numpy()
+    assert_polysemanticity_matches(got, V, f"{kind} k={k}", n_clusters=k)
+    with pytest.raises(ValueError):  # sklearn: n_samples should be >= n_clusters
+        scores.polysemanticity_score(torch.from_numpy(V[:, :2]).to(DEV), n_clusters=3)
 
 
 def test_probe_dict_uses_one_native_call_and_matches_per_layer():

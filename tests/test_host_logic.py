@@ -292,19 +292,24 @@ def test_kmeans_draws_match_sklearn_seeding():
     from semanticlens_amd.scores import kmeans_draws
 
     n, n_init, seed = 20, 10, 123
-    first, rand = kmeans_draws(n, n_init, seed)
-    X = np.random.RandomState(0).randn(n, 8).astype(np.float32)
-    rs = np.random.RandomState(seed)
-    sw = np.ones(n, dtype=np.float32)
+    X = np.random.RandomState(0).randn(n, 8)  # float64, what the reference's torch-tensor input becomes inside sklearn
     norms = (X * X).sum(1)
-    for i in range(n_init):
-        state_before = rs.get_state()
-        centers, idx = _kmeans._kmeans_plusplus(X, 2, norms, sw, rs)
-        assert idx[0] == first[i]
-        replay = np.random.RandomState()
-        replay.set_state(state_before)
-        replay.choice(n, p=sw / sw.sum())
-        assert np.array_equal(replay.uniform(size=2), rand[i])
+    sw = np.ones(n, dtype=np.float64)
+    for k in (2, 3, 8):
+        trials = 2 + int(np.log(k))
+        first, rand = kmeans_draws(n, n_init, seed, k)
+        assert rand.shape == (n_init, k - 1, trials)
+        rs = np.random.RandomState(seed)
+        for i in range(n_init):
+            state_before = rs.get_state()
+            centers, idx = _kmeans._kmeans_plusplus(X, k, norms, sw, rs)
+            assert idx[0] == first[i]
+            replay = np.random.RandomState()
+            replay.set_state(state_before)
+            replay.choice(n, p=sw / sw.sum())
+            for c in range(k - 1):
+                assert np.array_equal(replay.uniform(size=trials), rand[i, c])
+            assert replay.get_state()[1].tolist() == rs.get_state()[1].tolist() and replay.get_state()[2] == rs.get_state()[2]
 
 
 # ------------------------------------------------------------------------------------ distributed
