@@ -185,6 +185,13 @@ __global__ __launch_bounds__(256) void actmax_merge_states_kernel(uint16_t* __re
 }
 
 size_t row_smem_bytes(int64_t k) { return (size_t)kWavesPerBlock * (size_t)k * (sizeof(int64_t) + sizeof(uint32_t)); }
+// k in (1365, 2048] needs 64-96 KiB of dynamic LDS: above the default limit the attribute must be raised first
+template <class K>
+int allow_smem(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024)
+    SL_CHECK_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return 0;
+}
 
 int check_state(const char* fn, const void* vals, const void* ids, int64_t C, int64_t k) {
   SL_REQUIRE(C >= 0 && k >= 0, "%s: negative shape", fn);
@@ -229,6 +236,7 @@ SL_API int sl_actmax_merge(uint16_t* d_vals, int64_t* d_ids, int64_t C, int64_t 
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof(SL_PROF_MERGE, st, bytes + (double)C * k * 10);
   const unsigned blocks = (unsigned)((C + kWavesPerBlock - 1) / kWavesPerBlock);
+  if (int rc = allow_smem(actmax_merge_kernel, row_smem_bytes(k))) return rc;
   SL_LAUNCH(prof, actmax_merge_kernel, dim3(blocks), dim3(256), row_smem_bytes(k), st, d_vals, d_ids, C, (int)k, d_cand, sa,
             (const int64_t*)nullptr);
   SL_CHECK_HIP(hipGetLastError());
@@ -259,6 +267,7 @@ SL_API int sl_actmax_update(uint16_t* d_vals, int64_t* d_ids, int64_t C, int64_t
   sa.id_base[0] = id_base;
   sa.rows[0] = B;
   const unsigned blocks = (unsigned)((C + kWavesPerBlock - 1) / kWavesPerBlock);
+  if (int rc = allow_smem(actmax_merge_kernel, row_smem_bytes(k))) return rc;
   SL_LAUNCH(prof, actmax_merge_kernel, dim3(blocks), dim3(256), row_smem_bytes(k), st, d_vals, d_ids, C, (int)k, d_cand, sa,
             d_sample_ids);
   SL_CHECK_HIP(hipGetLastError());
@@ -274,6 +283,7 @@ SL_API int sl_actmax_merge_states(uint16_t* d_vals, int64_t* d_ids, int64_t C, i
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof(SL_PROF_MERGE, st, (double)(R + 1) * C * k * 10);
   const unsigned blocks = (unsigned)((C + kWavesPerBlock - 1) / kWavesPerBlock);
+  if (int rc = allow_smem(actmax_merge_states_kernel, row_smem_bytes(k))) return rc;
   SL_LAUNCH(prof, actmax_merge_states_kernel, dim3(blocks), dim3(256), row_smem_bytes(k), st, d_vals, d_ids, C, (int)k,
             d_other_vals, d_other_ids, R);
   SL_CHECK_HIP(hipGetLastError());

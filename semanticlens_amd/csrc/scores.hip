@@ -61,14 +61,18 @@ __global__ __launch_bounds__(256) void rowmax_offdiag_kernel(const float* __rest
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nw = (int64_t)gridDim.x * 4;
   for (int64_t r = wave; r < C; r += nw) {
+    // torch's .max propagates NaN (scores.py:79), fmaxf drops it: remember it separately
     float m = -__builtin_huge_valf();
+    bool nan = false;
     for (int64_t j = lane; j < C; j += 64) {
       float v = sims[r * C + j];
       if (j == r) v -= 2.f;
+      nan |= (v != v);
       m = fmaxf(m, v);
     }
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if (lane == 0) rowmax[r] = m;
+    const bool any_nan = __any(nan);
+    if (lane == 0) rowmax[r] = any_nan ? __builtin_nanf("") : m;
   }
 }
 

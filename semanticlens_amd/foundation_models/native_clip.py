@@ -194,6 +194,8 @@ class NativeTextTower:
     def __call__(self, tokens: torch.Tensor) -> torch.Tensor:
         tokens = N.to_device(tokens).to(torch.int64).contiguous()
         B, T = tokens.shape
+        if T > self.pos.shape[0]:
+            raise ValueError(f"{T} tokens exceed the text tower's context length {self.pos.shape[0]}")
         eot = tokens.argmax(dim=-1)  # end-of-text token (highest id): the position CLIP's text tower pools
         if self.truncate and B > 0:
             # the tower is causal: position t only sees positions <= t, so nothing after the last end-of-text token of
@@ -210,6 +212,29 @@ class NativeTextTower:
             picked = N.gather_rows(self.tower.forward(x, B, T, causal=True), rows, check=False)
         pooled = N.layernorm(picked, *self.ln_final)
         return N.linear(pooled, self.w_proj)
+
+
+def _require_clip_layout(model):
+    """open_clip builds many variants behind the same attribute names.  The native towers implement exactly one: class-token
+    pooling of the image tower, a causal text tower pooled at the end-of-text (argmax) token, no LayerScale, no attention
+    pooling.  Anything else is refused here instead of silently producing different features."""
+    v = model.visual
+    problems = []
+    if getattr(v, "attn_pool", None) is not None:
+        problems.append("visual.attn_pool is set (attention pooling)")
+    if getattr(v, "pool_type", "tok") not in ("tok",):
+        problems.append(f"visual.pool_type={getattr(v, 'pool_type', None)!r} (only 'tok')")
+    if getattr(model, "text_pool_type", "argmax") not in ("argmax",):
+        problems.append(f"text_pool_type={getattr(model, 'text_pool_type', None)!r} (only 'argmax')")
+    for tower in (getattr(v, "transformer", None), getattr(model, "transformer", None)):
+        for blk in getattr(tower, "resblocks", []):
+            for ls in ("ls_1", "ls_2"):
+                if hasattr(blk, ls) and not isinstance(getattr(blk, ls), nn.Identity):
+                    problems.append(f"{ls} is not Identity (LayerScale)")
+    if getattr(model, "attn_mask", None) is None and hasattr(model, "attn_mask"):
+        problems.append("the text tower has no causal attn_mask")
+    if problems:
+        raise TypeError("NativeClip does not implement this open_clip variant: " + "; ".join(sorted(set(problems))))
 
 
 class NativeClip(AbstractVLM):
@@ -232,6 +257,7 @@ class NativeClip(AbstractVLM):
         if hasattr(model, "visual") and hasattr(model.visual, "conv1"):  # open_clip: CLIP.visual is the whole image tower
             visual, vblocks = model.visual, _first(model.visual, "transformer.resblocks")
             tblocks = _first(model, "transformer.resblocks")
+            _require_clip_layout(model)
         else:  # synth._ClipModel: embedding members on the model, block stacks in .visual / .text
             visual, vblocks = _SynthVisual(model), model.visual.blocks
             tblocks = model.text.blocks

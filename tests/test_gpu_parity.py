@@ -454,6 +454,14 @@ def test_text_probes_golden(golden):
                 assert np.array_equal(emb.cpu().numpy(), g[f"q{nq}_t{nt}_bs{bs}"]), (nq, nt, bs)
 
 
+def test_redundancy_propagates_nan_like_torch_max():
+    """scores.py:76-81: `.max(-1)` of the cosine matrix propagates NaN; a NaN embedding poisons the mean."""
+    x = torch.randn(40, 32)
+    assert torch.isfinite(scores.redundancy_score(x.to(DEV))).item()
+    x[7, 3] = float("nan")
+    assert torch.isnan(scores.redundancy_score(x.to(DEV))).item()
+
+
 def test_image_probing_golden(golden):
     """lens.py:124-162 — a single image is used as is, several images are averaged; tensor and dict DBs."""
     from helpers import FakeVLM

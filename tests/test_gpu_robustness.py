@@ -68,6 +68,18 @@ def test_large_k_and_limits():
         assert np.array_equal(bits(am.activations), ref.vals) and np.array_equal(am.sample_ids.numpy(), ref.ids)
     with pytest.raises(ValueError, match="exceeds the supported maximum"):
         ActMax(5000, 4, tie_mode="total").update(torch.randn(8, 4), torch.arange(8))
+    # the k boundary: k = 2048 needs 96 KiB of dynamic LDS per workgroup (above the 64 KiB default limit)
+    big = rng.randn(2100, 3).astype(np.float32)
+    am = ActMax(2048, 3, tie_mode="total")
+    ref = oracle.ActMaxOracle(2048, 3, oracle.MODE_TOTAL)
+    for s in range(0, 2100, 700):
+        am.update(torch.from_numpy(big[s:s + 700]), torch.arange(s, s + 700))
+        ref.update(big[s:s + 700], np.arange(s, s + 700))
+    assert np.array_equal(bits(am.activations), ref.vals) and np.array_equal(am.sample_ids.numpy(), ref.ids)
+    other = ActMax(2048, 3, tie_mode="total")
+    other.update(torch.from_numpy(big[:100] + 1), torch.arange(5000, 5100))
+    am.merge_states(other.device_state()[0][None], other.device_state()[1][None])  # K4 at the boundary
+    assert am.activations.shape == (3, 2048)
 
 
 def test_half_precision_activations_through_hooks():
