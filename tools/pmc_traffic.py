@@ -25,7 +25,9 @@ def main(fetch_csv, write_csv, out_json):
     write = load(write_csv, "WRITE_SIZE")
     # bench shapes (tools/pmc_target.py): ResNet-50 layer2/3/4 at B=256 fp32, in kernel-template order
     # (the template list continues with the cache-policy argument, hence prefix matches)
-    algo = {"<64, 4, 0, true,": 256 * 512 * 784 * 4, "<64, 8, 0, true,": 256 * 1024 * 196 * 4, "<16, 8, 0, false,": 256 * 2048 * 49 * 4}
+    # round 2: the LDS-DMA kernels rowreduce_dma_kernel<G, U, OP, ALIGNED>: layer2 <64, 1, ..>, layer3 <16, 1, ..>, layer4 <16, 4, .., false>
+    algo = {"rowreduce_dma_kernel<64, 1, 0, true>": 256 * 512 * 784 * 4, "rowreduce_dma_kernel<16, 1, 0, true>": 256 * 1024 * 196 * 4,
+            "rowreduce_dma_kernel<16, 4, 0, false>": 256 * 2048 * 49 * 4}
     kernels = {}
     tot_traffic = tot_algo = 0.0
     for name, kib in fetch.items():
@@ -34,7 +36,7 @@ def main(fetch_csv, write_csv, out_json):
         entry = {"fetch_size_kib": kib, "write_size_kib": write.get(name), "hbm_read_bytes": rd, "hbm_write_bytes": wr,
                  "hbm_bytes_per_launch": rd + wr}
         for key, a in algo.items():
-            if "rowreduce_fast_kernel" + key in name:
+            if key in name:
                 entry["algorithmic_bytes_per_launch"] = a
                 entry["traffic_over_algorithmic"] = (rd + wr) / a
                 tot_traffic += rd + wr
