@@ -516,6 +516,16 @@ __global__ __launch_bounds__(256) void rowreduce_fast_kernel(const float* __rest
 #ifndef SL_REDUCE_LAB
 #define SL_REDUCE_LAB 0  // tools/native/reduce_lab.hip: 1 = no per-row reduce / store, 2 = no NaN-detector sum (garbage results)
 #endif
+// lab only: cache-policy bits of the head / tail loads; TAIL_FIRST 0 = walk the tensor front to back
+#ifndef SL_REDUCE_LAB_HEAD_AUX
+#define SL_REDUCE_LAB_HEAD_AUX 2
+#endif
+#ifndef SL_REDUCE_LAB_TAIL_AUX
+#define SL_REDUCE_LAB_TAIL_AUX 0
+#endif
+#ifndef SL_REDUCE_LAB_TAIL_FIRST
+#define SL_REDUCE_LAB_TAIL_FIRST 1
+#endif
 constexpr int kDmaMaxBatch = 4096;  // bytes: four 1-KiB LDS-DMA instructions
 constexpr int kDmaDepth = 2;        // slots per wave: one batch in flight while one is reduced
 constexpr int kDmaLdsPerCu = 160 * 1024;
@@ -533,7 +543,6 @@ __global__ __launch_bounds__(256) void rowreduce_dma_kernel(const float* __restr
   const int li = lane & (G - 1);
   const int g = lane / G;
   const int64_t ntask = R / RPT;  // launcher guarantees R % RPT == 0
-  const int64_t nbatch = (ntask + U - 1) / U;
   const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -542,8 +551,6 @@ __global__ __launch_bounds__(256) void rowreduce_dma_kernel(const float* __restr
   const int h = ALIGNED ? 0 : ((g * S) & 3);
   const uint32_t row_byte0 = (uint32_t)(((g * S) >> 2) * 16);
   const uint32_t task_bytes = (uint32_t)(RPT * S) * 4u;  // multiple of 16
-  const uint32_t batch_bytes = (uint32_t)U * task_bytes;  // <= slot_bytes <= kDmaMaxBatch
-  const int64_t total_bytes = R * (int64_t)S * 4;
   const int pos0 = li * 4 - h;
   const bool k0 = (unsigned)(pos0 + 0) < (unsigned)S, k1 = (unsigned)(pos0 + 1) < (unsigned)S;
   const bool k2 = (unsigned)(pos0 + 2) < (unsigned)S, k3 = (unsigned)(pos0 + 3) < (unsigned)S;
@@ -557,15 +564,14 @@ __global__ __launch_bounds__(256) void rowreduce_dma_kernel(const float* __restr
   // constants and the loop has no data-dependent branches: lanes past the batch's bytes are masked; an instruction that
   // would be empty (short batches; the tensor's last batch) keeps lane 0 alive on the batch's first 16 bytes.
   constexpr int NI = kDmaMaxBatch / 1024;
-  auto issue = [&](int64_t tb, int slot) __attribute__((always_inline)) {
-    const int64_t off = tb * (int64_t)batch_bytes;
-    const int64_t left = total_bytes - off;
-    const uint32_t nb = left < (int64_t)batch_bytes ? (uint32_t)left : batch_bytes;
-    const unsigned char* src = xb + off;
+  const int tail32 = tail_from > (int64_t)0x7fffffff ? 0x7fffffff : (int)tail_from;  // first task of the default-policy tail
+  auto issue = [&](int task0, int nu, int slot) __attribute__((always_inline)) {
+    const uint32_t nb = (uint32_t)nu * task_bytes;
+    const unsigned char* src = xb + task0 * (int64_t)task_bytes;
     unsigned char* d = ring + slot * slot_bytes;
     // cache policy, wave-uniform per batch: streaming (nt) for bytes that come from HBM, default for the part of a
     // just-written input that the Infinity Cache still holds (see launch_rowreduce_dma)
-    const bool stream = tb < tail_from;
+    const bool stream = task0 < tail32;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const uint32_t byte = (uint32_t)i * 1024u + (uint32_t)lane * 16u;
@@ -574,8 +580,8 @@ __global__ __launch_bounds__(256) void rowreduce_dma_kernel(const float* __restr
       // workgroup's spare KiB, not in a slot
       unsigned char* dst_i = (uint32_t)i * 1024u < nb ? d + i * 1024 : spare;
       if (in || lane == 0) {
-        if (stream) __builtin_amdgcn_global_load_lds((glb_void*)(src + (in ? byte : 0u)), (lds_void*)dst_i, 16, 0, 2 /* nt */);
-        else __builtin_amdgcn_global_load_lds((glb_void*)(src + (in ? byte : 0u)), (lds_void*)dst_i, 16, 0, 0);
+        if (stream) __builtin_amdgcn_global_load_lds((glb_void*)(src + (in ? byte : 0u)), (lds_void*)dst_i, 16, 0, SL_REDUCE_LAB_HEAD_AUX /* 2 = nt */);
+        else __builtin_amdgcn_global_load_lds((glb_void*)(src + (in ? byte : 0u)), (lds_void*)dst_i, 16, 0, SL_REDUCE_LAB_TAIL_AUX);
       }
     }
   };
@@ -588,22 +594,54 @@ __global__ __launch_bounds__(256) void rowreduce_dma_kernel(const float* __restr
     }
   };
 
-  const int64_t nmine = nbatch > wave0 ? (nbatch - wave0 + nwaves - 1) / nwaves : 0;
-  for (int d = 0; d < kDmaDepth - 1; ++d)
-    if (d < nmine) issue(wave0 + d * nwaves, d);
-  for (int64_t it = 0; it < nmine; ++it) {
-    const int64_t tb = wave0 + it * nwaves;
-    const int slot = (int)(it % kDmaDepth);
-    if (it + (kDmaDepth - 1) < nmine) {
-      issue(tb + (kDmaDepth - 1) * nwaves, (int)((it + kDmaDepth - 1) % kDmaDepth));
-      wait_batches(kDmaDepth - 1);  // a constant: one s_waitcnt
+  // Work split.  `full` rounds in which every wave owns a whole batch of U tasks, batches interleaved over the waves
+  // (neighbouring waves read neighbouring bytes); the remaining `rem` tasks (< one round) are split EVENLY over the waves
+  // as one short batch each instead of leaving most waves idle for a round (the layer4 shape has 5.33 batches per wave:
+  // a 6th round for a third of the waves cost 10 %).  The short round covers the tensor's first tasks and is walked last.
+  // Walk order of the full rounds: when a tail policy is active (tail_from inside the tensor) the tail goes FIRST —
+  // the most recently written bytes are read while the Infinity Cache still holds them, before the head's traffic can
+  // displace them (in-pipeline 411 MB: 6.07 -> 6.44 TB/s).
+  // 32-bit task / batch indices (the launcher keeps ntask < 2^31): 64-bit scalar compares compile to VALU compares
+  // whose result the scalar branch then waits for.
+  const int ntask32 = (int)ntask, nwaves32 = (int)nwaves, w0 = (int)wave0;
+  const int round_tasks = nwaves32 * U;
+  const int full = ntask32 / round_tasks;
+  const int rem = ntask32 - full * round_tasks;
+  const int u_last = (rem + nwaves32 - 1) / nwaves32;  // <= U
+  const int nfull = full * nwaves32;                   // whole batches
+  int rot = 0;
+  if (SL_REDUCE_LAB_TAIL_FIRST && tail32 > rem && tail32 < ntask32) rot = (tail32 - rem) / U;
+  const int nmine = full + ((int64_t)w0 * u_last < rem ? 1 : 0);
+  auto work_of = [&](int it, int& t0, int& n) __attribute__((always_inline)) {
+    if (it < full) {
+      int v = w0 + it * nwaves32 + rot;
+      if (v >= nfull) v -= nfull;
+      t0 = rem + v * U;
+      n = U;
     } else {
-      wait_batches(0);  // the last batches of this wave: drain
+      t0 = w0 * u_last;
+      n = rem - t0 < u_last ? rem - t0 : u_last;
+    }
+  };
+  int task0 = 0, task_next = 0;
+  int nu = 0, nu_next = 0;
+  if (nmine > 0) {
+    work_of(0, task_next, nu_next);
+    issue(task_next, nu_next, 0);
+  }
+  static_assert(kDmaDepth == 2, "the loop below keeps exactly one batch in flight beside the one being reduced");
+  for (int it = 0; it < nmine; ++it) {
+    const int slot = it & 1;
+    task0 = task_next;
+    nu = nu_next;
+    if (it + 1 < nmine) {
+      work_of(it + 1, task_next, nu_next);
+      issue(task_next, nu_next, slot ^ 1);
+      wait_batches(1);  // a constant: one s_waitcnt
+    } else {
+      wait_batches(0);  // the wave's last batch: drain
     }
     const unsigned char* sl_ = ring + slot * slot_bytes;
-    const int64_t task0 = tb * U;
-    int nu = U;
-    if (task0 + U > ntask) nu = (int)(ntask - task0);
     float m[U], sum[U];
     f32x2 sum2[U];  // two partial sums per task, added with one v_pk_add_f32 per half piece
 #pragma unroll
@@ -668,7 +706,7 @@ __global__ __launch_bounds__(256) void rowreduce_dma_kernel(const float* __restr
           const float sred = group_allreduce_f<G, true>(sum[u]);
           bool nan = false;
           if (row_ok && sred != sred) {
-            const float* rowp = x + ((task0 + u) * RPT + g) * (int64_t)S;
+            const float* rowp = x + ((int64_t)(task0 + u) * RPT + g) * (int64_t)S;
             for (int i = li; i < S; i += G) nan |= (rowp[i] != rowp[i]);
           }
           const float f = group_allreduce_f<G, false>(nan ? 1.f : 0.f);
@@ -682,7 +720,7 @@ __global__ __launch_bounds__(256) void rowreduce_dma_kernel(const float* __restr
 #pragma unroll
       for (int u = p + 1; u < U && u < p + G; ++u) sel = (li == u - p) ? r[u] : sel;
       const int uu = p + li;
-      if (li < G && uu < nu) store_outputs(sel, (task0 + uu) * RPT + g, cand, outf);
+      if (li < G && uu < nu) store_outputs(sel, (int64_t)(task0 + uu) * RPT + g, cand, outf);
     }
   }
 }
@@ -842,8 +880,8 @@ void launch_rowreduce_dma(ProfScope& prof, const float* x, int64_t R, int S, flo
   if (blocks < 1) blocks = 1;
   const int64_t nt_min_bytes = nt_min_bytes_(), tail_bytes = tail_bytes_();  // cache policy: see the top of this file
   const int64_t bytes = R * (int64_t)S * 4;
-  int64_t tail_from = 0;  // batches from here on use the default policy
-  if (bytes >= nt_min_bytes) tail_from = tail_bytes > 0 ? (bytes > tail_bytes ? (bytes - tail_bytes) / slot : 0) : INT64_MAX;
+  int64_t tail_from = 0;  // tasks from here on use the default policy
+  if (bytes >= nt_min_bytes) tail_from = tail_bytes > 0 ? (bytes > tail_bytes ? (bytes - tail_bytes) / ((int64_t)RPT * S * 4) : 0) : INT64_MAX;
   SL_LAUNCH(prof, (rowreduce_dma_kernel<G, U, OP, ALIGNED>), dim3((unsigned)blocks), dim3(256), (size_t)lds, st, x, R, S, denom,
             slot, tail_from, cand, outf);
 }
@@ -857,7 +895,7 @@ bool try_rowreduce_dma(ProfScope& prof, const float* x, int64_t R, int S, float 
   }();
   constexpr int RPT = kWave / G;
   const int64_t task_bytes = (int64_t)RPT * S * 4;
-  if (!enabled || task_bytes > kDmaMaxBatch || R * (int64_t)S * 4 < (8ll << 20)) return false;  // small inputs: launch-bound either way
+  if (!enabled || task_bytes > kDmaMaxBatch || R * (int64_t)S * 4 < (8ll << 20) || R > 0x7fffffffll) return false;  // small inputs: launch-bound either way; the kernel indexes tasks with 32 bits
   const int u = (int)(kDmaMaxBatch / task_bytes);
   if (u >= 4) launch_rowreduce_dma<G, 4, OP, ALIGNED>(prof, x, R, S, denom, cand, outf, st);
   else if (u == 3) launch_rowreduce_dma<G, 3, OP, ALIGNED>(prof, x, R, S, denom, cand, outf, st);
