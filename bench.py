@@ -264,7 +264,7 @@ def api_path_leg(dev, model, fm_base, args):
     assert all(v.shape == (c, args.k, 512) for v, c in zip(db.values(), (512, 1024, 2048)))
     return {"api_path_images_per_s": n / dt, "images": n, "seconds": dt,
             "workload": f"Lens.compute_concept_db(cv, batch_size={B}, single_pass=True): host Datasets ({n} normalised "
-                        f"224x224 fp32 samples + raw {w}x{h} uint8 images), DataLoader num_workers=0, 16 host threads, device preprocessing "
+                        f"224x224 fp32 samples + raw {w}x{h} uint8 images), DataLoader num_workers=0 walked by the background prefetch threads (pinned staging, uploads ahead of the device), 16 host threads, device preprocessing "
                         "(K12), tie_mode='aten', concept_db returned on the host"}
 
 

@@ -25,6 +25,7 @@ from tqdm import tqdm
 
 from semanticlens_amd import _native as N
 from semanticlens_amd.component_visualization import aggregators
+from semanticlens_amd.component_visualization._prefetch import PinnedStack, Prefetcher, upload_stage
 from semanticlens_amd.component_visualization.activation_caching import ActMaxCache
 from semanticlens_amd.component_visualization.base import AbstractComponentVisualizer
 from semanticlens_amd.utils.helper import get_fallback_name
@@ -47,6 +48,9 @@ class ActivationComponentVisualizer(AbstractComponentVisualizer):
         "mean": aggregators.aggregate_conv_mean,
         "max": aggregators.aggregate_conv_max,
     }
+    #: walk the DataLoaders from a background thread, batches staged in pinned memory and uploaded (or preprocessed)
+    #: ahead of the device (``_prefetch.py``); False = the reference's synchronous loops
+    prefetch = True
 
     def __init__(
         self,
@@ -162,15 +166,46 @@ class ActivationComponentVisualizer(AbstractComponentVisualizer):
             dataset = torch.utils.data.Subset(self.dataset, range(start, stop))
             for name in self.layer_names:
                 self.actmax_cache.sample_idx_counter[name] = start
-        dataloader = torch.utils.data.DataLoader(dataset, batch_size=batch_size, shuffle=False, num_workers=num_workers)
+        dataloader = self._model_loader(dataset, batch_size, num_workers)
         with self.actmax_cache.hook_context(self.model):
-            for images, _ in tqdm(dataloader, total=len(dataloader), desc="Collecting ActMax"):
+            for images in tqdm(dataloader, total=len(dataloader), desc="Collecting ActMax"):
                 self.collect_batch(images)
 
         if self._cache_root and sample_range is None:
             self.actmax_cache.store(self.storage_dir)
             logger.debug(f"Stored activation maximization cache at {self.storage_dir}")
         return self.actmax_cache.cache
+
+    def _model_loader(self, dataset, batch_size, num_workers):
+        """Iterable of image batches of ``dataset`` (labels dropped, as the reference's ``for images, _ in ...``)."""
+        dev = torch.device(self.device)
+        if not (self.prefetch and dev.type == "cuda"):
+            loader = torch.utils.data.DataLoader(dataset, batch_size=batch_size, shuffle=False, num_workers=num_workers)
+            return _FirstOfBatch(loader)
+        if num_workers == 0:
+            stack = PinnedStack()
+            loader = torch.utils.data.DataLoader(dataset, batch_size=batch_size, shuffle=False, collate_fn=stack)
+            return Prefetcher(loader, upload_stage(dev, stack), dev)
+        loader = torch.utils.data.DataLoader(dataset, batch_size=batch_size, shuffle=False, num_workers=num_workers,
+                                             pin_memory=True)
+        return Prefetcher(loader, upload_stage(dev), dev)
+
+    def _fm_loader(self, fm, data, batch_size, collate, **kwargs):
+        """Iterable of ``(items, preprocessed or None)`` of ``dataset_fm``: with prefetching ``fm.preprocess`` runs in
+        the background thread (device preprocessing: pack + upload + K12 on the thread's stream; a host transform:
+        the PIL work of the next batch beside the encoder of this one)."""
+        loader = torch.utils.data.DataLoader(data, batch_size=batch_size, shuffle=False, collate_fn=collate, **kwargs)
+        dev = torch.device(self.device)
+        if not (self.prefetch and dev.type == "cuda"):
+            return _WithNone(loader)
+
+        def stage(items):
+            pre = fm.preprocess(items)
+            if isinstance(pre, torch.Tensor) and not pre.is_cuda:
+                pre = pre.to(dev, non_blocking=True)
+            return items, pre
+
+        return Prefetcher(loader, stage, dev)
 
     def collect_batch(self, images: torch.Tensor):
         """One step of hot loop 1: forward ``images`` (host or device resident) under the active hooks.
@@ -219,19 +254,22 @@ class ActivationComponentVisualizer(AbstractComponentVisualizer):
         def first(batch):
             return [item[0] if isinstance(item, (tuple, list)) else item for item in batch]
 
-        loader_m = torch.utils.data.DataLoader(self.dataset, batch_size=batch_size, shuffle=False, num_workers=num_workers)
-        loader_f = torch.utils.data.DataLoader(self.dataset_fm, batch_size=batch_size, shuffle=False, collate_fn=first,
-                                               num_workers=num_workers)
+        loader_m = self._model_loader(self.dataset, batch_size, num_workers)
+        loader_f = self._fm_loader(fm, self.dataset_fm, batch_size, first, num_workers=num_workers)
         n_total = len(self.dataset_fm)
         main = torch.cuda.current_stream(self.device)
         side = torch.cuda.Stream(self.device)
         embeds, filled = None, 0
         with self.actmax_cache.hook_context(self.model):
-            for (images, _), items in tqdm(zip(loader_m, loader_f), total=len(loader_m), desc="Collecting + embedding"):
+            it_f = iter(loader_f)
+            for images in tqdm(loader_m, total=len(loader_m), desc="Collecting + embedding"):
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    embeds, filled = self.embed_batch(fm, items, embeds, filled, n_total)
+                    items, pre = next(it_f)
+                    embeds, filled = self.embed_batch(fm, items, embeds, filled, n_total, preprocessed=pre)
                 self.collect_batch(images)
+            for _ in it_f:  # both datasets have the same length (checked by the constructor)
+                raise RuntimeError("dataset_fm yielded more batches than dataset")
         main.wait_stream(side)
         if embeds is None:
             raise RuntimeError("dataset_fm is empty: nothing to embed")
@@ -271,13 +309,13 @@ class ActivationComponentVisualizer(AbstractComponentVisualizer):
             return list(batch)
 
         data = self.dataset_fm if subset is None else torch.utils.data.Subset(self.dataset_fm, subset)
-        loader = torch.utils.data.DataLoader(data, batch_size=batch_size, shuffle=False, collate_fn=pil_list_collate, **kwargs)
+        loader = self._fm_loader(fm, data, batch_size, pil_list_collate, **kwargs)
         n_total = len(data)
         embeds = None
         filled = 0
         with tqdm(total=n_total, desc="Embedding Dataset") as pbar:
-            for pil_list in loader:
-                embeds, filled = self.embed_batch(fm, pil_list, embeds, filled, n_total)
+            for items, pre in loader:
+                embeds, filled = self.embed_batch(fm, items, embeds, filled, n_total, preprocessed=pre)
                 pbar.update(batch_size)
         if embeds is None:
             raise RuntimeError("dataset_fm is empty: nothing to embed")
@@ -285,10 +323,11 @@ class ActivationComponentVisualizer(AbstractComponentVisualizer):
         return embeds
 
     @staticmethod
-    def embed_batch(fm, items, embeds, filled: int, n_total: int):
+    def embed_batch(fm, items, embeds, filled: int, n_total: int, preprocessed=None):
         """One step of hot loop 2: ``fm.encode_image(fm.preprocess(items))`` written into rows
-        ``[filled, filled + B)`` of the device-resident ``(n_total, D)`` table (allocated on first use)."""
-        out = fm.encode_image(fm.preprocess(items))
+        ``[filled, filled + B)`` of the device-resident ``(n_total, D)`` table (allocated on first use).
+        ``preprocessed`` = the result of ``fm.preprocess(items)`` when the loader already produced it."""
+        out = fm.encode_image(fm.preprocess(items) if preprocessed is None else preprocessed)
         out = N.to_device(out.detach()).to(torch.float32)
         if embeds is None:
             embeds = torch.empty((n_total, out.shape[1]), dtype=torch.float32, device=out.device)
@@ -350,6 +389,34 @@ class ActivationComponentVisualizer(AbstractComponentVisualizer):
     def _check_layer_name(self, layer_name):
         if layer_name not in self.layer_names:
             raise ValueError(f"Layer '{layer_name}' not found in model layers: {self.layer_names}")
+
+
+class _FirstOfBatch:
+    """``(images, labels)`` batches -> ``images``."""
+
+    def __init__(self, loader):
+        self.loader = loader
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for batch in self.loader:
+            yield batch[0] if isinstance(batch, (tuple, list)) else batch
+
+
+class _WithNone:
+    """``items`` -> ``(items, None)``: the synchronous form of ``_fm_loader``."""
+
+    def __init__(self, loader):
+        self.loader = loader
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for items in self.loader:
+            yield items, None
 
 
 def _image_grid(images: list[torch.Tensor], per_row: int, padding: int = 2) -> torch.Tensor:

@@ -154,3 +154,53 @@ def test_single_pass_two_stream_build_equals_two_pass(tmp_path):
     again = cv2._compute_concept_db(FakeVLM().to(DEV), batch_size=8, single_pass=True)
     h.remove()
     assert not model_calls and all(torch.equal(again[n], want[n]) for n in ("0", "2"))
+
+
+# ---- host prefetch (component_visualization/_prefetch.py) -----------------------------------------------------------
+def test_prefetcher_order_exceptions_and_early_stop():
+    from semanticlens_amd.component_visualization._prefetch import PinnedStack, Prefetcher, upload_stage
+
+    data = [(torch.full((3, 4, 4), float(i)), i) for i in range(37)]
+    stack = PinnedStack(slots=3)
+    loader = torch.utils.data.DataLoader(data, batch_size=5, shuffle=False, collate_fn=stack)
+    got = [b for b in Prefetcher(loader, upload_stage(DEV, stack), DEV, depth=2)]
+    assert len(got) == 8 and all(b.is_cuda for b in got)
+    assert torch.equal(torch.cat(got)[:, 0, 0, 0].cpu(), torch.arange(37, dtype=torch.float32))
+
+    def boom(item):
+        if int(item[0, 0, 0, 0]) >= 10:
+            raise ValueError("bad sample")
+        return item.to(DEV)
+
+    seen = []
+    with pytest.raises(ValueError, match="bad sample"):
+        for b in Prefetcher(torch.utils.data.DataLoader(data, batch_size=5, collate_fn=PinnedStack()), boom, DEV):
+            seen.append(b)
+    assert len(seen) == 2  # the exception surfaces at its position in the stream
+
+    pf = Prefetcher(torch.utils.data.DataLoader(data, batch_size=2, collate_fn=PinnedStack()), lambda t: t.to(DEV), DEV)
+    for i, b in enumerate(pf):
+        if i == 3:
+            break
+    pf.close()
+    assert not pf._thread.is_alive()
+
+
+def test_prefetch_on_and_off_build_the_same_concept_db(tmp_path):
+    """The background walk changes when host work happens, nothing else: same top-k states, same concept DB, in the
+    two-pass and the single-pass form."""
+    x = make_int_images(70, seed=21)
+    ds = TensorPairDataset(x, name="pf")
+    outs = []
+    for prefetch in (True, False):
+        for single in (True, False):
+            cv = ActivationComponentVisualizer(make_int_conv_model().to(DEV), ds, ds, ["0", "2"], num_samples=6,
+                                               aggregate_fn=aggregators.aggregate_conv_max, cache_dir=None)
+            cv.prefetch = prefetch
+            fm = FakeVLM().to(DEV)
+            db = Lens(fm, device=DEV).compute_concept_db(cv, batch_size=16, single_pass=single)
+            outs.append((db, {n: cv.get_max_reference(n).clone() for n in cv.layer_names}))
+    for db, ids in outs[1:]:
+        for name in ids:
+            assert torch.equal(ids[name], outs[0][1][name])
+            assert torch.equal(db[name], outs[0][0][name])
