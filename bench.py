@@ -66,6 +66,7 @@ def parse():
                          "batch distinct.  For dataset sizes whose uint8 pixels exceed HBM (1.28 M images = 193 GB)")
     ap.add_argument("--no-self-check", action="store_true")
     ap.add_argument("--no-api-leg", action="store_true")
+    ap.add_argument("--no-channels-last", action="store_true")
     ap.add_argument("--api-images", type=int, default=2048, help="raw 500x375 images of the API-path leg")
     return ap.parse_args()
 
@@ -482,8 +483,8 @@ def main():
 
     assert n_local > 0, "every rank needs at least one sample (--images >= --gpus)"
 
-    def timed_job(fm_used, batches, n_total, n_local):
-        cv_ = make_cv(model, n_total, args.k, args.tie_mode)
+    def timed_job(fm_used, batches, n_total, n_local, model_=None):
+        cv_ = make_cv(model_ or model, n_total, args.k, args.tie_mode)
         N.prof_enable(True)
         N.prof_reset()
         torch.cuda.synchronize()
@@ -586,6 +587,26 @@ def main():
         N.prof_enable(False)
         line["images_per_s_fp32_gemm"] = {"value": n_few / dt32, "steps": len(few),
                                           "note": "same step with NativeClip(gemm='f32'): no bf16 operand anywhere"}
+    if world == 1 and not args.no_channels_last:
+        # the same job on a channels_last copy of the probed model: the hooked activations arrive component-contiguous and
+        # K1 runs its column-reduce kernel instead of the row-reduce kernel of the headline
+        import copy
+
+        model_cl = copy.deepcopy(model).to(memory_format=torch.channels_last)
+        few = batches[: min(K, 24)]
+        n_few = sum(b.shape[0] for b in few)
+        timed_job(fm, few[:2], 2 * B, 2 * B, model_cl)  # MIOpen picks its NHWC kernels
+        dtcl, _ = timed_job(fm, few, n_few, n_few, model_cl)
+        cl_ms, cl_n, cl_bytes = N.prof_read(N.SL_PROF_REDUCE)
+        N.prof_enable(False)
+        line["channels_last"] = {
+            "images_per_s": n_few / dtcl, "steps": len(few),
+            "k1": {"kernel": "colreduce (K1, component axis contiguous)", "GB/s": cl_bytes / cl_ms / 1e6 if cl_ms else None,
+                   "frac": cl_bytes / cl_ms / 1e6 / HBM_PEAK_GBPS if cl_ms else None, "launches": cl_n,
+                   "avg_launch_us": cl_ms / max(cl_n, 1) * 1e3},
+            "self_check": None if args.no_self_check else self_check(dev, model_cl, fm, args),
+            "note": "same step with model.to(memory_format=torch.channels_last); not the headline (the reference's models run NCHW)"}
+        del model_cl
     if world == 1 and not args.no_api_leg:
         line["api_path"] = api_path_leg(dev, model, fm_base, args)
     if world == 1 and not args.no_probing:
