@@ -398,5 +398,16 @@ inline bool worth_it(int64_t M, int64_t N) {
   return tiles_of(M, N) * 100 >= (int64_t)min_pct * num_cus();
 }
 
+// fp32-input MFMA mode: a tile takes 5.3x longer than in bf16x3 mode and the 128 x 128 kernel reaches 0.76-0.83 of peak on
+// its own, so the big kernel only pays when its last round is nearly full or there is a single round
+// (tools/native/gemm3_lab, K = 1152: 150 tiles 84 vs 79 TFLOP/s, 600 tiles 112 vs 120, 1280 tiles 140 vs 126, 1440 tiles
+// 132 vs 123).
+inline bool worth_it_f32(int64_t M, int64_t N) {
+  if (!worth_it(M, N)) return false;
+  const int64_t t = tiles_of(M, N), cus = num_cus();
+  const int64_t rounds = (t + cus - 1) / cus;
+  return rounds == 1 || t * 10 >= rounds * cus * 9;
+}
+
 }  // namespace gemm8
 }  // namespace sl

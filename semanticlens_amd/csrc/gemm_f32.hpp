@@ -205,7 +205,7 @@ int launch_gemm_nt(ProfScope& prof, const float* A, int64_t M, const float* B, i
     const char* e = getenv("SL_F32_TILE");
     return e ? atoi(e) : 0;
   }();
-  if (vec && K % 32 == 0 && K > 0 && gemm8::fits(M, N, K * 4) && (forced ? forced == 8 : gemm8::worth_it(M, N)))
+  if (vec && K % 32 == 0 && K > 0 && gemm8::fits(M, N, K * 4) && (forced ? forced == 8 : gemm8::worth_it_f32(M, N)))
     return gemm8::launch<gemm8::MODE_F32>(prof, A, M, B, N, K * 4, K / 32, epi, st);
   if (vec)
     SL_LAUNCH(prof, (gemm_nt_kernel<true, Epi>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, A, B, M, N, K, (int)tn, epi);

@@ -18,6 +18,7 @@
 //                   workgroup split T and combine through LDS.
 //   generic       — any strides / fp16 / bf16: one lane per output element.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -730,14 +731,15 @@ __device__ inline float4 nt_load4(const float* p) {
   const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
   return make_float4(v[0], v[1], v[2], v[3]);
 }
-#define SL_NT_LOAD4(p) nt_load4(p)
 
 // ---- colreduce: out[b][f] = op_t x[b][t][f], f contiguous ------------------------------------
 // One workgroup (4 waves) per (b, 256-float chunk of F); waves split T; LDS combine.
+// Cache policy as in the row kernels (top of this file): tasks below `tail_from` (in memory order: b-major) stream with
+// nt, the rest use the default policy, and the walk starts at `tail_from` so that the bytes written last are read first.
 template <int OP>
 __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ x, int64_t B, int T, int64_t F,
                                                          int64_t sb, int64_t st, int t_begin, int t_end,
-                                                         float denom, uint16_t* __restrict__ cand,
+                                                         float denom, int64_t tail_from, uint16_t* __restrict__ cand,
                                                          float* __restrict__ outf) {
   __shared__ float s_part[4][256];
   constexpr bool SUM = (OP == OP_SUM || OP == OP_ABSSUM);
@@ -745,29 +747,41 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
   const int w = threadIdx.x >> 6;
   const int64_t nchunk = (F + 255) / 256;
   const int64_t ntask = B * nchunk;
-  for (int64_t task = blockIdx.x; task < ntask; task += gridDim.x) {
+  const int64_t rot = (tail_from > 0 && tail_from < ntask) ? tail_from : 0;
+  for (int64_t ti = blockIdx.x; ti < ntask; ti += gridDim.x) {
+    int64_t task = ti + rot;
+    if (task >= ntask) task -= ntask;
     const int64_t b = task / nchunk;
     const int64_t f0 = (task % nchunk) * 256 + lane * 4;
     Acc<OP> a0, a1, a2, a3;
     a0.init(); a1.init(); a2.init(); a3.init();
     const bool in = f0 < F;  // F % 4 == 0 on this path
     const float* base = x + b * sb + f0;
-    if (in) {
+    auto walk = [&](auto NT) __attribute__((always_inline)) {
+      constexpr bool nt = decltype(NT)::value;
+      auto ld = [&](const float* p) __attribute__((always_inline)) {
+        if constexpr (nt) return nt_load4(p);
+        else return *reinterpret_cast<const float4*>(p);
+      };
       int t = t_begin + w;
 #pragma unroll 1
       for (; t + 28 < t_end; t += 32) {  // 8 loads in flight per lane
         float4 v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = SL_NT_LOAD4(base + (int64_t)(t + 4 * j) * st);
+        for (int j = 0; j < 8; ++j) v[j] = ld(base + (int64_t)(t + 4 * j) * st);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           a0.add(v[j].x, true); a1.add(v[j].y, true); a2.add(v[j].z, true); a3.add(v[j].w, true);
         }
       }
       for (; t < t_end; t += 4) {
-        float4 v = SL_NT_LOAD4(base + (int64_t)t * st);
+        float4 v = ld(base + (int64_t)t * st);
         a0.add(v.x, true); a1.add(v.y, true); a2.add(v.z, true); a3.add(v.w, true);
       }
+    };
+    if (in) {
+      if (task < tail_from) walk(std::true_type());
+      else walk(std::false_type());
     }
     s_part[w][lane * 4 + 0] = a0.lane_value();
     s_part[w][lane * 4 + 1] = a1.lane_value();
@@ -948,8 +962,13 @@ void launch_colreduce(ProfScope& prof, const float* x, int64_t B, int T, int64_t
   const int64_t cap = (int64_t)num_cus() * 8;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  SL_LAUNCH(prof, (colreduce_kernel<OP>), dim3((unsigned)blocks), dim3(256), 0, st, x, B, T, F, sb, st_, t0, t1, denom, cand,
-            outf);
+  // cache policy (top of this file), in tasks = (b, chunk) pairs, b-major like the bytes
+  const int64_t nt_min_bytes = nt_min_bytes_(), tail_bytes = tail_bytes_();
+  const int64_t nchunk = (F + 255) / 256, per_b = (int64_t)T * F * 4, bytes = B * per_b;
+  int64_t tail_from = 0;  // everything with the default policy
+  if (bytes >= nt_min_bytes) tail_from = tail_bytes > 0 ? (bytes > tail_bytes ? (bytes - tail_bytes) / per_b * nchunk : 0) : INT64_MAX;
+  SL_LAUNCH(prof, (colreduce_kernel<OP>), dim3((unsigned)blocks), dim3(256), 0, st, x, B, T, F, sb, st_, t0, t1, denom, tail_from,
+            cand, outf);
 }
 
 template <typename T, int OP>
