@@ -732,12 +732,52 @@ __device__ inline float4 nt_load4(const float* p) {
   return make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// ---- 2-byte activations (fp16 / bf16 models): element tags are _Float16 and uint16_t (bf16 bits) ---------------------
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ inline void unpack2(uint32_t w, float& lo, float& hi);
+template <>
+__device__ inline void unpack2<uint16_t>(uint32_t w, float& lo, float& hi) {
+  lo = bits_f32(w << 16);
+  hi = bits_f32(w & 0xFFFF0000u);
+}
+template <>
+__device__ inline void unpack2<_Float16>(uint32_t w, float& lo, float& hi) {
+  const f16x2 h = __builtin_bit_cast(f16x2, w);
+  lo = (float)h[0];
+  hi = (float)h[1];
+}
+// four consecutive elements as floats: one 16-byte (fp32) or 8-byte (fp16 / bf16) load, streaming policy or default
+template <typename T, bool NT>
+__device__ inline float4 load4_as_f32(const T* p) {
+  if constexpr (sizeof(T) == 4) {
+    if constexpr (NT) return nt_load4(reinterpret_cast<const float*>(p));
+    else return *reinterpret_cast<const float4*>(p);
+  } else {
+    u32x2 w;
+    if constexpr (NT) w = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
+    else w = *reinterpret_cast<const u32x2*>(p);
+    float4 r;
+    unpack2<T>(w[0], r.x, r.y);
+    unpack2<T>(w[1], r.z, r.w);
+    return r;
+  }
+}
+// round to the activation dtype first (the reference aggregates in that dtype), then report
+template <typename T>
+__device__ inline float round_to_dtype(float v) { return v; }
+template <>
+__device__ inline float round_to_dtype<_Float16>(float v) { return (float)(_Float16)v; }
+template <>
+__device__ inline float round_to_dtype<uint16_t>(float v) { return bf16_to_f32(f32_to_bf16_rne(v)); }
+
 // ---- colreduce: out[b][f] = op_t x[b][t][f], f contiguous ------------------------------------
 // One workgroup (4 waves) per (b, 256-float chunk of F); waves split T; LDS combine.
 // Cache policy as in the row kernels (top of this file): tasks below `tail_from` (in memory order: b-major) stream with
 // nt, the rest use the default policy, and the walk starts at `tail_from` so that the bytes written last are read first.
-template <int OP>
-__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ x, int64_t B, int T, int64_t F,
+template <typename E, int OP>
+__global__ __launch_bounds__(256) void colreduce_kernel(const E* __restrict__ x, int64_t B, int T, int64_t F,
                                                          int64_t sb, int64_t st, int t_begin, int t_end,
                                                          float denom, int64_t tail_from, uint16_t* __restrict__ cand,
                                                          float* __restrict__ outf) {
@@ -756,13 +796,10 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
     Acc<OP> a0, a1, a2, a3;
     a0.init(); a1.init(); a2.init(); a3.init();
     const bool in = f0 < F;  // F % 4 == 0 on this path
-    const float* base = x + b * sb + f0;
+    const E* base = x + b * sb + f0;
     auto walk = [&](auto NT) __attribute__((always_inline)) {
       constexpr bool nt = decltype(NT)::value;
-      auto ld = [&](const float* p) __attribute__((always_inline)) {
-        if constexpr (nt) return nt_load4(p);
-        else return *reinterpret_cast<const float4*>(p);
-      };
+      auto ld = [&](const E* p) __attribute__((always_inline)) { return load4_as_f32<E, nt>(p); };
       int t = t_begin + w;
 #pragma unroll 1
       for (; t + 28 < t_end; t += 32) {  // 8 loads in flight per lane
@@ -796,11 +833,128 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
         r = combine<SUM>(r, s_part[1][f]);
         r = combine<SUM>(r, s_part[2][f]);
         r = combine<SUM>(r, s_part[3][f]);
-        r = finish<OP>(r, denom);
+        r = round_to_dtype<E>(finish<OP>(r, denom));  // the reference aggregates in the activation's dtype
         store_outputs(r, b * F + fg, cand, outf);
       }
     }
     __syncthreads();
+  }
+}
+
+// ---- rowreduce_h: contiguous rows of 2-byte elements (NCHW activations of fp16 / bf16 models) -------------------------
+// x 16-byte aligned, R rows of S elements back to back.  G lanes per row (64 / G rows = one *set* per wave pass); a lane
+// loads 16-byte pieces (8 elements) of its row's window, converts to fp32 and masks the elements that belong to the
+// neighbouring rows (rows start on 2-byte boundaries).  An aligned 16-byte piece that holds at least one valid byte never
+// crosses a page, so the window's first and last piece are safe to read whole.  U sets x J pieces per lane are in flight
+// before any is reduced (short rows would otherwise keep < 1 KB per wave in flight).  max: v_max_f32 drops NaN, so a
+// running sum rides along as the NaN detector and a row whose sum is NaN is re-scanned exactly (as in the fp32 kernels).
+// Same cache policy and tail-first walk as the fp32 kernels; sums accumulate in fp32 and are rounded to the activation
+// dtype once, like torch's.
+template <typename T, int G, int U, int J, int OP, bool ALIGNED>
+__global__ __launch_bounds__(256) void rowreduce_h_kernel(const T* __restrict__ x, int64_t R, int S, float denom, int64_t tail_from,
+                                                           uint16_t* __restrict__ cand, float* __restrict__ outf) {
+  constexpr int RPW = kWave / G;
+  constexpr bool SUMOP = (OP == OP_SUM || OP == OP_ABSSUM);
+  constexpr bool ABS = (OP == OP_ABSMAX || OP == OP_ABSSUM);
+  const float fill = SUMOP ? 0.f : -__builtin_huge_valf();
+  const int lane = threadIdx.x & 63;
+  const int li = lane & (G - 1);
+  const int g = lane / G;
+  const int64_t nsets = (R + RPW - 1) / RPW;
+  const int64_t nbatch = (nsets + U - 1) / U;  // a batch = U consecutive sets
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int64_t rot = (tail_from > 0 && tail_from < nbatch) ? tail_from : 0;
+  const int np_max = ALIGNED ? S / 8 : (S + 14) / 8;  // pieces a row's window can touch
+  const u32x4* xp = reinterpret_cast<const u32x4*>(x);
+  for (int64_t bi = wave0; bi < nbatch; bi += nwaves) {
+    int64_t batch = bi + rot;
+    if (batch >= nbatch) batch -= nbatch;
+    int64_t row[U];
+    int h[U], np[U];
+    const u32x4* rp[U];
+    float m[U], sum[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      row[u] = (batch * U + u) * RPW + g;
+      const bool ok = row[u] < R;
+      const int64_t e0 = (ok ? row[u] : 0) * (int64_t)S;
+      h[u] = ALIGNED ? 0 : (int)(e0 & 7);
+      np[u] = ok ? (h[u] + S + 7) >> 3 : 0;
+      rp[u] = xp + (e0 >> 3);
+      m[u] = fill;
+      sum[u] = 0.f;
+    }
+    auto walk = [&](auto NT) __attribute__((always_inline)) {
+      constexpr bool nt = decltype(NT)::value;
+      for (int q0 = 0; q0 < np_max; q0 += J * G) {
+        u32x4 w[U][J];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            const int q = q0 + j * G + li;
+            w[u][j] = u32x4{0u, 0u, 0u, 0u};
+            if (q < np[u]) {
+              if constexpr (nt) w[u][j] = __builtin_nontemporal_load(rp[u] + q);
+              else w[u][j] = rp[u][q];
+            }
+          }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            const int q = q0 + j * G + li;
+            const bool in = q < np[u];
+            const int idx0 = q * 8 - h[u];  // row-relative index of the piece's first element
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              float e[2];
+              unpack2<T>(w[u][j][d], e[0], e[1]);
+#pragma unroll
+              for (int k = 0; k < 2; ++k) {
+                float v = ABS ? __builtin_fabsf(e[k]) : e[k];
+                const bool valid = ALIGNED ? in : (in && (unsigned)(idx0 + 2 * d + k) < (unsigned)S);
+                v = valid ? v : fill;
+                if constexpr (SUMOP) {
+                  sum[u] += v;
+                } else {
+                  m[u] = __builtin_fmaxf(m[u], v);
+                  sum[u] += v;  // NaN detector only
+                }
+              }
+            }
+          }
+      }
+    };
+    if (batch < tail_from) walk(std::true_type());
+    else walk(std::false_type());
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = row[u] < R;
+      float r;
+      if constexpr (SUMOP) {
+        r = group_allreduce_f<G, true>(sum[u]);
+      } else {
+        r = group_allreduce_f<G, false>(m[u]);
+        if (__builtin_expect(__any(ok && sum[u] != sum[u]), 0)) {  // a NaN, or +inf and -inf (or fill) together: look again
+          const float sred = group_allreduce_f<G, true>(sum[u]);
+          bool nan = false;
+          if (ok && sred != sred) {
+            const T* rowp = x + row[u] * (int64_t)S;
+            for (int i = li; i < S; i += G) {
+              float lo, hi;
+              unpack2<T>((uint32_t)__builtin_bit_cast(uint16_t, rowp[i]), lo, hi);
+              nan |= (lo != lo);
+            }
+          }
+          const float f = group_allreduce_f<G, false>(nan ? 1.f : 0.f);
+          if (f > 0.f) r = bits_f32(0x7FC00000u);
+        }
+      }
+      r = round_to_dtype<T>(finish<OP>(r, denom));
+      if (li == 0 && ok) store_outputs(r, row[u], cand, outf);
+    }
   }
 }
 
@@ -813,14 +967,6 @@ template <>
 __device__ inline float load_as_f32<_Float16>(const void* p, int64_t i) { return (float)((const _Float16*)p)[i]; }
 template <>
 __device__ inline float load_as_f32<uint16_t>(const void* p, int64_t i) { return bf16_to_f32(((const uint16_t*)p)[i]); }
-
-// round to the activation dtype first (the reference aggregates in that dtype), then report
-template <typename T>
-__device__ inline float round_to_dtype(float v) { return v; }
-template <>
-__device__ inline float round_to_dtype<_Float16>(float v) { return (float)(_Float16)v; }
-template <>
-__device__ inline float round_to_dtype<uint16_t>(float v) { return bf16_to_f32(f32_to_bf16_rne(v)); }
 
 template <typename T, int OP>
 __global__ __launch_bounds__(256) void generic_reduce_kernel(const void* __restrict__ x, int64_t B, int64_t C,
@@ -955,8 +1101,8 @@ void dispatch_rowreduce(ProfScope& prof, const float* x, int64_t R, int S, float
   else launch_rowreduce<64, 4, OP>(prof, x, R, S, denom, cand, outf, st);
 }
 
-template <int OP>
-void launch_colreduce(ProfScope& prof, const float* x, int64_t B, int T, int64_t F, int64_t sb, int64_t st_, int t0, int t1,
+template <typename T, int OP>
+void launch_colreduce(ProfScope& prof, const T* x, int64_t B, int T_, int64_t F, int64_t sb, int64_t st_, int t0, int t1,
                       float denom, uint16_t* cand, float* outf, hipStream_t st) {
   int64_t blocks = B * ((F + 255) / 256);
   const int64_t cap = (int64_t)num_cus() * 8;
@@ -964,11 +1110,50 @@ void launch_colreduce(ProfScope& prof, const float* x, int64_t B, int T, int64_t
   if (blocks < 1) blocks = 1;
   // cache policy (top of this file), in tasks = (b, chunk) pairs, b-major like the bytes
   const int64_t nt_min_bytes = nt_min_bytes_(), tail_bytes = tail_bytes_();
-  const int64_t nchunk = (F + 255) / 256, per_b = (int64_t)T * F * 4, bytes = B * per_b;
+  const int64_t nchunk = (F + 255) / 256, per_b = (int64_t)T_ * F * (int64_t)sizeof(T), bytes = B * per_b;
   int64_t tail_from = 0;  // everything with the default policy
   if (bytes >= nt_min_bytes) tail_from = tail_bytes > 0 ? (bytes > tail_bytes ? (bytes - tail_bytes) / per_b * nchunk : 0) : INT64_MAX;
-  SL_LAUNCH(prof, (colreduce_kernel<OP>), dim3((unsigned)blocks), dim3(256), 0, st, x, B, T, F, sb, st_, t0, t1, denom, tail_from,
+  SL_LAUNCH(prof, (colreduce_kernel<T, OP>), dim3((unsigned)blocks), dim3(256), 0, st, x, B, T_, F, sb, st_, t0, t1, denom,
+            tail_from, cand, outf);
+}
+
+template <typename T, int G, int U, int J, int OP, bool ALIGNED>
+void launch_rowreduce_h(ProfScope& prof, const T* x, int64_t R, int S, float denom, uint16_t* cand, float* outf, hipStream_t st) {
+  constexpr int RPW = kWave / G;
+  const int64_t nsets = (R + RPW - 1) / RPW;
+  const int64_t nbatch = (nsets + U - 1) / U;
+  int64_t blocks = (nbatch + 3) / 4;
+  const int64_t cap = (int64_t)num_cus() * 8;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  const int64_t nt_min_bytes = nt_min_bytes_(), tail_bytes = tail_bytes_();
+  const int64_t batch_bytes = (int64_t)U * RPW * S * 2, bytes = R * (int64_t)S * 2;
+  int64_t tail_from = 0;
+  if (bytes >= nt_min_bytes) tail_from = tail_bytes > 0 ? (bytes > tail_bytes ? (bytes - tail_bytes) / batch_bytes : 0) : INT64_MAX;
+  SL_LAUNCH(prof, (rowreduce_h_kernel<T, G, U, J, OP, ALIGNED>), dim3((unsigned)blocks), dim3(256), 0, st, x, R, S, denom, tail_from,
             cand, outf);
+}
+
+// G = lanes per row: the smallest power of two that covers the pieces of a row's window (at most 64: longer rows loop)
+template <typename T, int OP>
+void dispatch_rowreduce_h(ProfScope& prof, const T* x, int64_t R, int S, float denom, uint16_t* cand, float* outf, hipStream_t st) {
+  const bool al = S % 8 == 0;
+  const int np = al ? S / 8 : (S + 14) / 8;
+#define SL_ROWH(G, U, J)                                                                          \
+  do {                                                                                            \
+    if (al) launch_rowreduce_h<T, G, U, J, OP, true>(prof, x, R, S, denom, cand, outf, st);       \
+    else launch_rowreduce_h<T, G, U, J, OP, false>(prof, x, R, S, denom, cand, outf, st);         \
+    return;                                                                                       \
+  } while (0)
+  if (np <= 1) SL_ROWH(1, 4, 1);
+  if (np <= 2) SL_ROWH(2, 4, 1);
+  if (np <= 4) SL_ROWH(4, 4, 1);
+  if (np <= 8) SL_ROWH(8, 4, 1);
+  if (np <= 16) SL_ROWH(16, 4, 1);
+  if (np <= 32) SL_ROWH(32, 4, 1);
+  if (np <= 64) SL_ROWH(64, 4, 1);
+  SL_ROWH(64, 2, 2);
+#undef SL_ROWH
 }
 
 template <typename T, int OP>
@@ -1001,7 +1186,18 @@ int reduce_dispatch(ProfScope& prof, const void* x, int dtype, int64_t B, int64_
     dispatch_rowreduce<OP>(prof, (const float*)x, B * C, (int)S, denom, cand, outf, st);
   } else if (dtype == SL_F32 && aligned && sc == 1 && (C % 4) == 0 && (ss % 4) == 0 && (sb % 4) == 0 &&
              S < (1 << 30)) {
-    launch_colreduce<OP>(prof, (const float*)x, B, (int)S, C, sb, ss, (int)s0, (int)s1, denom, cand, outf, st);
+    launch_colreduce<float, OP>(prof, (const float*)x, B, (int)S, C, sb, ss, (int)s0, (int)s1, denom, cand, outf, st);
+  } else if (dtype != SL_F32 && aligned && full && ss == 1 && sc == S && sb == C * S && S > 0 && S < (1 << 27)) {
+    // fp16 / bf16, NCHW-contiguous rows
+    if (dtype == SL_F16) dispatch_rowreduce_h<_Float16, OP>(prof, (const _Float16*)x, B * C, (int)S, denom, cand, outf, st);
+    else dispatch_rowreduce_h<uint16_t, OP>(prof, (const uint16_t*)x, B * C, (int)S, denom, cand, outf, st);
+  } else if (dtype != SL_F32 && ((uintptr_t)x & 7) == 0 && sc == 1 && (C % 4) == 0 && (ss % 4) == 0 && (sb % 4) == 0 &&
+             S < (1 << 30)) {
+    // fp16 / bf16, component axis contiguous (channels_last, tokens): 8-byte loads of four components
+    if (dtype == SL_F16)
+      launch_colreduce<_Float16, OP>(prof, (const _Float16*)x, B, (int)S, C, sb, ss, (int)s0, (int)s1, denom, cand, outf, st);
+    else
+      launch_colreduce<uint16_t, OP>(prof, (const uint16_t*)x, B, (int)S, C, sb, ss, (int)s0, (int)s1, denom, cand, outf, st);
   } else {
     dispatch_generic<OP>(prof, x, dtype, B, C, S, sb, sc, ss, s0, s1, denom, cand, outf, st);
   }

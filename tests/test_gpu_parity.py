@@ -233,6 +233,79 @@ def test_conv_reduce_special_values_and_partial_batches(shape):
             assert np.array_equal(got[~fin & ~np.isnan(want)], want[~fin & ~np.isnan(want)])
 
 
+HALF_SHAPES = [(2, 3, 1, 1), (3, 5, 1, 3), (4, 8, 7, 7), (5, 6, 7, 7), (3, 7, 3, 3), (2, 16, 8, 8), (3, 5, 9, 9), (2, 8, 14, 14),
+               (3, 3, 15, 17), (2, 4, 28, 28), (1, 3, 56, 56), (2, 2, 57, 59), (1, 2, 100, 103), (33, 64, 7, 7), (16, 64, 14, 14),
+               (8, 32, 28, 28), (9, 100, 14, 14), (2, 3, 40, 40)]
+
+
+@pytest.mark.parametrize("shape", HALF_SHAPES)
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_conv_reduce_half_precision_fast_paths(shape, dt):
+    """fp16 / bf16 activations (half-precision models) on their own kernels: NCHW rows (rowreduce_h: 16-byte pieces of 8
+    elements, rows starting on any 2-byte boundary), channels_last (8-byte loads of four components) and, through a
+    misaligned view, the generic kernel — all three must agree with the oracle fed the same (rounded) values.  max is
+    exact; mean accumulates in fp32 and is rounded once to the activation dtype, like torch's."""
+    rng = np.random.RandomState(sum(shape) + (1 if dt == torch.float16 else 2))
+    x = torch.from_numpy(rng.randn(*shape).astype(np.float32)).to(dt)
+    flat = x.view(shape[0] * shape[1], -1)
+    R, S = flat.shape
+    for r in rng.choice(R, size=min(R, 10), replace=False):
+        kind, c = rng.randint(6), rng.randint(S)
+        if kind == 0:
+            flat[r, c] = float("nan")
+        elif kind == 1:
+            flat[r, c] = float("inf")
+            flat[r, (c + 1) % S] = -float("inf")
+        elif kind == 2:
+            flat[r, :] = -float("inf")
+        elif kind == 3:
+            flat[r, S - 1] = float("nan")
+        elif kind == 4:
+            flat[r, 0] = float("inf")
+        else:
+            flat[r, c] = -float("inf")
+    xf = x.float().numpy()
+    B, C = shape[:2]
+    pad = torch.empty(x.numel() + 1, dtype=dt, device=DEV)
+    pad[1:] = x.reshape(-1).to(DEV)
+    variants = {"nchw": x.to(DEV), "channels_last": x.to(DEV).contiguous(memory_format=torch.channels_last),
+                "misaligned": pad[1:].view(shape)}
+    for name, code in (("max", N.SL_CONV_MAX), ("mean", N.SL_CONV_MEAN)):
+        want = oracle.agg_conv(xf, name)
+        if name == "mean":  # one rounding to the activation dtype (torch.mean of a half tensor)
+            want = torch.from_numpy(want).to(dt).float().numpy()
+        for tag, xd in variants.items():
+            cand = torch.empty((B, C), dtype=torch.bfloat16, device=DEV)
+            out = torch.empty((B, C), dtype=torch.float32, device=DEV)
+            N.reduce_conv(xd, code, cand, out)
+            got = out.cpu().numpy()
+            if name == "max":
+                assert feq(got, want), (tag, shape)
+                assert np.array_equal(bits(cand), oracle.f32_to_bf16(want)), (tag, shape)
+            else:
+                assert np.array_equal(np.isnan(got), np.isnan(want)), (tag, shape)
+                fin = np.isfinite(want)
+                ulp = 2.0 ** -10 if dt == torch.float16 else 2.0 ** -7  # one ulp of the activation dtype
+                np.testing.assert_allclose(got[fin], want[fin], rtol=ulp, atol=1e-6)
+                assert np.array_equal(got[~fin & ~np.isnan(want)], want[~fin & ~np.isnan(want)]), (tag, shape)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_half_precision_full_size_equals_torch(dt):
+    """ResNet-50 layer shapes at the bench batch size: the kernels' max equals torch.amax bit for bit in both layouts."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for shape in ((256, 512, 28, 28), (256, 1024, 14, 14), (256, 2048, 7, 7)):
+        x = torch.randn(shape, device=DEV, generator=g).to(dt)
+        want = x.amax((2, 3)).to(torch.bfloat16)
+        for xd in (x, x.contiguous(memory_format=torch.channels_last)):
+            cand = torch.empty(shape[:2], dtype=torch.bfloat16, device=DEV)
+            N.reduce_conv(xd, N.SL_CONV_MAX, cand, None)
+            assert torch.equal(cand, want), shape
+        got = agg.aggregate_conv_mean(x)
+        assert got.dtype == dt
+        assert torch.allclose(got.float(), x.float().mean((2, 3)).cpu(), rtol=2.0 ** -7, atol=1e-6)
+
+
 TOKEN_SHAPES = [(2, 10, 16), (3, 197, 24), (2, 5, 7), (4, 50, 768), (2, 197, 260), (1, 1, 4), (3, 33, 1000)]
 
 
