@@ -192,8 +192,11 @@ __global__ __launch_bounds__(256) void rowreduce_kernel(const float* __restrict_
     const float4* __restrict__ A = reinterpret_cast<const float4*>(x + a0);  // wave-uniform, 16-byte aligned
     // last whole piece of the tensor, relative to A: lanes whose piece would start beyond it are
     // clamped onto it; every element they then hold is masked by its row position anyway
+    // (a batch that starts at or beyond the last whole piece — always the case for a tensor of fewer than four floats —
+    // clamps onto its own first piece: aligned, holds at least one float of the tensor, hence readable; index -1 would
+    // be the 16 bytes in front of the tensor)
     const int64_t lim = (total4 - a0) / 4 - 1;
-    const int idx_max = lim > 0x7FFFFFFF ? 0x7FFFFFFF : (int)lim;
+    const int idx_max = lim > 0x7FFFFFFF ? 0x7FFFFFFF : (lim < 0 ? 0 : (int)lim);
     const int64_t rel = total4 - a0;  // floats of whole pieces left from A on
     const int rel_lim = rel > 0x7FFFFFFF ? 0x7FFFFFFF : (int)rel;
 

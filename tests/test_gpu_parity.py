@@ -136,6 +136,7 @@ def test_total_mode_is_batch_invariant_and_shard_mergeable():
 
 # ------------------------------------------------------------------------------------------- K1/K2
 CONV_SHAPES = [
+    (1, 1, 1, 1), (1, 2, 1, 1), (1, 3, 1, 1), (1, 1, 1, 3), (3, 1, 1, 1), (1, 1, 1, 2),  # fewer than four floats in all
     (2, 3, 1, 1), (3, 5, 1, 3), (2, 4, 2, 2), (3, 7, 3, 3), (4, 8, 7, 7), (5, 6, 7, 7), (2, 16, 8, 8), (3, 5, 9, 9),
     (2, 9, 13, 13), (2, 8, 14, 14), (3, 3, 15, 17), (2, 4, 28, 28), (1, 3, 56, 56), (2, 2, 57, 59), (1, 2, 100, 103),
     (64, 256, 7, 7), (16, 64, 14, 14),
