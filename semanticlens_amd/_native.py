@@ -154,14 +154,17 @@ def _dtype_code(t: torch.Tensor) -> int:
 # K1 / K2
 # ------------------------------------------------------------------------------------------------
 def _flatten_spatial(x: torch.Tensor):
-    """(B,C,H,W) -> strides (sb, sc, ss) of the (B,C,H*W) view, making a copy only if H,W cannot merge."""
+    """(B,C,H,W) -> strides (sb, sc, ss) of the (B,C,H*W) view, making a copy only if H,W cannot merge.  The stride of a
+    size-1 dimension carries no information (torch keeps whatever the view had), so it is never used."""
     B, C, H, W = x.shape
     sb, sc, sh, sw = x.stride()
     if H == 1:
         return x, sb, sc, sw
+    if W == 1:
+        return x, sb, sc, sh
     if sh != W * sw:
         x = x.contiguous()
-        sb, sc, sh, sw = x.stride()
+        return x, C * H * W, H * W, 1
     return x, sb, sc, sw
 
 

@@ -181,6 +181,12 @@ def test_conv_reduce_layouts_and_dtypes():
         N.reduce_conv(variant, N.SL_CONV_MAX, None, out)
         assert feq(out.cpu().numpy(), ref)
     assert feq(agg.aggregate_conv_max(xd.contiguous(memory_format=torch.channels_last)).numpy(), want)
+    # views with a size-1 spatial dimension: its stride is whatever the view had and must not be used
+    y = torch.randn(4, 3, 1, 8, generator=g).to(DEV)
+    for variant in (y.transpose(2, 3), y, y.transpose(2, 3)[:, :, ::2], y[:, :, :, ::3]):
+        out = torch.empty(variant.shape[:2], dtype=torch.float32, device=DEV)
+        N.reduce_conv(variant, N.SL_CONV_MAX, None, out)
+        assert feq(out.cpu().numpy(), oracle.agg_conv(variant.cpu().contiguous().numpy(), "max"))
     for dt in (torch.float16, torch.bfloat16):
         xh = xd.to(dt)
         got = agg.aggregate_conv_max(xh)

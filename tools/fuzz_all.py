@@ -1,0 +1,204 @@
+"""Edge-shape fuzz of the C-ABI kernels against the oracle, synchronising after every call and printing the case first
+(a GPU memory fault kills the process: the last line names the culprit).  python tools/fuzz_all.py [seed] [family]"""
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import oracle  # noqa: E402
+from semanticlens_amd import _native as N  # noqa: E402
+from semanticlens_amd import scores  # noqa: E402
+
+DEV = "cuda:0"
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+family = sys.argv[2] if len(sys.argv) > 2 else "all"
+rng = np.random.RandomState(seed)
+
+
+def feq(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+def fuzz_reduce(n=300):
+    for it in range(n):
+        B, C, H, W = (int(rng.randint(1, 10)) for _ in range(4))
+        if rng.randint(4) == 0:
+            H, W = int(rng.choice([7, 14, 28, 13])), int(rng.choice([7, 14, 28, 5]))
+        dt = [torch.float32, torch.float16, torch.bfloat16][rng.randint(3)]
+        layout = ["nchw", "cl", "slice_c", "slice_hw", "transpose", "offset"][rng.randint(6)]
+        print("reduce", it, (B, C, H, W), dt, layout, flush=True)
+        x = torch.from_numpy(rng.randn(B, C, H, W).astype(np.float32)).to(dt)
+        if rng.randint(3) == 0:
+            x.view(-1)[rng.randint(x.numel())] = float("nan")
+        xd = x.to(DEV)
+        if layout == "cl":
+            v = xd.contiguous(memory_format=torch.channels_last)
+        elif layout == "slice_c":
+            v = xd[:, ::2]
+        elif layout == "slice_hw":
+            v = xd[:, :, : max(1, H - 1), : max(1, W - 1)]
+        elif layout == "transpose":
+            v = xd.transpose(2, 3)
+        elif layout == "offset":
+            pad = torch.empty(x.numel() + 3, dtype=dt, device=DEV)
+            off = int(rng.randint(0, 4))
+            pad[off : off + x.numel()] = xd.reshape(-1)
+            v = pad[off : off + x.numel()].view(B, C, H, W)
+        else:
+            v = xd
+        ref_in = v.float().cpu().contiguous().numpy()
+        for name, code in (("max", N.SL_CONV_MAX), ("mean", N.SL_CONV_MEAN), ("sum", N.SL_CONV_SUM)):
+            out = torch.empty(v.shape[:2], dtype=torch.float32, device=DEV)
+            cand = torch.empty(v.shape[:2], dtype=torch.bfloat16, device=DEV)
+            N.reduce_conv(v, code, cand, out)
+            sync()
+            want = oracle.agg_conv(ref_in, name)
+            got = out.cpu().numpy()
+            if name == "max":
+                assert feq(got, want), (name, got, want)
+            else:
+                assert np.array_equal(np.isnan(got), np.isnan(want))
+                tol = 2e-6 if dt == torch.float32 else (2.0 ** -9 if dt == torch.float16 else 2.0 ** -6)
+                m = ~np.isnan(want)
+                np.testing.assert_allclose(got[m], want[m], rtol=tol, atol=1e-5)
+
+
+def fuzz_tokens(n=200):
+    for it in range(n):
+        B, T, F = int(rng.randint(1, 9)), int(rng.randint(1, 40)), int(rng.choice([1, 2, 3, 4, 5, 8, 12, 16, 31, 64, 260]))
+        dt = [torch.float32, torch.float16, torch.bfloat16][rng.randint(3)]
+        print("tokens", it, (B, T, F), dt, flush=True)
+        x = torch.from_numpy(rng.randn(B, T, F).astype(np.float32)).to(dt).to(DEV)
+        ref_in = x.float().cpu().numpy()
+        for name, code in (("mean", N.SL_TOK_MEAN), ("max", N.SL_TOK_MAX), ("absmax", N.SL_TOK_ABSMAX), ("token", N.SL_TOK_TOKEN)):
+            pos = int(rng.randint(T)) if name == "token" else 0
+            out = torch.empty((B, F), dtype=torch.float32, device=DEV)
+            N.reduce_tokens(x, code, pos, None, out)
+            sync()
+            want = oracle.agg_tokens(ref_in, name, pos)
+            tol = 2e-6 if dt == torch.float32 else (2.0 ** -9 if dt == torch.float16 else 2.0 ** -6)
+            np.testing.assert_allclose(out.cpu().numpy(), want, rtol=tol, atol=1e-5, err_msg=name)
+
+
+def fuzz_gather(n=150):
+    for it in range(n):
+        Nn, D = int(rng.randint(1, 50)), int(rng.choice([1, 2, 3, 4, 7, 16, 33, 512]))
+        C, k = int(rng.randint(1, 9)), int(rng.randint(1, 9))
+        print("gather", it, Nn, D, C, k, flush=True)
+        emb = rng.randn(Nn, D).astype(np.float32)
+        ids = rng.randint(-1, Nn, size=(C, k)).astype(np.int64)
+        got = N.gather_rows(torch.from_numpy(emb).to(DEV), torch.from_numpy(ids))
+        sync()
+        assert np.array_equal(got.cpu().numpy(), oracle.gather_rows(emb, ids))
+
+
+def fuzz_similarity(n=150):
+    for it in range(n):
+        Q, C, D = int(rng.randint(1, 40)), int(rng.randint(1, 40)), int(rng.choice([1, 2, 3, 4, 5, 8, 31, 32, 33, 64, 100, 129]))
+        mode = ["bf16x3", "f32"][rng.randint(2)]
+        print("similarity", it, Q, C, D, mode, flush=True)
+        x, y = rng.randn(Q, D).astype(np.float32), rng.randn(C, D).astype(np.float32)
+        N.set_gemm_mode(mode)
+        try:
+            got = scores.similarity_score(torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV))
+            sync()
+        finally:
+            N.set_gemm_mode(None)
+        want = oracle.similarity(x, y)
+        assert got.shape == want.shape, (got.shape, want.shape)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=2e-5)
+
+
+def fuzz_scores(n=120):
+    for it in range(n):
+        # k = 1 is excluded: the reference divides by k - 1 there and returns rounding-dependent inf / nan
+        C, k, D = int(rng.randint(1, 20)), int(rng.randint(2, 24)), int(rng.choice([1, 2, 3, 4, 8, 17, 64, 512]))
+        print("scores", it, C, k, D, flush=True)
+        V = rng.randn(C, k, D).astype(np.float32)
+        Vd = torch.from_numpy(V).to(DEV)
+        got = scores.clarity_score(Vd); sync()
+        np.testing.assert_allclose(got.cpu().numpy(), oracle.clarity(V), rtol=1e-4, atol=1e-5)
+        got = scores.redundancy_score(Vd); sync()
+        np.testing.assert_allclose(got.cpu().numpy(), oracle.redundancy(V), rtol=1e-4, atol=1e-5)
+        if k >= 2:
+            nc = int(rng.randint(2, min(k, 6) + 1))
+            got = scores.polysemanticity_score(Vd, n_clusters=nc); sync()
+            want = oracle.polysemanticity(V, n_clusters=nc)
+            np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-5, atol=1e-5, err_msg=f"poly k={nc}")
+
+
+def fuzz_preprocess(n=120):
+    from semanticlens_amd.foundation_models import DevicePreprocess
+
+    for it in range(n):
+        size = int(rng.choice([1, 2, 7, 24, 33, 64]))
+        mode = ["shortest", "squash"][rng.randint(2)]
+        interp = ["bicubic", "bilinear"][rng.randint(2)]
+        B = int(rng.randint(1, 6))
+        hws = []
+        for _ in range(B):
+            kind = rng.randint(4)
+            if kind == 0:
+                hws.append((int(rng.randint(1, 5)), int(rng.randint(1, 5))))  # tiny sources (upsampling)
+            elif kind == 1:
+                hws.append((int(rng.randint(1, 4)), int(rng.randint(40, 300))))  # extreme aspect ratios
+            elif kind == 2:
+                hws.append((int(rng.randint(40, 300)), int(rng.randint(1, 4))))
+            else:
+                hws.append((int(rng.randint(5, 200)), int(rng.randint(5, 200))))
+        print("preprocess", it, size, mode, interp, hws, flush=True)
+        imgs = [rng.randint(0, 256, (h, w, 3)).astype(np.uint8) for h, w in hws]
+        pp = DevicePreprocess(size, resize_mode=mode, interpolation=interp, device=DEV)
+        got = pp(imgs).cpu().numpy()
+        sync()
+        for i, im in enumerate(imgs):
+            want = oracle.preprocess(im, size, pp.mean, pp.std, mode, interp)[1]
+            assert np.array_equal(got[i], want), (i, hws[i], np.abs(got[i] - want).max())
+
+
+def fuzz_template(n=100):
+    for it in range(n):
+        Q, T, D = int(rng.randint(1, 20)), int(rng.randint(1, 9)), int(rng.choice([1, 2, 3, 4, 5, 8, 31, 512, 1152]))
+        print("template", it, Q, T, D, flush=True)
+        E, E0 = rng.randn(Q * T, D).astype(np.float32), rng.randn(T, D).astype(np.float32)
+        got = N.template_mean(torch.from_numpy(E).to(DEV), torch.from_numpy(E0).to(DEV), Q)
+        sync()
+        np.testing.assert_allclose(got.cpu().numpy(), oracle.template_mean(E, E0, Q), rtol=2e-6, atol=2e-6)
+
+
+def fuzz_collect(n=150):
+    from semanticlens_amd.component_visualization.activation_caching import ActMax
+
+    for it in range(n):
+        C, k = int(rng.randint(1, 40)), int(rng.randint(1, 12))
+        H, W = int(rng.randint(1, 8)), int(rng.randint(1, 8))
+        mode = ["aten", "total"][rng.randint(2)]
+        nb = int(rng.randint(1, 12))
+        print("collect", it, C, k, (H, W), mode, nb, flush=True)
+        am = ActMax(n_collect=k, n_latents=C, tie_mode=mode)
+        ref = oracle.ActMaxOracle(k, C, oracle.MODE_ATEN if mode == "aten" else oracle.MODE_TOTAL)
+        base = 0
+        for _ in range(nb):
+            B = int(rng.randint(1, 20))
+            x = (rng.randint(-3, 8, size=(B, C, H, W)) / 2).astype(np.float32)
+            am.collect(torch.from_numpy(x).to(DEV), ("conv", N.SL_CONV_MAX, 0), base)
+            sync()
+            ref.update(oracle.agg_conv(x, "max"), np.arange(base, base + B))
+            base += B
+        am.flush()
+        v = am.activations.view(torch.int16).numpy().view(np.uint16)
+        assert np.array_equal(v, ref.vals) and np.array_equal(am.sample_ids.numpy(), ref.ids)
+
+
+FAMS = {"preprocess": fuzz_preprocess, "template": fuzz_template, "collect": fuzz_collect, "reduce": fuzz_reduce, "tokens": fuzz_tokens, "gather": fuzz_gather, "similarity": fuzz_similarity, "scores": fuzz_scores}
+for name, fn in FAMS.items():
+    if family in ("all", name):
+        fn()
+        print(name, "ok", flush=True)
