@@ -143,6 +143,13 @@ def _ptr(t: torch.Tensor | None):
     return _vp(t.data_ptr()) if t is not None and t.numel() > 0 else _vp(None)
 
 
+def _need_f32(what: str, *tensors):
+    """The encoder entry points take raw fp32 device pointers: refuse anything else instead of reinterpreting its bytes."""
+    for t in tensors:
+        if t is not None and (t.dtype != torch.float32 or not t.is_cuda):
+            raise TypeError(f"{what}: expected float32 tensors on a HIP device, got {t.dtype} on {t.device}")
+
+
 def _dtype_code(t: torch.Tensor) -> int:
     try:
         return _DTYPES[t.dtype]
@@ -451,6 +458,7 @@ def linear(x, w, bias=None, act=SL_ACT_NONE, residual=None, out=None, scatter=No
     row_offset)`` writes row r to (r // rpg) * group_stride + row_offset + r % rpg of ``out`` (+ ``rowadd`` rows)."""
     M, K = x.shape
     Nn = w.shape[0]
+    _need_f32("linear", x, w, bias, residual, out, rowadd)
     if out is None:
         out = torch.empty((M, Nn), dtype=torch.float32, device=x.device)
     rpg, gs, ro = scatter if scatter is not None else (0, 0, 0)
@@ -490,6 +498,7 @@ class Split:
 
     @classmethod
     def of(cls, x: torch.Tensor, row_scale: torch.Tensor | None = None) -> "Split":
+        _need_f32("Split.of", x, row_scale)
         x = x.contiguous()
         out = cls(x.shape[0], x.shape[1], x.device)
         with torch.cuda.device(x.device):
@@ -509,6 +518,7 @@ def linear3(x: Split, w: Split, bias=None, act=SL_ACT_NONE, residual=None, out=N
     M, K = x.shape
     Nn = w.shape[0]
     dev = x.buf.device
+    _need_f32("linear3", bias, residual, out, rowadd)
     if w.shape[1] != K:
         raise ValueError(f"linear3: x has {K} columns, w has {w.shape[1]}")
     if out is None and out_split is None:
@@ -523,6 +533,7 @@ def linear3(x: Split, w: Split, bias=None, act=SL_ACT_NONE, residual=None, out=N
 
 
 def layernorm(x, gamma, beta, eps, out=None, rows=None, x_row_stride=None, out_split: Split | None = None):
+    _need_f32("layernorm", x, gamma, beta, out)
     cols = x.shape[-1]
     rows = rows if rows is not None else x.numel() // cols
     xs = x_row_stride if x_row_stride is not None else cols
@@ -536,6 +547,7 @@ def layernorm(x, gamma, beta, eps, out=None, rows=None, x_row_stride=None, out_s
 
 
 def attention(qkv, B, T, H, head_dim, causal, out=None, out_split: Split | None = None):
+    _need_f32("attention", qkv, out)
     if out is None and out_split is None:
         out = torch.empty((B * T, H * head_dim), dtype=torch.float32, device=qkv.device)
     with torch.cuda.device(qkv.device):
@@ -548,6 +560,7 @@ def attention_pool(q, kv, B, T, H, head_dim, out=None):
     """One query per head against the keys / values of each image: ``q`` (H*head_dim) projected probe, ``kv`` (B*T, 2*W)
     rows ``[k | v]`` -> ``(B, W)``."""
     W = H * head_dim
+    _need_f32("attention_pool", q, kv, out)
     if out is None:
         out = torch.empty((B, W), dtype=torch.float32, device=kv.device)
     with torch.cuda.device(kv.device):
@@ -558,6 +571,7 @@ def attention_pool(q, kv, B, T, H, head_dim, out=None):
 
 def patchify(img, P, out=None, out_split: Split | None = None):
     B, C, Hi, Wi = img.shape
+    _need_f32("patchify", img, out)
     if out is None and out_split is None:
         out = torch.empty((B * (Hi // P) * (Wi // P), C * P * P), dtype=torch.float32, device=img.device)
     with torch.cuda.device(img.device):

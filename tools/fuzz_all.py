@@ -197,7 +197,53 @@ def fuzz_collect(n=150):
         assert np.array_equal(v, ref.vals) and np.array_equal(am.sample_ids.numpy(), ref.ids)
 
 
-FAMS = {"preprocess": fuzz_preprocess, "template": fuzz_template, "collect": fuzz_collect, "reduce": fuzz_reduce, "tokens": fuzz_tokens, "gather": fuzz_gather, "similarity": fuzz_similarity, "scores": fuzz_scores}
+def fuzz_encoder_ops(n=120):
+    """The towers' building blocks against torch in float64: odd M / N / K, every epilogue, any sequence length."""
+    import torch.nn.functional as Fn
+
+    for it in range(n):
+        M, Nn, K = int(rng.randint(1, 300)), int(rng.choice([1, 2, 7, 32, 33, 64, 100, 256, 260])), int(rng.choice([1, 5, 31, 32, 33, 64, 96, 200]))
+        act = int(rng.randint(4))
+        use_bias, use_res, f32 = bool(rng.randint(2)), bool(rng.randint(2)), bool(rng.randint(2))
+        print("linear", it, M, Nn, K, act, use_bias, use_res, "f32" if f32 else "bf16x3", flush=True)
+        x, w = torch.from_numpy(rng.randn(M, K).astype(np.float32)).to(DEV), torch.from_numpy((rng.randn(Nn, K) / np.sqrt(K)).astype(np.float32)).to(DEV)
+        b = torch.from_numpy(rng.randn(Nn).astype(np.float32)).to(DEV) if use_bias else None
+        r = torch.from_numpy(rng.randn(M, Nn).astype(np.float32)).to(DEV) if use_res else None
+        if f32:
+            got = N.linear(x, w, b, act, r)
+        else:
+            got = N.linear3(N.Split.of(x), N.Split.of(w), b, act, r)
+        sync()
+        y = x.double() @ w.double().T + (b.double() if b is not None else 0)
+        y = [y, Fn.gelu(y), y * torch.sigmoid(1.702 * y), Fn.gelu(y, approximate="tanh")][act]
+        if r is not None:
+            y = y + r.double()
+        tol = 2e-5 if f32 else 1e-4  # split-bf16 x3 drops the lo*lo term: 2^-16 relative per product
+        np.testing.assert_allclose(got.cpu().numpy(), y.float().cpu().numpy(), rtol=tol, atol=tol)
+    for it in range(n):
+        rows, cols = int(rng.randint(1, 200)), int(rng.choice([1, 3, 8, 31, 64, 100, 768, 1152]))
+        print("layernorm", it, rows, cols, flush=True)
+        x = torch.from_numpy(rng.randn(rows, cols).astype(np.float32) * 3 + 1).to(DEV)
+        g_, b_ = torch.from_numpy(rng.randn(cols).astype(np.float32)).to(DEV), torch.from_numpy(rng.randn(cols).astype(np.float32)).to(DEV)
+        got = N.layernorm(x, g_, b_, 1e-5)
+        sync()
+        want = Fn.layer_norm(x.double(), (cols,), g_.double(), b_.double(), 1e-5)
+        np.testing.assert_allclose(got.cpu().numpy(), want.float().cpu().numpy(), rtol=2e-5, atol=2e-5)
+    for it in range(n):
+        B, T, H = int(rng.randint(1, 5)), int(rng.choice([1, 2, 7, 31, 32, 33, 50, 77, 197, 257, 300])), int(rng.randint(1, 4))
+        hd = int(rng.choice([32, 64, 72, 80, 96, 128]))
+        causal = bool(rng.randint(2))
+        print("attention", it, B, T, H, hd, causal, flush=True)
+        W = H * hd
+        qkv = torch.from_numpy(rng.randn(B * T, 3 * W).astype(np.float32)).to(DEV)
+        got = N.attention(qkv, B, T, H, hd, causal)
+        sync()
+        q, k, v = (t.reshape(B, T, H, hd).transpose(1, 2).double() for t in qkv.split(W, dim=1))
+        want = Fn.scaled_dot_product_attention(q, k, v, is_causal=causal).transpose(1, 2).reshape(B * T, W)
+        np.testing.assert_allclose(got.cpu().numpy(), want.float().cpu().numpy(), rtol=3e-5, atol=3e-5)
+
+
+FAMS = {"encoder": fuzz_encoder_ops, "preprocess": fuzz_preprocess, "template": fuzz_template, "collect": fuzz_collect, "reduce": fuzz_reduce, "tokens": fuzz_tokens, "gather": fuzz_gather, "similarity": fuzz_similarity, "scores": fuzz_scores}
 for name, fn in FAMS.items():
     if family in ("all", name):
         fn()
