@@ -776,15 +776,16 @@ template <>
 __device__ inline float round_to_dtype<uint16_t>(float v) { return bf16_to_f32(f32_to_bf16_rne(v)); }
 
 // ---- colreduce: out[b][f] = op_t x[b][t][f], f contiguous ------------------------------------
-// One workgroup (4 waves) per (b, 256-float chunk of F); waves split T; LDS combine.
+// One workgroup (NW = 4 waves, or 16 when there are too few (b, chunk) tasks to fill the chip — small batches of long
+// token sequences) per (b, 256-float chunk of F); the waves split T; LDS combine.
 // Cache policy as in the row kernels (top of this file): tasks below `tail_from` (in memory order: b-major) stream with
 // nt, the rest use the default policy, and the walk starts at `tail_from` so that the bytes written last are read first.
-template <typename E, int OP>
-__global__ __launch_bounds__(256) void colreduce_kernel(const E* __restrict__ x, int64_t B, int T, int64_t F,
+template <typename E, int OP, int NW>
+__global__ __launch_bounds__(64 * NW) void colreduce_kernel(const E* __restrict__ x, int64_t B, int T, int64_t F,
                                                          int64_t sb, int64_t st, int t_begin, int t_end,
                                                          float denom, int64_t tail_from, uint16_t* __restrict__ cand,
                                                          float* __restrict__ outf) {
-  __shared__ float s_part[4][256];
+  __shared__ float s_part[NW][256];
   constexpr bool SUM = (OP == OP_SUM || OP == OP_ABSSUM);
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;
@@ -805,16 +806,16 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const E* __restrict__ x,
       auto ld = [&](const E* p) __attribute__((always_inline)) { return load4_as_f32<E, nt>(p); };
       int t = t_begin + w;
 #pragma unroll 1
-      for (; t + 28 < t_end; t += 32) {  // 8 loads in flight per lane
+      for (; t + 7 * NW < t_end; t += 8 * NW) {  // 8 loads in flight per lane
         float4 v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = ld(base + (int64_t)(t + 4 * j) * st);
+        for (int j = 0; j < 8; ++j) v[j] = ld(base + (int64_t)(t + NW * j) * st);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           a0.add(v[j].x, true); a1.add(v[j].y, true); a2.add(v[j].z, true); a3.add(v[j].w, true);
         }
       }
-      for (; t < t_end; t += 4) {
+      for (; t < t_end; t += NW) {
         float4 v = ld(base + (int64_t)t * st);
         a0.add(v.x, true); a1.add(v.y, true); a2.add(v.z, true); a3.add(v.w, true);
       }
@@ -828,14 +829,13 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const E* __restrict__ x,
     s_part[w][lane * 4 + 2] = a2.lane_value();
     s_part[w][lane * 4 + 3] = a3.lane_value();
     __syncthreads();
-    {
+    if (threadIdx.x < 256) {
       const int f = threadIdx.x;  // 256 threads -> 256 features of the chunk
       const int64_t fg = (task % nchunk) * 256 + f;
       if (fg < F) {
         float r = s_part[0][f];
-        r = combine<SUM>(r, s_part[1][f]);
-        r = combine<SUM>(r, s_part[2][f]);
-        r = combine<SUM>(r, s_part[3][f]);
+#pragma unroll
+        for (int i = 1; i < NW; ++i) r = combine<SUM>(r, s_part[i][f]);
         r = round_to_dtype<E>(finish<OP>(r, denom));  // the reference aggregates in the activation's dtype
         store_outputs(r, b * F + fg, cand, outf);
       }
@@ -1116,8 +1116,12 @@ void launch_colreduce(ProfScope& prof, const T* x, int64_t B, int T_, int64_t F,
   const int64_t nchunk = (F + 255) / 256, per_b = (int64_t)T_ * F * (int64_t)sizeof(T), bytes = B * per_b;
   int64_t tail_from = 0;  // everything with the default policy
   if (bytes >= nt_min_bytes) tail_from = tail_bytes > 0 ? (bytes > tail_bytes ? (bytes - tail_bytes) / per_b * nchunk : 0) : INT64_MAX;
-  SL_LAUNCH(prof, (colreduce_kernel<T, OP>), dim3((unsigned)blocks), dim3(256), 0, st, x, B, T_, F, sb, st_, t0, t1, denom,
-            tail_from, cand, outf);
+  if (B * nchunk < 2 * (int64_t)num_cus() && t1 - t0 >= 128)  // too few tasks for 4-wave workgroups: 16 waves split T
+    SL_LAUNCH(prof, (colreduce_kernel<T, OP, 16>), dim3((unsigned)blocks), dim3(1024), 0, st, x, B, T_, F, sb, st_, t0, t1, denom,
+              tail_from, cand, outf);
+  else
+    SL_LAUNCH(prof, (colreduce_kernel<T, OP, 4>), dim3((unsigned)blocks), dim3(256), 0, st, x, B, T_, F, sb, st_, t0, t1, denom,
+              tail_from, cand, outf);
 }
 
 template <typename T, int G, int U, int J, int OP, bool ALIGNED>
