@@ -598,3 +598,36 @@ def test_setup_colored_logging_levels_env_and_file(monkeypatch, tmp_path, caplog
     for h in list(logger.handlers):
         logger.removeHandler(h)
     logger.addHandler(logging.NullHandler())
+
+
+def test_flatten_spatial_never_uses_the_stride_of_a_size_one_dimension():
+    """Host half of K1: (B,C,H,W) -> (sb, sc, ss) of the (B,C,H*W) view.  torch keeps an arbitrary stride for a size-1
+    dimension (a transposed (B,C,1,W) is "contiguous" with stride 8 on its last axis); using it gave wrong maxima."""
+    from semanticlens_amd._native import _flatten_spatial
+
+    def walk(x):
+        v, sb, sc, ss = _flatten_spatial(x)
+        B, C, H, W = x.shape
+        flat = v.as_strided((B, C, H * W), (sb, sc, ss), v.storage_offset())
+        return flat
+
+    base = torch.arange(4 * 3 * 8, dtype=torch.float32).reshape(4, 3, 1, 8)
+    for x in (base, base.transpose(2, 3), base.transpose(2, 3)[:, :, ::2], base[:, :, :, ::3],
+              torch.arange(2 * 3 * 4 * 5, dtype=torch.float32).reshape(2, 3, 4, 5).transpose(2, 3),
+              torch.arange(2 * 3 * 4 * 5, dtype=torch.float32).reshape(2, 3, 4, 5)[:, :, 1:3, 1:4],
+              torch.arange(2 * 3 * 4 * 5, dtype=torch.float32).reshape(2, 3, 4, 5).contiguous(memory_format=torch.channels_last)):
+        assert torch.equal(walk(x).amax(-1), x.amax((2, 3))), tuple(x.shape)
+
+
+def test_pinned_stack_falls_back_to_default_collate_without_a_device():
+    from semanticlens_amd.component_visualization._prefetch import PinnedStack
+
+    stack = PinnedStack()
+    batch = [(torch.full((2, 3), float(i)), i) for i in range(5)]
+    out = stack(batch)
+    if not torch.cuda.is_available():
+        assert stack.last_slot == -1
+    assert out.shape == (5, 2, 3) and torch.equal(out[:, 0, 0], torch.arange(5.0))
+    ragged = [(torch.zeros(2), 0), (torch.zeros(3), 1)]
+    with pytest.raises(RuntimeError):
+        stack(ragged)  # default_collate's own error, as in the reference
