@@ -530,6 +530,9 @@ __global__ __launch_bounds__(256) void rowreduce_fast_kernel(const float* __rest
 #ifndef SL_REDUCE_LAB_TAIL_FIRST
 #define SL_REDUCE_LAB_TAIL_FIRST 1
 #endif
+#ifndef SL_REDUCE_LAB_ROT_MB
+#define SL_REDUCE_LAB_ROT_MB 0  // lab only: inputs read entirely with the default policy start this many MiB before their end
+#endif
 constexpr int kDmaMaxBatch = 4096;  // bytes: four 1-KiB LDS-DMA instructions
 constexpr int kDmaDepth = 2;        // slots per wave: one batch in flight while one is reduced
 constexpr int kDmaLdsPerCu = 160 * 1024;
@@ -615,6 +618,10 @@ __global__ __launch_bounds__(256) void rowreduce_dma_kernel(const float* __restr
   const int nfull = full * nwaves32;                   // whole batches
   int rot = 0;
   if (SL_REDUCE_LAB_TAIL_FIRST && tail32 > rem && tail32 < ntask32) rot = (tail32 - rem) / U;
+  if (SL_REDUCE_LAB_ROT_MB > 0 && tail32 == 0) {
+    const int back = (int)(((int64_t)SL_REDUCE_LAB_ROT_MB << 20) / ((int64_t)U * task_bytes));
+    rot = back < nfull ? nfull - back : 0;
+  }
   const int nmine = full + ((int64_t)w0 * u_last < rem ? 1 : 0);
   auto work_of = [&](int it, int& t0, int& n) __attribute__((always_inline)) {
     if (it < full) {

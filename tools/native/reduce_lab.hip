@@ -67,6 +67,38 @@ static void fixed_mode(const std::vector<float*>& bufs, uint16_t* cand) {
   }
 }
 
+// producer variants behind which K1 runs with the DEFAULT policy: what the ~1.8 us in-pipeline penalty of the two
+// cache-resident inputs belongs to
+static void producer_mode(const std::vector<float*>& bufs, uint16_t* cand) {
+  const Shape shapes[] = {{256, 1024, 196}, {256, 2048, 49}};
+  const char* names[] = {"no producer (cold, policy all-nt)", "relu on the SAME buffer (the pipeline)", "relu on ANOTHER buffer (dirty caches, cold input)",
+                         "relu on the same buffer, then an empty kernel"};
+  for (int variant = 0; variant < 4; ++variant) {
+    sl_set_reduce_policy(variant == 0 || variant == 2 ? 0 : -1, variant == 0 || variant == 2 ? 0 : -1);
+    printf("%-52s", names[variant]);
+    for (const Shape& s : shapes) {
+      const int64_t n = s.B * s.C * s.S, bytes = n * 4;
+      sl_prof_enable(1);
+      sl_prof_reset();
+      for (int i = 0; i < 16; ++i) {
+        float* x = bufs[i % bufs.size()];
+        float* other = bufs[(i + 2) % bufs.size()];
+        const dim3 grid((unsigned)((n / 4 + 1023) / 1024));
+        if (variant == 1 || variant == 3) hipLaunchKernelGGL(relu_inplace_kernel, grid, dim3(256), 0, nullptr, (float4*)x, n / 4);
+        if (variant == 2) hipLaunchKernelGGL(relu_inplace_kernel, grid, dim3(256), 0, nullptr, (float4*)other, n / 4);
+        if (variant == 3) hipLaunchKernelGGL(null_kernel, dim3(256), dim3(256), 0, nullptr, (float*)nullptr);
+        sl_reduce_conv(x, SL_F32, s.B, s.C, s.S, s.C * s.S, s.S, 1, SL_CONV_MAX, cand, nullptr, nullptr);
+      }
+      double ms = 0, work = 0; int64_t nl = 0;
+      sl_prof_read(SL_PROF_REDUCE, &ms, &nl, &work);
+      sl_prof_enable(0);
+      printf("  %4.0f MB: %6.2f us %5.0f GB/s", bytes / 1e6, ms / nl * 1e3, bytes * (double)nl / ms / 1e6);
+    }
+    printf("\n");
+  }
+  sl_set_reduce_policy(-1, -1);
+}
+
 static void pipe_mode(const std::vector<float*>& bufs, uint16_t* cand) {
   const Shape shapes[] = {{256, 512, 784}, {256, 1024, 196}, {256, 2048, 49}};
   struct Pol { int64_t nt_min, tail; const char* name; };
@@ -113,6 +145,7 @@ int main(int argc, char** argv) {
   uint16_t* cand; CK(hipMalloc(&cand, 64 << 20));
   if (argc > 1 && !strcmp(argv[1], "pipe")) { pipe_mode(bufs, cand); return 0; }
   if (argc > 1 && !strcmp(argv[1], "fixed")) { fixed_mode(bufs, cand); return 0; }
+  if (argc > 1 && !strcmp(argv[1], "producer")) { producer_mode(bufs, cand); return 0; }
   sl_set_reduce_policy(0, 0);  // cold inputs: every byte with the streaming policy
   for (const Shape& s : shapes) {
     const int64_t bytes = s.B * s.C * s.S * 4;
