@@ -204,3 +204,45 @@ def test_prefetch_on_and_off_build_the_same_concept_db(tmp_path):
         for name in ids:
             assert torch.equal(ids[name], outs[0][1][name])
             assert torch.equal(db[name], outs[0][0][name])
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("channels_last", [False, True])
+@pytest.mark.parametrize("agg_name", ["max", "mean"])
+def test_half_precision_model_through_the_hooks(dt, channels_last, agg_name):
+    """A model run in fp16 / bf16 (optionally channels_last): the hooked activations arrive in that dtype and take the
+    half-precision kernels.  The oracle is fed the SAME device activations (captured by a second hook), aggregated in
+    fp32 and rounded once to the activation dtype for the mean, as torch's `mean` of a half tensor does."""
+    import oracle
+
+    model = make_int_conv_model().to(DEV).to(dt)
+    if channels_last:
+        model = model.to(memory_format=torch.channels_last)
+    n, k, bs = 45, 7, 16
+    x = make_int_images(n, seed=13).to(dt)
+    ds = TensorPairDataset(x, name="half")
+    fn = aggregators.aggregate_conv_max if agg_name == "max" else aggregators.aggregate_conv_mean
+    cv = ActivationComponentVisualizer(model, ds, ds, ["0", "2"], num_samples=k, aggregate_fn=fn, cache_dir=None, tie_mode="aten")
+    raw = {"0": [], "2": []}
+    taps = [model[int(nm)].register_forward_hook(lambda m, i, o, nm=nm: raw[nm].append(o.detach().float().cpu().numpy())) for nm in raw]
+    try:
+        cv.run(batch_size=bs)
+    finally:
+        for h in taps:
+            h.remove()
+    for nm, c in (("0", 8), ("2", 16)):
+        ref = oracle.ActMaxOracle(k, c, oracle.MODE_ATEN)
+        start = 0
+        for a in raw[nm]:
+            v = oracle.agg_conv(a, agg_name)
+            if agg_name == "mean":
+                v = torch.from_numpy(v).to(dt).float().numpy()
+            ref.update(v, np.arange(start, start + a.shape[0]))
+            start += a.shape[0]
+        am = cv.actmax_cache.cache[nm]
+        if agg_name == "max":
+            assert np.array_equal(bits(am.activations), ref.vals), nm
+            assert np.array_equal(am.sample_ids.numpy(), ref.ids), nm
+        else:  # fp32 summation order differs: values within one ulp of the activation dtype
+            got, want = oracle.bf16_to_f32(bits(am.activations)), oracle.bf16_to_f32(ref.vals)
+            assert np.allclose(got, want, rtol=2.0 ** -7, atol=1e-6), nm
