@@ -42,17 +42,23 @@ __host__ __device__ inline size_t split_elems(int64_t R, int64_t K) { return (si
 __host__ __device__ inline int64_t split_pos(int64_t row, int64_t col, int64_t Kp) {
   return row * 2 * Kp + (col >> 5) * 64 + (col & 31);
 }
+// hi / lo halves of a split operand through gfx950's v_cvt_pk_bf16_f32 (round to nearest even, one instruction for two
+// values; the bit-twiddled f32_to_bf16_rne of common.hpp costs six each and stays where NaN bit patterns are part of the
+// contract: the top-k candidates).  Finite values convert identically.
+__device__ inline uint16_t bf16_bits_hw(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
 __device__ inline void store_split(float v, int64_t row, int64_t col, int64_t Kp, uint16_t* __restrict__ sp) {
-  const uint16_t h = f32_to_bf16_rne(v);
+  const __bf16 h = (__bf16)v;
   const int64_t p = split_pos(row, col, Kp);
-  sp[p] = h;
-  sp[p + 32] = f32_to_bf16_rne(v - bf16_to_f32(h));
+  sp[p] = __builtin_bit_cast(uint16_t, h);
+  sp[p + 32] = bf16_bits_hw(v - (float)h);
 }
 // four consecutive columns (col % 4 == 0): two 8-byte stores
 __device__ inline void store_split4(const float4 y, int64_t row, int64_t col, int64_t Kp, uint16_t* __restrict__ sp) {
-  const uint16_t h0 = f32_to_bf16_rne(y.x), h1 = f32_to_bf16_rne(y.y), h2 = f32_to_bf16_rne(y.z), h3 = f32_to_bf16_rne(y.w);
-  const uint16_t l0 = f32_to_bf16_rne(y.x - bf16_to_f32(h0)), l1 = f32_to_bf16_rne(y.y - bf16_to_f32(h1));
-  const uint16_t l2 = f32_to_bf16_rne(y.z - bf16_to_f32(h2)), l3 = f32_to_bf16_rne(y.w - bf16_to_f32(h3));
+  const __bf16 b0 = (__bf16)y.x, b1 = (__bf16)y.y, b2 = (__bf16)y.z, b3 = (__bf16)y.w;
+  const uint16_t h0 = __builtin_bit_cast(uint16_t, b0), h1 = __builtin_bit_cast(uint16_t, b1);
+  const uint16_t h2 = __builtin_bit_cast(uint16_t, b2), h3 = __builtin_bit_cast(uint16_t, b3);
+  const uint16_t l0 = bf16_bits_hw(y.x - (float)b0), l1 = bf16_bits_hw(y.y - (float)b1);
+  const uint16_t l2 = bf16_bits_hw(y.z - (float)b2), l3 = bf16_bits_hw(y.w - (float)b3);
   const int64_t p = split_pos(row, col, Kp);
   *reinterpret_cast<uint2*>(sp + p) = make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16));
   *reinterpret_cast<uint2*>(sp + p + 32) = make_uint2((uint32_t)l0 | ((uint32_t)l1 << 16), (uint32_t)l2 | ((uint32_t)l3 << 16));
