@@ -6,3 +6,5 @@ dev = torch.device("cuda:0")
 for i in range(4):
     r = bench.probing_leg(dev)
     print(i, round(r["roofline"]["achieved"],1), round(r["roofline"]["frac"],3), round(r["fp32_mfma_mode"]["roofline"]["frac"],3), round(r["value"]), flush=True)
+r = bench.probing_leg(dev)
+print("f32 mode Msim/s", round(r["fp32_mfma_mode"]["value"]), "wall ms", round(r["fp32_mfma_mode"]["wall_ms"], 3), "| bf16x3 wall ms", round(r["wall_ms"], 3))
