@@ -177,38 +177,6 @@ void set_gemm_mode(int m) { g_gemm_mode = m; }
 // bytes of split-bf16 scratch for an (R x K) operand: hi + lo
 size_t split_bytes(int64_t R, int64_t K) { return align256_(gemm3::split_elems(R, K) * 2); }
 
-// out[M][N] = cos(A rows, B rows).  ra/rb: scratch for the inverse norms; split: scratch of
-// split_bytes(M,K) + split_bytes(N,K) bytes (may be NULL -> fp32 path).  Used by K6 and K8.
-int cosine_matrix_nt(const float* A, int64_t M, const float* B, int64_t N, int64_t K, float* ra, float* rb, float* out,
-                     void* split, hipStream_t st) {
-  if (int rc = launch_inv_norm(A, M, K, 1e-12f, ra, st)) return rc;
-  const bool same = (B == A && N == M);
-  if (same) {
-    rb = ra;
-  } else if (int rc = launch_inv_norm(B, N, K, 1e-12f, rb, st)) {
-    return rc;
-  }
-  // below K = 64 too few products average the ~2^-16 split error down; those GEMMs are tiny anyway
-  if (split && use_bf16x3() && K >= 64) {
-    unsigned char* p = (unsigned char*)split;
-    uint16_t* as = (uint16_t*)p;
-    uint16_t* bs = as;
-    if (int rc = gemm3::launch_split(A, ra, M, K, as, st)) return rc;  // x_hat = x * rinv, then the split matrix
-    if (!same) {
-      bs = (uint16_t*)(p + split_bytes(M, K));
-      if (int rc = gemm3::launch_split(B, rb, N, K, bs, st)) return rc;
-    }
-    ProfScope prof(SL_PROF_GEMM, st, 2.0 * (double)M * (double)N * (double)K);
-    return gemm3::launch_gemm3_nt(prof, as, M, bs, N, K, PlainEpi{out, N}, st);
-  }
-  ProfScope prof(SL_PROF_GEMM, st, 2.0 * (double)M * (double)N * (double)K);
-  return gemm::launch_gemm_nt(prof, A, M, B, N, K, CosineEpi{ra, rb, out, N}, st);
-}
-
-size_t cosine_split_bytes(int64_t M, int64_t N, int64_t K) { return split_bytes(M, K) + split_bytes(N, K); }
-
-// One query matrix against L concept matrices (the per-layer loop of lens.py:206-214): the query is
-// normalised and split once, each layer then costs its own split + one GEMM.
 // rows of up to kMaxFusedLayers matrices -> their rows of ONE split operand, L2-normalised on the way: the inverse norm
 // (the arithmetic of row_inv_norm_kernel: lane-strided squares, xor-shuffle tree) and the scaled hi / lo halves in one
 // pass over HBM — the row is read a second time out of L2.  Replaces one row_inv_norm + one split launch per matrix
@@ -289,6 +257,44 @@ int launch_norm_split(const RowSources& src, int64_t K, float eps, uint16_t* sp,
   return 0;
 }
 
+// out[M][N] = cos(A rows, B rows).  ra/rb: scratch for the inverse norms; split: scratch of
+// split_bytes(M,K) + split_bytes(N,K) bytes (may be NULL -> fp32 path).  Used by K6 and K8.
+int cosine_matrix_nt(const float* A, int64_t M, const float* B, int64_t N, int64_t K, float* ra, float* rb, float* out,
+                     void* split, hipStream_t st) {
+  const bool same = (B == A && N == M);
+  // below K = 64 too few products average the ~2^-16 split error down; those GEMMs are tiny anyway
+  if (split && use_bf16x3() && K >= 64) {
+    unsigned char* p = (unsigned char*)split;
+    uint16_t* as = (uint16_t*)p;
+    uint16_t* bs = as;
+    RowSources src{};
+    src.ptr[0] = A;
+    src.start[1] = M;
+    src.n = 1;
+    if (int rc = launch_norm_split(src, K, 1e-12f, as, st)) return rc;  // x_hat = x * rinv, then the split matrix
+    if (!same) {
+      bs = (uint16_t*)(p + split_bytes(M, K));
+      src.ptr[0] = B;
+      src.start[1] = N;
+      if (int rc = launch_norm_split(src, K, 1e-12f, bs, st)) return rc;
+    }
+    ProfScope prof(SL_PROF_GEMM, st, 2.0 * (double)M * (double)N * (double)K);
+    return gemm3::launch_gemm3_nt(prof, as, M, bs, N, K, PlainEpi{out, N}, st);
+  }
+  if (int rc = launch_inv_norm(A, M, K, 1e-12f, ra, st)) return rc;
+  if (same) {
+    rb = ra;
+  } else if (int rc = launch_inv_norm(B, N, K, 1e-12f, rb, st)) {
+    return rc;
+  }
+  ProfScope prof(SL_PROF_GEMM, st, 2.0 * (double)M * (double)N * (double)K);
+  return gemm::launch_gemm_nt(prof, A, M, B, N, K, CosineEpi{ra, rb, out, N}, st);
+}
+
+size_t cosine_split_bytes(int64_t M, int64_t N, int64_t K) { return split_bytes(M, K) + split_bytes(N, K); }
+
+// One query matrix against L concept matrices (the per-layer loop of lens.py:206-214): the query is
+// normalised and split once, each layer then costs its own split + one GEMM.
 int cosine_matrix_multi(const float* X, int64_t Q, int64_t K, const float* const* Ys, const int64_t* Cs, int L,
                         float* const* outs, unsigned char* ws, hipStream_t st) {
   int64_t cmax = 0, csum = 0;
