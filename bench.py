@@ -68,7 +68,8 @@ def parse():
     ap.add_argument("--no-api-leg", action="store_true")
     ap.add_argument("--no-channels-last", action="store_true")
     ap.add_argument("--min-warmup-seconds", type=float, default=1.5,
-                    help="after the first --warmup job, repeat it until this much wall time has passed (0: exactly --warmup steps)")
+                    help="after the first --warmup job, repeat it for at least this long and until it runs at a settled speed, at most "
+                         "ten times as long (0: exactly --warmup steps)")
     ap.add_argument("--api-images", type=int, default=8192,
                     help="raw 500x375 images of the API-path leg (9.5 GB of host memory at 8192; at 2048 the pipeline's fill and the "
                          "final device-to-host copy of the concept DB cost 12 %% of the run)")
@@ -498,9 +499,9 @@ def main():
                 t_warm = time.perf_counter()
             spent = time.perf_counter() - t_warm
             # settled = the last two jobs ran within 3 % of the fastest one seen (a box that has just started can run the
-            # first ten seconds of a process 10 % slow: 5 250 vs 5 850 images/s); give up waiting after 15 s
+            # first ten seconds of a process 10 % slow: 5 250 vs 5 850 images/s); give up waiting after ten times --min-warmup-seconds (15 s)
             settled = len(job_times) >= 3 and max(job_times[-2:]) <= 1.03 * min(job_times[1:])
-            more = 1.0 if spent < args.min_warmup_seconds or (not settled and spent < 15.0) else 0.0
+            more = 1.0 if spent < args.min_warmup_seconds or (not settled and spent < 10.0 * args.min_warmup_seconds) else 0.0
             if world > 1:
                 t = torch.tensor([more], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)

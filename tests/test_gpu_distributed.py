@@ -138,11 +138,11 @@ def _bench_line(extra_env, args, nproc):
 def test_bench_two_ranks_sharing_one_gpu_over_gloo():
     """BASELINE configs[2] code path (`bench.py --gpus N`): per-rank collect, packed all-gather, K4 merge, sharded K5
     gather + all-reduce, max-over-ranks timing — with two ranks on ONE GPU and gloo as the transport."""
-    line = _bench_line({"SL_BENCH_BACKEND": "gloo", "SL_BENCH_SHARE_GPU": "1"}, ["--steps", "3", "--warmup", "1", "--batch", "64"], 2)
+    line = _bench_line({"SL_BENCH_BACKEND": "gloo", "SL_BENCH_SHARE_GPU": "1"}, ["--steps", "3", "--warmup", "1", "--batch", "64", "--min-warmup-seconds", "0.3"], 2)
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
     assert line["config"]["images_total"] == 2 * 3 * 64 and line["value"] > 0
     line = _bench_line({"SL_BENCH_BACKEND": "gloo", "SL_BENCH_SHARE_GPU": "1"},
-                       ["--scaling", "strong", "--images", "500", "--warmup", "1", "--batch", "64"], 2)
+                       ["--scaling", "strong", "--images", "500", "--warmup", "1", "--batch", "64", "--min-warmup-seconds", "0"], 2)
     assert line["scaling"] == "strong" and line["config"]["images_total"] == 500 and line["steps"] == 4
 
 
