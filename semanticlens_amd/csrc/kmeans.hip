@@ -832,6 +832,7 @@ SL_API int sl_polykmeans(const float* d_V, int64_t C, int64_t n, int64_t D, int 
   SL_REQUIRE(n >= n_clusters, "sl_polykmeans: n_samples=%lld should be >= n_clusters=%d.", (long long)n, n_clusters);  // sklearn's ValueError
   SL_REQUIRE(n <= kMaxNGeneral, "sl_polykmeans: n_samples=%lld exceeds the supported maximum %d", (long long)n, kMaxNGeneral);
   SL_REQUIRE(n_init >= 1 && n_init <= 32, "sl_polykmeans: n_init=%d not in [1, 32]", n_init);
+  SL_REQUIRE(C <= 65535, "sl_polykmeans: %lld components in one call (the Gram kernel's grid holds 65535: split the call)", (long long)C);
   SL_REQUIRE(d_V && d_out && h_first_center && h_rand, "sl_polykmeans: null pointer");
   SL_REQUIRE(d_ws && ws_bytes >= sl_polykmeans_ws_bytes(C, n, D, n_clusters, n_init), "sl_polykmeans: workspace too small");
   hipStream_t st = (hipStream_t)stream;
