@@ -310,7 +310,32 @@ def gen_image_probes():
     save("image_probes", **out)
 
 
+def gen_scores_k():
+    """polysemanticity_score(n_clusters=k) of the reference for k != 2 (scores.py:132,167): random rows, three / four
+    well-separated blobs, rows with duplicated points (empty clusters, the < 2 samples fallback)."""
+    import warnings
+
+    g = torch.Generator().manual_seed(11)
+    P = torch.randn(14, 24, 32, generator=g)
+    cents = torch.randn(14, 4, 1, 32, generator=g) * 3
+    for i in range(4, 8):  # three blobs of 8
+        P[i] = torch.cat([cents[i, j] + 0.3 * torch.randn(8, 32, generator=g) for j in range(3)], 0)
+    for i in range(8, 11):  # four blobs of 6
+        P[i] = torch.cat([cents[i, j] + 0.3 * torch.randn(6, 32, generator=g) for j in range(4)], 0)
+    P[11, 4:] = P[11, 4:5]  # 4 distinct points + 20 copies
+    P[12] = P[12, :1]  # all identical
+    P[13, :12] = P[13, 0:1]
+    P[13, 12:] = P[13, 12:13]  # two exact groups
+    out = {"P": P.numpy()}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # sklearn's ConvergenceWarning on the degenerate rows
+        for k in (3, 4, 6):
+            out[f"poly_k{k}"] = ref_scores.polysemanticity_score(P, n_clusters=k).numpy()
+    save("scores_k", **out)
+
+
 GENERATORS = {
+    "scores_k": gen_scores_k,
     "known_answer": gen_known_answer,
     "streams": gen_streams,
     "aggregators": gen_aggregators,

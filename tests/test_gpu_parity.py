@@ -580,6 +580,15 @@ def test_polysemanticity_goldens(golden):
     assert scores.polysemanticity_score(torch.from_numpy(g["P10"])).device.type == "cpu"
 
 
+def test_polysemanticity_goldens_any_n_clusters(golden):
+    """n_clusters = 3 / 4 / 6 against outputs of the reference itself (tests/golden/scores_k.npz): random rows, three- and
+    four-blob rows, rows of duplicated points (empty clusters relocated, the fallback branch)."""
+    g = golden("scores_k")
+    for k in (3, 4, 6):
+        got = scores.polysemanticity_score(torch.from_numpy(g["P"]).to(DEV), n_clusters=k)
+        np.testing.assert_allclose(got.cpu().numpy(), g[f"poly_k{k}"], rtol=0, atol=1e-5)
+
+
 def assert_polysemanticity_matches(got, V, tag="", n_clusters=2):
     """Every component must reproduce scikit-learn's clustering — no tolerated minority.
 
