@@ -334,7 +334,34 @@ def gen_scores_k():
     save("scores_k", **out)
 
 
+def gen_aggregators_half():
+    """The reference's aggregators on fp16 / bf16 activations (half-precision models): what dtype comes back and how the
+    means are rounded (torch reduces in fp32 and rounds once to the tensor's dtype)."""
+    g = torch.Generator().manual_seed(23)
+    out = {}
+    x4 = {"h4a": torch.randn(3, 5, 7, 7, generator=g), "h4b": torch.randn(2, 8, 14, 14, generator=g) * 4,
+          "h4c": torch.randn(2, 6, 28, 28, generator=g).relu()}
+    x3 = {"h3a": torch.randn(2, 50, 24, generator=g), "h3b": torch.randn(3, 197, 16, generator=g) * 3}
+    for dname, dt in (("f16", torch.float16), ("bf16", torch.bfloat16)):
+        for tag, x in x4.items():
+            xh = x.to(dt)
+            out[f"{tag}_{dname}"] = xh.float().numpy()  # the rounded input, exactly representable
+            for fn in ("aggregate_conv_mean", "aggregate_conv_max"):
+                r = getattr(ref_agg, fn)(xh)
+                assert r.dtype == dt
+                out[f"{tag}_{dname}_{fn}"] = r.float().numpy()
+        for tag, x in x3.items():
+            xh = x.to(dt)
+            out[f"{tag}_{dname}"] = xh.float().numpy()
+            for fn in ("aggregate_transformer_mean", "aggregate_transformer_absmean", "aggregate_transformer_max", "aggregate_transformer_absmax"):
+                r = getattr(ref_agg, fn)(xh)
+                assert r.dtype == dt
+                out[f"{tag}_{dname}_{fn}"] = r.float().numpy()
+    save("aggregators_half", **out)
+
+
 GENERATORS = {
+    "aggregators_half": gen_aggregators_half,
     "scores_k": gen_scores_k,
     "known_answer": gen_known_answer,
     "streams": gen_streams,

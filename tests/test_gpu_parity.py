@@ -745,3 +745,29 @@ torch.save(outs, sys.argv[1])
         f32[tile] = torch.load(out)
     for a, b in zip(f32["128"], f32["8"]):
         assert torch.equal(a, b), ("f32", tuple(a.shape))
+
+
+def test_aggregator_goldens_half_precision(golden):
+    """The reference's own outputs on fp16 / bf16 activations (tests/golden/aggregators_half.npz, CPU torch): result dtype =
+    activation dtype; max / absmax exact; means within one ulp of that dtype (fp32 summation order differs)."""
+    g = golden("aggregators_half")
+    for dname, dt, ulp in (("f16", torch.float16, 2.0 ** -10), ("bf16", torch.bfloat16, 2.0 ** -7)):
+        for tag in ("h4a", "h4b", "h4c"):
+            x = torch.from_numpy(g[f"{tag}_{dname}"]).to(dt).to(DEV)
+            for layout in (x, x.contiguous(memory_format=torch.channels_last)):
+                got = agg.aggregate_conv_max(layout)
+                assert got.dtype == dt and got.device.type == "cpu"
+                assert feq(got.float().numpy(), g[f"{tag}_{dname}_aggregate_conv_max"])
+                got = agg.aggregate_conv_mean(layout)
+                assert got.dtype == dt
+                np.testing.assert_allclose(got.float().numpy(), g[f"{tag}_{dname}_aggregate_conv_mean"], rtol=ulp, atol=1e-6)
+        for tag in ("h3a", "h3b"):
+            x = torch.from_numpy(g[f"{tag}_{dname}"]).to(dt).to(DEV)
+            for fn in ("aggregate_transformer_max", "aggregate_transformer_absmax"):
+                got = getattr(agg, fn)(x)
+                assert got.dtype == dt
+                assert feq(got.float().numpy(), g[f"{tag}_{dname}_{fn}"]), (tag, dname, fn)
+            for fn in ("aggregate_transformer_mean", "aggregate_transformer_absmean"):
+                got = getattr(agg, fn)(x)
+                assert got.dtype == dt
+                np.testing.assert_allclose(got.float().numpy(), g[f"{tag}_{dname}_{fn}"], rtol=ulp, atol=1e-6, err_msg=f"{tag} {dname} {fn}")
