@@ -867,6 +867,8 @@ __global__ __launch_bounds__(256) void rowreduce_h_kernel(const T* __restrict__ 
   constexpr bool SUMOP = (OP == OP_SUM || OP == OP_ABSSUM);
   constexpr bool ABS = (OP == OP_ABSMAX || OP == OP_ABSSUM);
   const float fill = SUMOP ? 0.f : -__builtin_huge_valf();
+  // the same value as a pair of raw elements (-inf is 0xFF80 in bf16, 0xFC00 in fp16)
+  const uint32_t fillw = SUMOP ? 0u : (std::is_same<T, uint16_t>::value ? 0xFF80FF80u : 0xFC00FC00u);
   const int lane = threadIdx.x & 63;
   const int li = lane & (G - 1);
   const int g = lane / G;
@@ -884,6 +886,7 @@ __global__ __launch_bounds__(256) void rowreduce_h_kernel(const T* __restrict__ 
     int h[U], np[U];
     const u32x4* rp[U];
     float m[U], sum[U];
+    f32x2 sum2[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       row[u] = (batch * U + u) * RPW + g;
@@ -894,6 +897,7 @@ __global__ __launch_bounds__(256) void rowreduce_h_kernel(const T* __restrict__ 
       rp[u] = xp + (e0 >> 3);
       m[u] = fill;
       sum[u] = 0.f;
+      sum2[u] = f32x2{0.f, 0.f};
     }
     auto walk = [&](auto NT) __attribute__((always_inline)) {
       constexpr bool nt = decltype(NT)::value;
@@ -904,7 +908,7 @@ __global__ __launch_bounds__(256) void rowreduce_h_kernel(const T* __restrict__ 
 #pragma unroll
           for (int j = 0; j < J; ++j) {
             const int q = q0 + j * G + li;
-            w[u][j] = u32x4{0u, 0u, 0u, 0u};
+            w[u][j] = u32x4{fillw, fillw, fillw, fillw};  // lanes without a piece contribute the fill value
             if (q < np[u]) {
               if constexpr (nt) w[u][j] = __builtin_nontemporal_load(rp[u] + q);
               else w[u][j] = rp[u][q];
@@ -921,16 +925,21 @@ __global__ __launch_bounds__(256) void rowreduce_h_kernel(const T* __restrict__ 
             for (int d = 0; d < 4; ++d) {
               float e[2];
               unpack2<T>(w[u][j][d], e[0], e[1]);
+              if constexpr (ALIGNED) {  // whole pieces: two elements per v_max3 / v_pk_add
+                if constexpr (ABS) {
+                  e[0] = __builtin_fabsf(e[0]);
+                  e[1] = __builtin_fabsf(e[1]);
+                }
+                if constexpr (!SUMOP) m[u] = v_max3(m[u], e[0], e[1]);
+                sum2[u] += f32x2{e[0], e[1]};  // the sum, or the NaN detector of the max
+              } else {
 #pragma unroll
-              for (int k = 0; k < 2; ++k) {
-                float v = ABS ? __builtin_fabsf(e[k]) : e[k];
-                const bool valid = ALIGNED ? in : (in && (unsigned)(idx0 + 2 * d + k) < (unsigned)S);
-                v = valid ? v : fill;
-                if constexpr (SUMOP) {
-                  sum[u] += v;
-                } else {
-                  m[u] = __builtin_fmaxf(m[u], v);
-                  sum[u] += v;  // NaN detector only
+                for (int k = 0; k < 2; ++k) {
+                  float v = ABS ? __builtin_fabsf(e[k]) : e[k];
+                  const bool valid = in && (unsigned)(idx0 + 2 * d + k) < (unsigned)S;
+                  v = valid ? v : fill;
+                  if constexpr (!SUMOP) m[u] = __builtin_fmaxf(m[u], v);
+                  sum[u] += v;  // the sum, or the NaN detector of the max
                 }
               }
             }
@@ -942,6 +951,7 @@ __global__ __launch_bounds__(256) void rowreduce_h_kernel(const T* __restrict__ 
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const bool ok = row[u] < R;
+      if constexpr (ALIGNED) sum[u] = sum2[u][0] + sum2[u][1];
       float r;
       if constexpr (SUMOP) {
         r = group_allreduce_f<G, true>(sum[u]);

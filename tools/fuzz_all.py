@@ -65,7 +65,8 @@ def fuzz_reduce(n=300):
                 assert feq(got, want), (name, got, want)
             else:
                 assert np.array_equal(np.isnan(got), np.isnan(want))
-                tol = 2e-6 if dt == torch.float32 else (2.0 ** -9 if dt == torch.float16 else 2.0 ** -6)
+                # fp32: the strided (generic) kernel sums a row sequentially: ~sqrt(S) ulp
+                tol = 2e-5 if dt == torch.float32 else (2.0 ** -9 if dt == torch.float16 else 2.0 ** -6)
                 m = ~np.isnan(want)
                 np.testing.assert_allclose(got[m], want[m], rtol=tol, atol=1e-5)
 
