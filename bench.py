@@ -1,10 +1,11 @@
 """bench.py — concept-DB build throughput (BASELINE.json configs[1]) + text_probing, on N MI355X.
 
-    python bench.py --gpus 1 --steps 196 --warmup 3
+    python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A *step* is one pass of the hot path over one batch of B synthetic images already resident in HBM:
+A *step* is one pass of the hot path over `--batches-per-step` (10) batches of B = 256 synthetic images already resident
+in HBM — 2 560 images, so that the driver's `--steps 20` covers BASELINE configs[1]'s 50 000 images (51 200).  Per batch:
 ResNet-50 forward under the collect hooks (K1 reduce + K3 top-k merge for layer2/3/4) and the CLIP
 ViT-B/32 image encode of the same batch into the device-resident embedding table.  After the K timed
 steps the job is finished inside the timed region: pending merges are flushed, (N>1: per-rank
@@ -43,7 +44,8 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=196)  # 196 x 256 = 50,176 images (configs[1]: "50k")
+    ap.add_argument("--steps", type=int, default=20)  # 20 steps x 10 batches x 256 = 51,200 images (configs[1]: "50k")
+    ap.add_argument("--batches-per-step", type=int, default=10, help="batches of --batch images one step walks")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--k", type=int, default=20)  # num_samples; the reference tutorial's value
@@ -65,6 +67,9 @@ def parse():
                     help="keep only this many distinct batches resident and cycle through them (ids stay unique); 0 = every "
                          "batch distinct.  For dataset sizes whose uint8 pixels exceed HBM (1.28 M images = 193 GB)")
     ap.add_argument("--no-self-check", action="store_true")
+    ap.add_argument("--quick", action="store_true", help="headline + self-check only: none of the extra legs (tests)")
+    ap.add_argument("--no-tokens-leg", action="store_true")
+    ap.add_argument("--no-half-leg", action="store_true")
     ap.add_argument("--no-api-leg", action="store_true")
     ap.add_argument("--no-channels-last", action="store_true")
     ap.add_argument("--min-warmup-seconds", type=float, default=1.5,
@@ -86,10 +91,10 @@ class _Len:
         return self.n
 
 
-def make_cv(model, n_total, k, tie_mode):
+def make_cv(model, n_total, k, tie_mode, layers=None, agg=None):
     return ActivationComponentVisualizer(
-        model, _Len(n_total, f"synthetic-{n_total}"), _Len(n_total, "synthetic-fm"), LAYERS, num_samples=k,
-        aggregate_fn=aggregators.aggregate_conv_max, cache_dir=None, tie_mode=tie_mode,
+        model, _Len(n_total, f"synthetic-{n_total}"), _Len(n_total, "synthetic-fm"), list(layers or LAYERS), num_samples=k,
+        aggregate_fn=agg or aggregators.aggregate_conv_max, cache_dir=None, tie_mode=tie_mode,
     )
 
 
@@ -97,23 +102,28 @@ OVERLAP = True  # embed on a second HIP stream beside forward + collect (--no-ov
 
 
 @torch.no_grad()
-def run_steps(cv, fm, batches, id_start, n_local):
-    """The timed inner loop: K steps over device-resident uint8 batches."""
-    for name in LAYERS:
+def run_steps(cv, fm, batches, id_start, n_local, cast=None):
+    """The timed inner loop over device-resident uint8 batches (``cast``: dtype of a half-precision probed model)."""
+    for name in cv.layer_names:
         cv.actmax_cache.sample_idx_counter[name] = id_start
     embeds, filled = None, 0
     overlap = OVERLAP
     main = torch.cuda.current_stream()
     side = torch.cuda.Stream() if overlap else None
+
+    def model_input(u8):
+        x = synth.normalize_u8(u8, synth.IMAGENET_MEAN, synth.IMAGENET_STD)
+        return x if cast is None else x.to(cast)
+
     with cv.actmax_cache.hook_context(cv.model):
         for u8 in batches:
             if overlap:  # hot loop 2 (embed) on a second HIP stream beside hot loop 1 (forward + collect)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     embeds, filled = cv.embed_batch(fm, u8, embeds, filled, n_local)
-                cv.collect_batch(synth.normalize_u8(u8, synth.IMAGENET_MEAN, synth.IMAGENET_STD))
+                cv.collect_batch(model_input(u8))
             else:
-                cv.collect_batch(synth.normalize_u8(u8, synth.IMAGENET_MEAN, synth.IMAGENET_STD))
+                cv.collect_batch(model_input(u8))
                 embeds, filled = cv.embed_batch(fm, u8, embeds, filled, n_local)
     if overlap:
         main.wait_stream(side)
@@ -121,47 +131,58 @@ def run_steps(cv, fm, batches, id_start, n_local):
 
 
 @torch.no_grad()
-def finish_job(cv, embeds, id_start, n_total, world):
-    """Flush/merge the top-k states and gather the concept_db (device tensors)."""
-    if world > 1:
+def finish_job(cv, embeds, id_start, n_total, sharded):
+    """Flush/merge the top-k states and gather the concept_db (device tensors).  ``sharded``: a process group is up —
+    all-gather + K4 merge of the per-rank states, sharded K5 + all-reduce (also with ONE rank: SL_BENCH_FORCE_DIST)."""
+    if sharded:
         sld.merge_actmax_cache(cv.actmax_cache)
-        return {n: sld.gather_concept_db_sharded(embeds, id_start, n_total, cv.get_max_reference(n)) for n in LAYERS}
-    return {n: N.gather_rows(embeds, cv.actmax_cache.cache[n].device_state()[1]) for n in LAYERS}
+        return {n: sld.gather_concept_db_sharded(embeds, id_start, n_total, cv.get_max_reference(n)) for n in cv.layer_names}
+    return {n: N.gather_rows(embeds, cv.actmax_cache.cache[n].device_state()[1]) for n in cv.layer_names}
 
 
 @torch.no_grad()
-def self_check(dev, model, fm, args, n=512, B=256):
-    """What the timed region computes, checked against the oracle on a 512-image prefix (ids 0..511, two batches of the
+def self_check(dev, model, fm, args, n=512, B=256, layers=None, agg=None, cast=None):
+    """What the timed region computes, checked against the oracle on an n-image prefix (ids 0..n-1, batches of the
     bench's own size — other batch sizes would send MIOpen into a fresh kernel search): the SAME device activations go
     through (i) the product's hooks
-    (K1 reduce + K3 merge, the tie mode of the timed run) and (ii) the oracle's aggregate + ActMax restatement on the
+    (K1/K2 reduce + K3 merge, the tie mode of the timed run) and (ii) the oracle's aggregate + ActMax restatement on the
     host; top-k values and ids must be bit-equal, and the gathered concept_db (K5) must equal the oracle's gather of
     the device embeddings.  Raises on any difference."""
     import numpy as np
 
     import oracle  # the checker — never on the product path
 
-    cv = make_cv(model, n, args.k, args.tie_mode)
-    raw = {name: [] for name in LAYERS}
-    taps = [getattr(model, name).register_forward_hook(lambda m, i, o, name=name: raw[name].append(o.detach().cpu().numpy()))
-            for name in LAYERS]
-    batches = [synth.synth_images_u8(torch.arange(s, s + B, device=dev)) for s in range(0, n, B)]
+    layers = list(layers or LAYERS)
+    agg = agg or aggregators.aggregate_conv_max
+    tokens = agg._sl_native[0] == "tokens"
+    cv = make_cv(model, n, args.k, args.tie_mode, layers, agg)
+    mode = oracle.MODE_TOTAL if args.tie_mode == "total" else oracle.MODE_ATEN
+    refs, seen = {}, {name: 0 for name in layers}
+
+    def tap(name):
+        def fn(m, i, o):  # oracle side, streamed: aggregate on the host, merge into the oracle's state
+            act = o.detach().float().cpu().numpy()
+            a = oracle.agg_tokens(act, "max") if tokens else oracle.agg_conv(act, "max")
+            if name not in refs:
+                refs[name] = oracle.ActMaxOracle(args.k, a.shape[1], mode)
+            refs[name].update(a, np.arange(seen[name], seen[name] + a.shape[0]))
+            seen[name] += a.shape[0]
+
+        return fn
+
+    modules = dict(model.named_modules())
+    taps = [modules[name].register_forward_hook(tap(name)) for name in layers]
+    batches = [synth.synth_images_u8(torch.arange(s, min(n, s + B), device=dev)) for s in range(0, n, B)]
     try:
-        embeds = run_steps(cv, fm, batches, 0, n)
+        embeds = run_steps(cv, fm, batches, 0, n, cast)
     finally:
         for h in taps:
             h.remove()
-    db = finish_job(cv, embeds, 0, n, 1)
+    db = finish_job(cv, embeds, 0, n, False)
     torch.cuda.synchronize()
-    mode = oracle.MODE_TOTAL if args.tie_mode == "total" else oracle.MODE_ATEN
     emb_host = embeds.cpu().numpy()
-    for name in LAYERS:
-        ref = None
-        for step, act in enumerate(raw[name]):
-            a = oracle.agg_conv(act, "max")
-            if ref is None:
-                ref = oracle.ActMaxOracle(args.k, a.shape[1], mode)
-            ref.update(a, np.arange(step * B, step * B + a.shape[0]))
+    for name in layers:
+        ref = refs[name]
         am = cv.actmax_cache.cache[name]
         got_v = am.activations.view(torch.int16).numpy().view(np.uint16)
         if not np.array_equal(got_v, ref.vals):
@@ -345,8 +366,15 @@ def cpu_baseline(args, model_cpu, fm_cpu):
     for h in handles:
         h.remove()
     bytes_per_img = 2809856  # ResNet-50 layer2+3+4 fp32 activations per image
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = None
     return {
-        "value": n / dt, "unit": "images/s", "cores": threads, "kind": "port",
+        # `cores` = the threads the run USED (the fastest of 8/16/32/64/all on this box for the torch-CPU forward);
+        # `host_cores` = what the box has (logical CPUs / CPUs this process may run on)
+        "value": n / dt, "unit": "images/s", "cores": threads, "threads": threads, "host_cores": os.cpu_count(),
+        "host_cores_affinity": affinity, "kind": "port",
         "sample": f"{n} synthetic images (batch {B}), same models/layers/k, torch-CPU forward + oracle collect "
                   f"(ATen tie order) + CPU CLIP encode + gather; {dt:.1f} s",
         "collect_only_GBps": n * bytes_per_img / agg_s[0] / 1e9,
@@ -434,6 +462,38 @@ def probing_leg(dev):
     }
 
 
+def collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, cast=None, check_n=None):
+    """A short run of the same step on another probed model / aggregator / activation dtype, so that the reduce kernel that
+    configuration selects gets its own driver-measured roofline object (algorithmic bytes / per-dispatch HIP-event time, as
+    for the headline) and its own oracle self-check."""
+    warm = [synth.synth_images_u8(torch.arange(10**7 + i * B, 10**7 + (i + 1) * B, device=dev)) for i in range(2)]
+    cv_w = make_cv(model, 2 * B, args.k, args.tie_mode, layers, agg)
+    finish_job(cv_w, run_steps(cv_w, fm, warm, 0, 2 * B, cast), 0, 2 * B, False)  # MIOpen / hipBLASLt pick their kernels
+    batches = [synth.synth_images_u8(torch.arange(s * B, (s + 1) * B, device=dev)) for s in range(steps)]
+    n = steps * B
+    cv = make_cv(model, n, args.k, args.tie_mode, layers, agg)
+    N.prof_enable(True)
+    N.prof_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    finish_job(cv, run_steps(cv, fm, batches, 0, n, cast), 0, n, False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms, launches, nbytes = N.prof_read(N.SL_PROF_REDUCE)
+    N.prof_enable(False)
+    gbps = nbytes / ms / 1e6 if ms else None
+    out = {
+        "workload": workload, "images_per_s": n / dt, "steps": steps, "batch": B,
+        "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": gbps / HBM_PEAK_GBPS if gbps else None, "traffic": None, "kernel": kernel, "launches": launches,
+                     "avg_launch_us": ms / max(launches, 1) * 1e3, "algorithmic_bytes_per_launch": nbytes / max(launches, 1),
+                     "condition": "in-pipeline: inputs written by the model's last kernel microseconds earlier"},
+    }
+    if not args.no_self_check:
+        out["self_check"] = self_check(dev, model, fm, args, n=check_n or 2 * B, B=B, layers=layers, agg=agg, cast=cast)
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -442,12 +502,15 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     # SL_BENCH_BACKEND=gloo SL_BENCH_SHARE_GPU=1: debugging aid to exercise the N>1 code path with several
     # ranks on ONE GPU (collectives staged through the host); the driver's runs use nccl (RCCL), one GPU per rank.
+    # SL_BENCH_FORCE_DIST=1: bring the process group up even for ONE rank, so that a 1-GPU box runs the N>1 code
+    # (barriers, packed all-gather + K4, sharded K5 + all-reduce) over RCCL itself (tests/test_gpu_distributed.py).
     backend = os.environ.get("SL_BENCH_BACKEND", "nccl")
     if os.environ.get("SL_BENCH_SHARE_GPU") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded = world > 1 or os.environ.get("SL_BENCH_FORCE_DIST") == "1"
+    if sharded:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -456,15 +519,20 @@ def main():
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
     global OVERLAP
     OVERLAP = bool(args.overlap)
+    if args.quick:
+        args.no_api_leg = args.no_channels_last = args.no_probing = args.no_cpu_baseline = True
+        args.no_tokens_leg = args.no_half_leg = True
 
-    B, K, W = args.batch, args.steps, args.warmup
+    B, K, W, bps = args.batch, args.steps, args.warmup, max(1, args.batches_per_step)
     if args.scaling == "strong":  # fixed TOTAL work, contiguous shards (distributed.shard_range), ids global
-        n_total = args.images or K * B
+        n_total = args.images or K * bps * B
         id_start, id_stop = sld.shard_range(n_total, rank, world)
         n_local = id_stop - id_start
-        K = -(-n_local // B)
-    else:  # weak (the driver's contract): K batches per rank
-        n_local = K * B
+        n_batches = -(-n_local // B)
+        K = -(-n_batches // bps)
+    else:  # weak (the driver's contract): K steps of `bps` batches per rank
+        n_batches = K * bps
+        n_local = n_batches * B
         n_total = world * n_local
         id_start = rank * n_local
     model = synth.resnet50().to(dev)
@@ -477,21 +545,22 @@ def main():
     Lens(fm, device=dev)
 
     # ---- warm-up on throw-away state (MIOpen kernel selection, allocator, lazy kernel loads) ----
-    # The warm-up runs the complete job (incl. the RCCL collectives of finish_job) on W batches.
+    # The warm-up runs the complete job (incl. the RCCL collectives of finish_job) on W steps = W x bps batches.
     warm_steps_run = 0
     if W:
-        warm = [synth.synth_images_u8(torch.arange(10**7 + i * B, 10**7 + (i + 1) * B, device=dev)) for i in range(W)]
+        nw = W * bps
+        warm = [synth.synth_images_u8(torch.arange(10**7 + i * B, 10**7 + (i + 1) * B, device=dev)) for i in range(nw)]
         # The W-step warm-up job is repeated until `--min-warmup-seconds` of device work have passed (every rank runs the
         # same count: the decision is all-reduced).  On a fresh box the first process measured 8 % below the second with
-        # three warm-up steps only (5 423 vs 5 900 images/s): the part needs ~1 s of this load to settle, and MIOpen / the
-        # code-object loader still have first-use work after three steps.  The timed region is untouched: exactly K steps.
+        # three warm-up batches only (5 423 vs 5 900 images/s): the part needs ~1 s of this load to settle, and MIOpen / the
+        # code-object loader still have first-use work after three batches.  The timed region is untouched: exactly K steps.
         t_warm = None  # the clock starts after the first job: that one pays the one-time costs
         job_times = []
         while True:
-            warm_cv = make_cv(model, world * W * B, args.k, args.tie_mode)
+            warm_cv = make_cv(model, world * nw * B, args.k, args.tie_mode)
             t_job = time.perf_counter()
-            emb_w = run_steps(warm_cv, fm, warm, rank * W * B, W * B)
-            finish_job(warm_cv, emb_w, rank * W * B, world * W * B, world)
+            emb_w = run_steps(warm_cv, fm, warm, rank * nw * B, nw * B)
+            finish_job(warm_cv, emb_w, rank * nw * B, world * nw * B, sharded)
             torch.cuda.synchronize()
             job_times.append(time.perf_counter() - t_job)
             warm_steps_run += W
@@ -502,7 +571,7 @@ def main():
             # first ten seconds of a process 10 % slow: 5 250 vs 5 850 images/s); give up waiting after ten times --min-warmup-seconds (15 s)
             settled = len(job_times) >= 3 and max(job_times[-2:]) <= 1.03 * min(job_times[1:])
             more = 1.0 if spent < args.min_warmup_seconds or (not settled and spent < 10.0 * args.min_warmup_seconds) else 0.0
-            if world > 1:
+            if sharded:
                 t = torch.tensor([more], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 more = float(t.item())
@@ -514,10 +583,10 @@ def main():
     def batch_ids(s):
         return torch.arange(id_start + s * B, min(id_start + (s + 1) * B, id_start + n_local), device=dev)
 
-    pool = args.pool_batches if 0 < args.pool_batches < K else K
+    pool = args.pool_batches if 0 < args.pool_batches < n_batches else n_batches
     distinct = [synth.synth_images_u8(batch_ids(s)) for s in range(pool)]
-    if pool < K:  # cycle the resident pool; the last (possibly short) batch keeps its own size
-        batches = [distinct[s % pool][: batch_ids(s).numel()] for s in range(K)]
+    if pool < n_batches:  # cycle the resident pool; the last (possibly short) batch keeps its own size
+        batches = [distinct[s % pool][: batch_ids(s).numel()] for s in range(n_batches)]
     else:
         batches = distinct
 
@@ -528,13 +597,13 @@ def main():
         N.prof_enable(True)
         N.prof_reset()
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier()
         t0_ = time.perf_counter()
         embeds_ = run_steps(cv_, fm_used, batches, id_start, n_local)
-        db_ = finish_job(cv_, embeds_, id_start, n_total, world)
+        db_ = finish_job(cv_, embeds_, id_start, n_total, sharded)
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier()
         return time.perf_counter() - t0_, db_
 
@@ -543,7 +612,7 @@ def main():
     mrg_ms, mrg_n, _ = N.prof_read(N.SL_PROF_MERGE)
     gat_ms, gat_n, _ = N.prof_read(N.SL_PROF_GATHER)
     N.prof_enable(False)
-    if world > 1:
+    if sharded:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -551,7 +620,7 @@ def main():
     del concept_db
 
     if rank != 0:
-        if world > 1:
+        if sharded:
             dist.destroy_process_group()
         return
 
@@ -576,21 +645,24 @@ def main():
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
-        "dtype": "f32",
+        # the arithmetic type of the path: every activation, reduction, embedding and score is fp32; the encoder's GEMM operands
+        # are fp32 values carried as two bf16 halves (three MFMA products, fp32 accumulate: 8e-7 on cosines, tolerance 1e-4);
+        # `images_per_s_fp32_gemm` is the same job with no bf16 operand anywhere
+        "dtype": {"native": "f32 (encoder GEMMs split-bf16x3, fp32 accumulate)", "native-f32": "f32", "torch": "f32"}[args.fm],
         "data": "synthetic",
         "config": {
             "workload": "BASELINE configs[1]: ResNet-50 (random init) layer2-4, synthetic 224x224 images, "
                         "CLIP ViT-B/32 (random init) embed, aggregate_conv_max",
             "images_total": n_total, "images_per_gpu": n_local, "batch": B, "num_samples_k": args.k,
-            # configs[1] names 50k images: fewer steps measure the same per-step rate on a smaller embedding table and a
-            # top-k filter that has not reached its steady-state rejection rate
+            "batches_per_step": bps, "images_per_step": bps * B, "ms_per_batch": elapsed / n_batches * 1e3,
+            # configs[1] names 50k images
             "full_config_size": n_total >= 50000,
             "warmup_steps_run": warm_steps_run,  # --warmup repeated for --min-warmup-seconds; all untimed
             "distinct_resident_batches": pool,
             "tie_mode": args.tie_mode,
             "streams": 2 if args.overlap else 1, "layers": LAYERS, "parallelism": f"shard{world}" if world > 1 else "single",
             "collectives": "torch.distributed (RCCL): one all_gather_into_tensor of the packed top-k states + one "
-                           "all_reduce per layer of the sharded gather" if world > 1 else "none",
+                           "all_reduce per layer of the sharded gather" if sharded else "none",
             "clip_encoder": {"native": "NativeClip (HIP kernels, split-bf16 x3 GEMMs, fp32-class accuracy)",
                              "native-f32": "NativeClip (HIP kernels, fp32-input MFMA GEMMs)",
                              "torch": "torch module (hipBLASLt fp32)"}[args.fm],
@@ -614,50 +686,73 @@ def main():
             "collect_only_images_per_sec": n_local / ((red_ms + mrg_ms) / 1e3) if red_ms else None,
         },
     }
-    if world == 1 and not args.no_self_check:
+    single = world == 1
+    if single and not args.no_self_check:
         line["self_check"] = self_check(dev, model, fm, args)
-    if world == 1:
+    if single and not args.quick:
         line["roofline"]["cold_inputs"] = reduce_cold_leg(dev, B)
-    if world == 1 and args.fm == "native":
+    if single and args.fm == "native" and not args.quick:
         # the same job with every encoder GEMM on the fp32-input MFMA path (strict fp32 arithmetic end to end)
         from semanticlens_amd.foundation_models.native_clip import NativeClip
 
-        few = batches[: min(K, 24)]
+        few = batches[: min(n_batches, 24)]
         n_few = sum(b.shape[0] for b in few)
         dt32, _ = timed_job(NativeClip(fm_base, gemm="f32"), few, n_few, n_few)
         N.prof_enable(False)
-        line["images_per_s_fp32_gemm"] = {"value": n_few / dt32, "steps": len(few),
+        line["images_per_s_fp32_gemm"] = {"value": n_few / dt32, "batches": len(few),
                                           "note": "same step with NativeClip(gemm='f32'): no bf16 operand anywhere"}
-    if world == 1 and not args.no_channels_last:
+    if single and not args.no_channels_last:
         # the same job on a channels_last copy of the probed model: the hooked activations arrive component-contiguous and
         # K1 runs its column-reduce kernel instead of the row-reduce kernel of the headline
         import copy
 
         model_cl = copy.deepcopy(model).to(memory_format=torch.channels_last)
-        few = batches[: min(K, 24)]
+        few = batches[: min(n_batches, 24)]
         n_few = sum(b.shape[0] for b in few)
         timed_job(fm, few[:2], 2 * B, 2 * B, model_cl)  # MIOpen picks its NHWC kernels
         dtcl, _ = timed_job(fm, few, n_few, n_few, model_cl)
         cl_ms, cl_n, cl_bytes = N.prof_read(N.SL_PROF_REDUCE)
         N.prof_enable(False)
         line["channels_last"] = {
-            "images_per_s": n_few / dtcl, "steps": len(few),
+            "images_per_s": n_few / dtcl, "batches": len(few),
             "k1": {"kernel": "colreduce (K1, component axis contiguous)", "GB/s": cl_bytes / cl_ms / 1e6 if cl_ms else None,
                    "frac": cl_bytes / cl_ms / 1e6 / HBM_PEAK_GBPS if cl_ms else None, "launches": cl_n,
                    "avg_launch_us": cl_ms / max(cl_n, 1) * 1e3},
             "self_check": None if args.no_self_check else self_check(dev, model_cl, fm, args),
             "note": "same step with model.to(memory_format=torch.channels_last); not the headline (the reference's models run NCHW)"}
         del model_cl
-    if world == 1 and not args.no_api_leg:
+    if single and not args.no_half_leg:
+        # fp16 copy of the probed model: the hooked activations are fp16 NCHW rows -> rowreduce_h (K1 for 2-byte elements)
+        import copy
+
+        model_h = copy.deepcopy(model).half()
+        line["half_precision_model"] = collect_leg(
+            dev, fm, args, model_h, LAYERS, aggregators.aggregate_conv_max,
+            "rowreduce_h (K1 on fp16 NCHW activations: 16-byte pieces of 8 elements, fp32 compare, bf16 candidates)",
+            "configs[1] with the probed ResNet-50 in fp16 (model.half(), fp16 inputs): layer2-4 activations are fp16, "
+            "1 404 928 B/image", steps=min(n_batches, 16), B=B, cast=torch.float16)
+        del model_h
+    if single and not args.no_tokens_leg:
+        # BASELINE configs[3]'s collect stage: ViT-B/16 probed model, all 12 encoder blocks, token-max aggregator -> K2 (colreduce)
+        vit = synth.vit_b16().to(dev)
+        Bt = min(B, 128)
+        line["tokens_collect"] = collect_leg(
+            dev, fm, args, vit, [f"blocks.{i}" for i in range(12)], aggregators.aggregate_transformer_max,
+            "colreduce (K2, (B, 197, 768) token activations, component axis contiguous)",
+            "BASELINE configs[3] collect stage: ViT-B/16 (random init) probed model, all 12 encoder blocks (B,197,768) fp32, "
+            "aggregate_transformer_max, 7 262 208 B/image; embed = the headline's CLIP ViT-B/32", steps=min(n_batches, 12), B=Bt,
+            check_n=Bt)
+        del vit
+    if single and not args.no_api_leg:
         line["api_path"] = api_path_leg(dev, model, fm_base, args)
-    if world == 1 and not args.no_probing:
+    if single and not args.no_probing:
         line["text_probing"] = probing_leg(dev)
         line["text_probing"]["from_prompts"] = probing_end_to_end(fm, dev)
-    if world == 1 and not args.no_cpu_baseline:
+    if single and not args.no_cpu_baseline:
         torch.manual_seed(0)
         line["cpu_baseline"] = cpu_baseline(args, synth.resnet50(), synth.SyntheticClip(device="cpu"))
     print(json.dumps(line), flush=True)
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

@@ -413,8 +413,25 @@ def prof_read(family: int):
 POLY2_MAX_N = 128  # sl_poly2means keeps a component's state in LDS; larger n / other k: sl_polykmeans
 
 
+POLYK_MAX_N = 1024        # sl_polykmeans: samples per component (kMaxNGeneral in csrc/kmeans.hip)
+POLYK_MAX_CLUSTERS = 16   # sl_polykmeans: n_clusters (kMaxClusters)
+POLYK_MAX_COMPONENTS = 65535  # components per launch (grid.y of the Gram kernel)
+
+
+def _poly_ws_budget() -> int:
+    """Workspace bytes one K9 launch may take (default 8 GiB; ``SL_POLY_WS_GB``).  More components than fit run as
+    consecutive launches over component chunks — every component is independent, so the scores do not change."""
+    import os
+
+    return int(float(os.environ.get("SL_POLY_WS_GB", "8")) * (1 << 30))
+
+
 def poly2means(V: torch.Tensor, first_center, rand, replace_empty_clusters: bool = True, n_clusters: int = 2) -> torch.Tensor:
-    """polysemanticity of V (C,n,D): k-means per component on the device; float64 (C,) result."""
+    """polysemanticity of V (C,n,D): k-means per component on the device; float64 (C,) result.
+
+    Any number of components: calls are chunked by the Gram kernel's grid limit (65 535 components) and by the workspace
+    budget.  ``n_samples > 1024`` with ``n_clusters != 2`` (or > 128 samples), and ``n_clusters > 16``, raise
+    ``ValueError`` — limits the reference (scikit-learn on the host, scores.py:131-185) does not have."""
     import numpy as np
 
     Vd = _f32c(V)
@@ -426,27 +443,42 @@ def poly2means(V: torch.Tensor, first_center, rand, replace_empty_clusters: bool
     n_init = int(first_center.shape[0])
     out = torch.empty((C,), dtype=torch.float64, device=Vd.device)
     mincnt = torch.empty((C,), dtype=torch.int32, device=Vd.device)
-    if n_clusters != 2 or n > POLY2_MAX_N:
-        nbytes = int(lib().sl_polykmeans_ws_bytes(C, n, D, n_clusters, n_init))
-        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=Vd.device)
-        with torch.cuda.device(Vd.device):
-            rc = lib().sl_polykmeans(
-                _ptr(Vd), C, n, D, int(n_clusters), first_center.ctypes.data_as(_vp), n_init, rand.ctypes.data_as(_vp),
-                1 if replace_empty_clusters else 0, _ptr(out), _ptr(mincnt), _ptr(ws), nbytes, _stream(Vd),
-            )
-            torch.cuda.current_stream(Vd.device).synchronize()  # the draws were copied from host arrays owned by this call
-        _check(rc, "sl_polykmeans")
+    general = n_clusters != 2 or n > POLY2_MAX_N
+    if general:
+        if n_clusters > POLYK_MAX_CLUSTERS:
+            raise ValueError(f"n_clusters={n_clusters} exceeds the device kernel's maximum of {POLYK_MAX_CLUSTERS}")
+        if n > POLYK_MAX_N:
+            raise ValueError(f"n_samples={n} exceeds the device kernel's maximum of {POLYK_MAX_N} samples per component")
+    if C == 0:
         return out
-    nbytes = int(lib().sl_poly2means_ws_bytes(C, n, D))
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=Vd.device)
+    per_comp = int(lib().sl_polykmeans_ws_bytes(1, n, D, n_clusters, n_init)) if general else int(lib().sl_poly2means_ws_bytes(1, n, D))
+    chunk = max(1, min(C, POLYK_MAX_COMPONENTS, _poly_ws_budget() // max(per_comp, 1)))
+    ws = None
     with torch.cuda.device(Vd.device):
-        rc = lib().sl_poly2means(
-            _ptr(Vd), C, n, D, first_center.ctypes.data_as(_vp), n_init, rand.ctypes.data_as(_vp),
-            1 if replace_empty_clusters else 0, _ptr(out), _ptr(mincnt), _ptr(ws), nbytes, _stream(Vd),
-        )
-    if rc == -3:
-        raise NotImplementedError(lib().sl_last_error().decode())
-    _check(rc, "sl_poly2means")
+        for c0 in range(0, C, chunk):
+            cc = min(chunk, C - c0)
+            Vc, oc, mc = Vd[c0:c0 + cc], out[c0:c0 + cc], mincnt[c0:c0 + cc]
+            if general:
+                nbytes = int(lib().sl_polykmeans_ws_bytes(cc, n, D, n_clusters, n_init))
+                if ws is None or ws.numel() < nbytes:
+                    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=Vd.device)
+                rc = lib().sl_polykmeans(
+                    _ptr(Vc), cc, n, D, int(n_clusters), first_center.ctypes.data_as(_vp), n_init, rand.ctypes.data_as(_vp),
+                    1 if replace_empty_clusters else 0, _ptr(oc), _ptr(mc), _ptr(ws), nbytes, _stream(Vd),
+                )
+                torch.cuda.current_stream(Vd.device).synchronize()  # the draws were copied from host arrays owned by this call
+                _check(rc, "sl_polykmeans")
+            else:
+                nbytes = int(lib().sl_poly2means_ws_bytes(cc, n, D))
+                if ws is None or ws.numel() < nbytes:
+                    ws = torch.empty(nbytes, dtype=torch.uint8, device=Vd.device)
+                rc = lib().sl_poly2means(
+                    _ptr(Vc), cc, n, D, first_center.ctypes.data_as(_vp), n_init, rand.ctypes.data_as(_vp),
+                    1 if replace_empty_clusters else 0, _ptr(oc), _ptr(mc), _ptr(ws), nbytes, _stream(Vd),
+                )
+                if rc == -3:
+                    raise NotImplementedError(lib().sl_last_error().decode())
+                _check(rc, "sl_poly2means")
     return out
 
 

@@ -62,10 +62,14 @@ class ActMax:
     as in the reference; reading them flushes pending device work and copies the state down.
     """
 
-    def __init__(self, n_collect: int, n_latents: int | None = None, tie_mode: str | None = None):
+    def __init__(self, n_collect: int, n_latents: int | None = None, tie_mode: str | None = None,
+                 init_value: float = -0.0):
         self.n_collect = n_collect
         self.n_latents = n_latents
         self.is_setup = False
+        # the reference starts every slot at -0.0 (fine for post-ReLU activations); signed quantities (relevance) start
+        # at -inf so that an empty slot (id -1) never outranks a real negative value
+        self.init_value = float(init_value)
         self.tie_mode = tie_mode or default_tie_mode()
         if self.tie_mode not in N.TIE_MODES:
             raise ValueError(f"tie_mode must be one of {sorted(N.TIE_MODES)}, got {self.tie_mode!r}")
@@ -82,8 +86,8 @@ class ActMax:
 
     # ---- state -------------------------------------------------------------------------------
     def _setup_tensors(self):
-        """Initial state: values -0.0, ids -1 (activation_caching.py:101-110)."""
-        self._host_vals = -torch.zeros(self.n_latents, self.n_collect, dtype=torch.bfloat16)
+        """Initial state: values -0.0 (``init_value``), ids -1 (activation_caching.py:101-110)."""
+        self._host_vals = torch.full((self.n_latents, self.n_collect), self.init_value, dtype=torch.bfloat16)
         self._host_ids = -torch.ones(self.n_latents, self.n_collect, dtype=torch.int64)
         self._dev_vals = self._dev_ids = None
         self._dev_newer = False
@@ -297,10 +301,12 @@ class ActCache:
 class ActMaxCache(ActCache):
     """Per-layer :class:`ActMax` instances fed by forward hooks (activation_caching.py:318-534)."""
 
-    def __init__(self, layer_names: list[str], aggregation_fn: Callable, n_collect: int, tie_mode: str | None = None):
+    def __init__(self, layer_names: list[str], aggregation_fn: Callable, n_collect: int, tie_mode: str | None = None,
+                 init_value: float = -0.0):
         super().__init__(layer_names)
         self.aggregation_fn = aggregation_fn
         self.n_collect = n_collect
+        self.init_value = float(init_value)
         self.tie_mode = tie_mode or default_tie_mode()
         self.sample_idx_counter = Counter()  # per layer, never reset (activation_caching.py:359,410-413)
 
@@ -310,7 +316,7 @@ class ActMaxCache(ActCache):
         self.agg_fn_name = agg_fn_name
 
         self.cache: dict[str, ActMax] = {
-            name: ActMax(n_collect=n_collect, tie_mode=self.tie_mode) for name in layer_names
+            name: ActMax(n_collect=n_collect, tie_mode=self.tie_mode, init_value=self.init_value) for name in layer_names
         }
 
     def __getitem__(self, layer_name: str) -> ActMax:
@@ -421,5 +427,6 @@ class ActMaxCache(ActCache):
         for layer_name, path in paths.items():
             state = ActMax.load(path)
             state.tie_mode = self.tie_mode
+            state.init_value = self.init_value
             self.cache[layer_name] = state
         logger.info(f"Top-k cache: {len(paths)} layer(s) loaded from {root}")

@@ -60,8 +60,6 @@ def gradient_x_activation(model: nn.Module, layers: dict[str, nn.Module], images
 
     def keep(name):
         def hook(module, ins, out):
-            if out.requires_grad:
-                out.retain_grad()
             kept[name] = out
 
         return hook
@@ -75,13 +73,20 @@ def gradient_x_activation(model: nn.Module, layers: dict[str, nn.Module], images
                 raise ValueError(f"the probed model must return (B, n_classes) logits, got shape {tuple(logits.shape)}")
             if targets is None:
                 targets = logits.argmax(dim=1)
-            logits.gather(1, targets.reshape(-1, 1).to(logits.device)).sum().backward()
+            loss = logits.gather(1, targets.reshape(-1, 1).to(logits.device)).sum()
+            # gradients of the hooked outputs only: `.backward()` would also accumulate `.grad` into every parameter of
+            # the caller's model (memory the size of the model, wasted weight-gradient kernels, mutated grad state)
+            names = [n for n, a in kept.items() if a.requires_grad]
+            grads = torch.autograd.grad(loss, [kept[n] for n in names], allow_unused=True) if names else ()
     finally:
         for h in handles:
             h.remove()
+    by_name = dict(zip(names, grads))
     out = {}
     for name, act in kept.items():
-        grad = act.grad if act.grad is not None else torch.zeros_like(act)
+        grad = by_name.get(name)
+        if grad is None:
+            grad = torch.zeros_like(act)
         out[name] = (act.detach(), (act * grad).detach())
     return out
 
@@ -111,9 +116,15 @@ class RelevanceComponentVisualizer(ActivationComponentVisualizer):
                          aggregate_fn=relevance_sum_absnorm if self.abs_norm else relevance_sum, cache_dir=cache_dir,
                          tie_mode=tie_mode)
         self.num_samples = num_samples
+        # relevance is signed (more so after abs_norm): empty slots start at -inf, not at the reference's -0.0, so that a
+        # component with fewer than num_samples non-negative relevances ranks its negative ones (crp: argsort descending)
+        # instead of keeping id -1 (which the gather would wrap to the last sample)
+        self.actmax_cache.init_value = -float("inf")
+        for state in self.actmax_cache.cache.values():  # not yet set up (n_latents unknown), or loaded from a cache
+            state.init_value = -float("inf")
         # activation mode: crp's ActMax with abs_norm=False (relevance_based.py:140-145)
         self.activation_cache = ActMaxCache(self.layer_names, n_collect=num_samples, aggregation_fn=activation_sum,
-                                            tie_mode=self.actmax_cache.tie_mode)
+                                            tie_mode=self.actmax_cache.tie_mode, init_value=-float("inf"))
         if self.caching:
             try:
                 self.activation_cache.load(self.storage_dir)
@@ -163,7 +174,7 @@ class RelevanceComponentVisualizer(ActivationComponentVisualizer):
         for cache in (self.actmax_cache, self.activation_cache):  # fresh states, whatever the constructor loaded
             for name in self.layer_names:
                 old = cache.cache[name]
-                cache.cache[name] = type(old)(n_collect=old.n_collect, tie_mode=old.tie_mode)
+                cache.cache[name] = type(old)(n_collect=old.n_collect, tie_mode=old.tie_mode, init_value=old.init_value)
         loader = torch.utils.data.DataLoader(self.dataset, batch_size=batch_size, shuffle=False, num_workers=num_workers)
         start = 0
         for images, labels in tqdm(loader, total=len(loader), desc="Collecting relevance"):

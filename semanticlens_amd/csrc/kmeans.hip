@@ -96,6 +96,13 @@ __device__ inline double wave_sum(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
+__device__ inline double wave_max(double v) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
 __device__ inline int wave_sum_i(int v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
@@ -403,6 +410,10 @@ __global__ __launch_bounds__(64) void kmeans2_kernel(const double* __restrict__ 
 //     closest distances, np.argmin (first minimum) over the candidates' potentials;
 //   * E-step: first minimum of ||c_j||^2 - 2 x_i.c_j; empty clusters take, in ascending cluster id, the points farthest
 //     from their own centre (descending distance) and those points leave their old cluster (_relocate_empty_clusters_dense);
+//     nothing moves when the largest distance is 0 (its early return).  Caveats: with two or more empty clusters sklearn
+//     hands out the far points in np.argpartition's order, which is not sorted among the n_empty farthest — the SET of
+//     relocated points is the same, which cluster id gets which may differ (the score is symmetric in the ids); and
+//     "distance == 0" is tested in Gram space here, in feature space there (a centre of >= 3 duplicates may round off it);
 //   * strict convergence (labels unchanged) / tol = mean(var) * 1e-4 on the summed squared centre shifts / 300 iterations,
 //     a final E-step when not strictly converged, best of n_init by inertia unless _is_same_clustering.
 // Checked against scikit-learn on the host first (a numpy transcription of this kernel: 460 components, k = 2..6, with
@@ -469,7 +480,11 @@ __global__ __launch_bounds__(64) void kmeansk_kernel(const double* __restrict__ 
     return d > 0.0 ? d : 0.0;
   };
   // squared distance of point i to current centre j without the G_ii term
-  auto dpart = [&](const double* sarr, int i, int j) { return s_W[j] - 2.0 * sarr[(size_t)j * n + i] / s_cnt[j]; };
+  // (a cluster left empty — relocation skipped, below — is never the first minimum: sklearn parks its centre on the biggest
+  // cluster's, a tie the lower-numbered of the two wins without changing the partition)
+  auto dpart = [&](const double* sarr, int i, int j) {
+    return s_cnt[j] > 0 ? s_W[j] - 2.0 * sarr[(size_t)j * n + i] / s_cnt[j] : __builtin_huge_val();
+  };
   // member sets m[] -> sums so[j][i] = sum_{l in S_j} G_il, counts, W_j (into s_ncnt / s_nW)
   auto subset_stats = [&](const int* m, double* so) {
     for (int j = lane; j < k; j += kWave) s_count[j] = 0;
@@ -583,9 +598,17 @@ __global__ __launch_bounds__(64) void kmeansk_kernel(const double* __restrict__ 
       bool any_empty = false;
       for (int j = 0; j < k; ++j) any_empty |= (s_count[j] == 0);
       if (any_empty) {  // relocation: lane-uniform and sequential (rare)
-        for (int i = lane; i < n; i += kWave) w.cand[i] = Gd(i) + dpart(s_cur, i, w.label[i]);
+        double far = 0.0;
+        for (int i = lane; i < n; i += kWave) {
+          const double d = Gd(i) + dpart(s_cur, i, w.label[i]);
+          w.cand[i] = d;
+          far = d > far ? d : far;
+        }
+        far = wave_max(far);
         __syncthreads();
-        for (int j = 0; j < k; ++j) {
+        // _relocate_empty_clusters_dense returns early when max(distances) == 0 (every point on its centre: fewer distinct
+        // points than clusters); the empty clusters then stay empty and _average_centers parks them on the biggest one
+        for (int j = 0; j < k && far > 0.0; ++j) {
           if (s_count[j] != 0) continue;
           double bestd = -__builtin_huge_val();
           int besti = 0;
@@ -615,7 +638,8 @@ __global__ __launch_bounds__(64) void kmeansk_kernel(const double* __restrict__ 
       }
       __syncthreads();
       double shift = 0.0;
-      for (int j = 0; j < k; ++j) shift += s_W[j] + s_nW[j] - 2.0 * s_x[j] / (s_cnt[j] * (s_ncnt[j] > 0 ? s_ncnt[j] : 1.0));
+      for (int j = 0; j < k; ++j)  // a cluster empty on either side sits on another cluster's centre: no shift of its own
+        if (s_cnt[j] > 0 && s_ncnt[j] > 0) shift += s_W[j] + s_nW[j] - 2.0 * s_x[j] / (s_cnt[j] * s_ncnt[j]);
       __syncthreads();
       {
         double* t = s_cur;
@@ -698,6 +722,17 @@ __global__ __launch_bounds__(64) void kmeansk_kernel(const double* __restrict__ 
         s_dot[j * k + l] = (s_ncnt[j] > 0 && s_ncnt[l] > 0) ? g + (s_x[j] - mu) + (s_x[l] - mu) + mu : 0.0;
       }
     }
+  __syncthreads();
+  if (lane == 0) {  // _average_centers: a cluster without members takes the centre of the biggest one (np.argmax: the first)
+    int big = 0;
+    for (int j = 1; j < k; ++j)
+      if (s_ncnt[j] > s_ncnt[big]) big = j;
+    for (int j = 0; j < k; ++j) {
+      if (s_ncnt[j] > 0) continue;
+      for (int l = 0; l < k; ++l) s_dot[j * k + l] = s_dot[big * k + l];
+      for (int l = 0; l < k; ++l) s_dot[l * k + j] = s_dot[l * k + big];
+    }
+  }
   for (int j = lane; j < k; j += kWave) s_count[j] = 0;
   __syncthreads();
   for (int i = lane; i < n; i += kWave) atomicAdd(&s_count[w.best_label[i]], 1);

@@ -867,8 +867,9 @@ __global__ __launch_bounds__(256) void rowreduce_h_kernel(const T* __restrict__ 
   constexpr bool SUMOP = (OP == OP_SUM || OP == OP_ABSSUM);
   constexpr bool ABS = (OP == OP_ABSMAX || OP == OP_ABSSUM);
   const float fill = SUMOP ? 0.f : -__builtin_huge_valf();
-  // the same value as a pair of raw elements (-inf is 0xFF80 in bf16, 0xFC00 in fp16)
-  const uint32_t fillw = SUMOP ? 0u : (std::is_same<T, uint16_t>::value ? 0xFF80FF80u : 0xFC00FC00u);
+  // the same value as a pair of raw elements (-inf is 0xFF80 in bf16, 0xFC00 in fp16).  The aligned path takes |.| of
+  // whole pieces, fill included, so absmax fills with +0 (|x| >= 0 makes it neutral; |-inf| would be +inf).
+  const uint32_t fillw = (SUMOP || ABS) ? 0u : (std::is_same<T, uint16_t>::value ? 0xFF80FF80u : 0xFC00FC00u);
   const int lane = threadIdx.x & 63;
   const int li = lane & (G - 1);
   const int g = lane / G;

@@ -100,7 +100,7 @@ def merge_actmax_cache(actmax_cache, group=None, device=None):
 
     A rank whose shard was empty (``N < R``, or a short last shard) never saw a batch, so its ``ActMax`` objects do
     not know their width: the layer widths are agreed first (one small MAX all-reduce) and such ranks contribute the
-    initial state (values -0.0, ids -1), which loses every comparison."""
+    initial state (values ``init_value`` = -0.0 unless configured, ids -1), which loses every comparison."""
     rank = dist.get_rank(group)
     names = list(actmax_cache.layer_names)
     widths = _all_reduce_host_ints(
@@ -148,7 +148,7 @@ def run_sharded(cv, batch_size: int = 64, num_workers: int = 0, group=None):
             return cv.actmax_cache.cache
     for name in cv.layer_names:  # fresh states, whatever the constructor loaded
         old = cv.actmax_cache.cache[name]
-        cv.actmax_cache.cache[name] = type(old)(n_collect=old.n_collect, tie_mode=old.tie_mode)
+        cv.actmax_cache.cache[name] = type(old)(n_collect=old.n_collect, tie_mode=old.tie_mode, init_value=old.init_value)
     cv._run(batch_size=batch_size, num_workers=num_workers, sample_range=shard_range(len(cv.dataset), rank, world))
     merge_actmax_cache(cv.actmax_cache, group, cv.device)
     if cv.caching:

@@ -67,8 +67,12 @@ class OpenClip(AbstractVLM):
 
     def preprocess(self, img) -> torch.Tensor:
         """One image or a list of images -> ``(B, 3, S, S)`` on the model's device (clip.py:137-163)."""
-        samples = img if isinstance(img, list) else [img]
-        batch = torch.stack([self.preprocessor(sample) for sample in samples])
+        if isinstance(img, list):
+            batch = torch.stack([self.preprocessor(sample) for sample in img])
+        else:  # a transform that already returns a batch passes through; only a bare (3, S, S) gains the batch axis
+            batch = self.preprocessor(img)
+        if batch.ndim == 3:
+            batch = batch.unsqueeze(0)
         return batch.to(self.device)
 
     def tokenize(self, txt, context_length: int | None = None) -> torch.Tensor:
@@ -77,11 +81,13 @@ class OpenClip(AbstractVLM):
 
     # ---- the package's own execution path --------------------------------------------------------------------------
     def native(self, gemm: str = "bf16x3", device_preprocess: bool = True):
-        """This model with its towers on the HIP kernels (``NativeClip``) and, optionally, its inference transform
-        on the device (``DevicePreprocess.from_transform(self.preprocessor)``)."""
-        from semanticlens_amd.foundation_models.native_clip import NativeClip
+        """This model with its towers on the HIP kernels and, optionally, its inference transform on the device
+        (``DevicePreprocess.from_transform(self.preprocessor)``).  The native class follows the module layout open_clip
+        built: ``NativeClip`` for its own ``VisionTransformer`` towers, ``NativeSigLip`` for a timm trunk with a MAP head
+        (``SigLipV2``); layouts neither implements (MobileCLIP's hybrid tower) raise ``TypeError``."""
+        from semanticlens_amd.foundation_models.native_clip import native_model
 
-        return NativeClip(self, gemm=gemm, preprocess="device" if device_preprocess else None)
+        return native_model(self, gemm=gemm, preprocess="device" if device_preprocess else None)
 
 
 class SigLipV2(OpenClip):

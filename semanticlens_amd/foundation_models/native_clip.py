@@ -1,4 +1,4 @@
-"""NativeClip — a CLIP-family foundation model whose towers run on the package's own HIP kernels.
+"""NativeClip / NativeSigLip — CLIP-family foundation models whose towers run on the package's own HIP kernels.
 
 The reference's ``OpenClip.encode_image`` / ``encode_text`` (foundation_models/clip.py:103-135) call straight
 into the third-party ``open_clip`` torch model.  ``NativeClip`` wraps any such ``AbstractVLM`` (tokenizer and
@@ -11,10 +11,29 @@ activations emitted in split form by the producing kernel; ``gemm="f32"`` uses t
 way features agree with the torch modules to ~1e-5 relative, and the object plugs into ``Lens`` and
 ``ActivationComponentVisualizer`` like any other ``AbstractVLM``.
 
-Supported layout (probed by attribute, the names open_clip's ``VisionTransformer`` / ``TextTransformer`` and
-``synth.SyntheticClip`` use): ``conv1`` (patch embedding, no bias), ``class_embedding``, positional embedding,
-``ln_pre``, blocks with ``ln_1`` / ``attn`` (``torch.nn.MultiheadAttention``) / ``ln_2`` / ``mlp`` (Linear, GELU or
-QuickGELU, Linear), ``ln_post`` / ``ln_final``, projection matrices; head_dim 32 / 64 / 72 / 80 / 88 / 96 / 104 / 128.
+Module layouts read (probed by attribute; anything else is refused with a ``TypeError`` that names what was found):
+
+* **open_clip ``CLIP``** (what ``OpenClip(url)`` builds for the ViT-B/32, B/16, L/14 ... families, clip.py:52-62):
+  ``visual`` = ``VisionTransformer`` {``conv1`` (no bias), ``class_embedding``, ``positional_embedding``, ``ln_pre``
+  (or Identity), ``transformer.resblocks[i]`` {``ln_1``, ``attn`` (``nn.MultiheadAttention``), ``ls_1``, ``ln_2``,
+  ``mlp`` (``c_fc``, ``gelu``, ``c_proj``), ``ls_2``}, ``ln_post``, ``proj``, ``pool_type`` in {``tok``, ``avg``},
+  ``final_ln_after_pool``}; text members on the model itself: ``token_embedding``, ``positional_embedding``,
+  ``transformer``, ``ln_final``, ``text_projection`` (matrix or ``nn.Linear``), ``attn_mask``, ``text_pool_type`` in
+  {``argmax``, ``first``, ``last``}.  LayerScale (``ls_1`` / ``ls_2`` with a ``gamma``) is folded into the weights of
+  the projection it follows.  Attention pooling (CoCa) and hybrid / convolutional towers (MobileCLIP) are refused.
+* **open_clip ``CustomTextCLIP`` with a timm trunk** (what ``SigLipV2()`` builds, clip.py:190-211,
+  ``hf-hub:timm/ViT-B-16-SigLIP2``): ``visual`` = ``TimmModel`` {``trunk`` = timm ``VisionTransformer`` with
+  ``patch_embed.proj`` (bias), ``pos_embed``, no class token, ``blocks[i]`` {``norm1``, ``attn.qkv`` / ``attn.proj``,
+  ``norm2``, ``mlp.fc1`` / ``act`` / ``fc2``}, ``norm``, ``attn_pool`` (``AttentionPoolLatent``: ``latent``, ``q``, ``kv``,
+  ``proj``, ``norm``, ``mlp``), ``head``}; ``text`` = open_clip ``TextTransformer`` (non-causal, ``pool_type="last"``,
+  ``text_projection`` = ``nn.Linear`` with bias).  ``NativeSigLip``.
+* **transformers ``SiglipModel``** (``vision_model`` / ``text_model``; the SigLIP-so400m geometry of BASELINE configs[3]).
+  ``NativeSigLip``.
+* ``synth.SyntheticClip`` (the bench's random-init ViT-B/32).
+
+head_dim 32-128 in steps of 8.  open_clip / timm are not installed in this image, so the open_clip layouts are exercised
+against ``tests/openclip_like.py`` — torch modules carrying open_clip 3.0's attribute tree — and parity for this row
+stays build-vs-torch-module (the reference's own tests pin shapes only, tests/foundation_models/test_clip.py:32-85).
 """
 from __future__ import annotations
 
@@ -43,41 +62,141 @@ def _first(obj, *names):
     raise AttributeError(f"none of {names} found on {type(obj).__name__}")
 
 
-class _Block:
-    """Weights of one pre-LN residual block, as flat fp32 device tensors."""
+_HEAD_DIMS = tuple(range(32, 129, 8))  # what csrc/encoder.hip instantiates sl_attention for
 
-    def __init__(self, blk: nn.Module, device, split: bool):
-        attn: nn.MultiheadAttention = blk.attn
-        if not isinstance(attn, nn.MultiheadAttention) or attn.in_proj_weight is None:
-            raise TypeError("NativeClip expects torch.nn.MultiheadAttention blocks with a packed in_proj_weight")
-        self.heads = attn.num_heads
-        self.width = attn.embed_dim
+
+def _ln(mod: nn.Module, device):
+    """(gamma, beta, eps) of a LayerNorm-like module (open_clip's ``LayerNorm`` / ``LayerNormFp32`` subclass nn.LayerNorm)."""
+    if not isinstance(mod, nn.LayerNorm) or mod.weight is None or mod.bias is None:
+        raise TypeError(f"expected an affine LayerNorm, found {type(mod).__name__}")
+    return _f32(mod.weight, device), _f32(mod.bias, device), float(mod.eps)
+
+
+def _is_identity(mod) -> bool:
+    return mod is None or isinstance(mod, (nn.Identity, nn.Dropout))
+
+
+def _act_code(act) -> int:
+    """Activation of an MLP: a module (nn.GELU with ``approximate``, open_clip's QuickGELU, timm's GELUTanh / QuickGELU) or a
+    config string (transformers: ``gelu``, ``gelu_pytorch_tanh``, ``quick_gelu``)."""
+    if isinstance(act, nn.Module):
+        name = type(act).__name__.lower()
+        if isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "tanh":
+            return N.SL_ACT_GELU_TANH
+    else:
+        name = (act or "gelu").lower()
+    if "quick" in name:
+        return N.SL_ACT_QUICKGELU
+    if "tanh" in name:
+        return N.SL_ACT_GELU_TANH
+    if "gelu" in name:
+        return N.SL_ACT_GELU
+    raise TypeError(f"unsupported MLP activation {name!r} (GELU, tanh-GELU and QuickGELU are built)")
+
+
+def _layer_scale(mod, device):
+    """LayerScale gamma of a residual branch (open_clip ``ls_1`` / ``ls_2``, timm ``ls1`` / ``ls2``), or None."""
+    if _is_identity(mod):
+        return None
+    gamma = getattr(mod, "gamma", None)
+    if gamma is None:
+        raise TypeError(f"residual-branch scale {type(mod).__name__} has no `gamma`")
+    return _f32(gamma, device)
+
+
+class _BlockWeights:
+    """Weights of one pre-LN residual block as flat fp32 device tensors, whatever module layout they were read from:
+    ``x += W_o attn(LN1(x) W_qkv^T) ; x += W_pr act(W_fc LN2(x))`` with the in-projection packed ``[q | k | v]``."""
+
+    def __init__(self, width: int, heads: int, act: int):
+        self.width, self.heads, self.act = int(width), int(heads), act
         self.head_dim = self.width // self.heads
-        if self.head_dim not in (32, 64, 72, 80, 88, 96, 104, 128) or self.head_dim * self.heads != self.width:
-            raise ValueError(f"head_dim {self.head_dim} is not supported (32, 64, 72, 80, 88, 96, 104, 128)")
-        self.ln1 = (_f32(blk.ln_1.weight, device), _f32(blk.ln_1.bias, device), blk.ln_1.eps)
-        self.ln2 = (_f32(blk.ln_2.weight, device), _f32(blk.ln_2.bias, device), blk.ln_2.eps)
-        self.w_qkv, self.b_qkv = _f32(attn.in_proj_weight, device), _f32(attn.in_proj_bias, device)
-        self.w_o, self.b_o = _f32(attn.out_proj.weight, device), _f32(attn.out_proj.bias, device)
-        linears = [m for m in blk.mlp.modules() if isinstance(m, nn.Linear)]
-        if len(linears) != 2:
-            raise TypeError("NativeClip expects an MLP of two Linear layers")
-        self.w_fc, self.b_fc = _f32(linears[0].weight, device), _f32(linears[0].bias, device)
-        self.w_pr, self.b_pr = _f32(linears[1].weight, device), _f32(linears[1].bias, device)
-        acts = [m for m in blk.mlp.modules() if not isinstance(m, (nn.Linear, nn.Sequential)) and m is not blk.mlp]
-        name = type(acts[0]).__name__.lower() if acts else "gelu"
-        self.act = N.SL_ACT_QUICKGELU if "quick" in name else N.SL_ACT_GELU
-        if split:
+        if self.head_dim not in _HEAD_DIMS or self.head_dim * self.heads != self.width:
+            raise ValueError(f"head_dim {self.head_dim} is not supported (32 to 128 in steps of 8)")
+
+    def scale_branches(self, g_attn, g_mlp):
+        """Fold LayerScale into the projection it follows: gamma * (W x + b) = (gamma W) x + gamma b."""
+        if g_attn is not None:
+            self.w_o, self.b_o = (self.w_o * g_attn[:, None]).contiguous(), (self.b_o * g_attn).contiguous()
+        if g_mlp is not None:
+            self.w_pr, self.b_pr = (self.w_pr * g_mlp[:, None]).contiguous(), (self.b_pr * g_mlp).contiguous()
+        return self
+
+    def finish(self, split: bool):
+        if split and not hasattr(self, "s_qkv"):
             self.s_qkv, self.s_o = N.Split.of(self.w_qkv), N.Split.of(self.w_o)
             self.s_fc, self.s_pr = N.Split.of(self.w_fc), N.Split.of(self.w_pr)
+        return self
+
+
+def _bias(lin: nn.Linear, device):
+    return _f32(lin.bias, device) if lin.bias is not None else torch.zeros(lin.out_features, dtype=torch.float32, device=device)
+
+
+def _read_mha_block(blk: nn.Module, device) -> _BlockWeights:
+    """open_clip ``ResidualAttentionBlock`` (and ``synth._Block``): ``ln_1``, ``attn`` = nn.MultiheadAttention with the packed
+    in-projection, ``ls_1``, ``ln_2``, ``mlp`` = (Linear, activation, Linear), ``ls_2``."""
+    attn = getattr(blk, "attn", None)
+    if not isinstance(attn, nn.MultiheadAttention) or attn.in_proj_weight is None or attn.in_proj_bias is None:
+        raise TypeError("expected torch.nn.MultiheadAttention blocks with a packed in_proj_weight and bias")
+    if hasattr(blk, "ln_1_kv") or getattr(blk, "ln_attn", None) is not None and not _is_identity(blk.ln_attn):
+        raise TypeError("cross-attention / scaled-attention blocks are not built")
+    linears = [m for m in blk.mlp.modules() if isinstance(m, nn.Linear)]
+    others = [m for m in blk.mlp.children() if not isinstance(m, nn.Linear) and not _is_identity(m)]
+    if len(linears) != 2 or len(others) != 1:
+        raise TypeError("expected an MLP of Linear, activation, Linear")
+    w = _BlockWeights(attn.embed_dim, attn.num_heads, _act_code(others[0]))
+    w.ln1, w.ln2 = _ln(blk.ln_1, device), _ln(blk.ln_2, device)
+    w.w_qkv, w.b_qkv = _f32(attn.in_proj_weight, device), _f32(attn.in_proj_bias, device)
+    w.w_o, w.b_o = _f32(attn.out_proj.weight, device), _bias(attn.out_proj, device)
+    w.w_fc, w.b_fc = _f32(linears[0].weight, device), _bias(linears[0], device)
+    w.w_pr, w.b_pr = _f32(linears[1].weight, device), _bias(linears[1], device)
+    return w.scale_branches(_layer_scale(getattr(blk, "ls_1", None), device), _layer_scale(getattr(blk, "ls_2", None), device))
+
+
+def _read_hf_siglip_block(blk: nn.Module, heads: int, act: int, device) -> _BlockWeights:
+    """transformers ``SiglipEncoderLayer``: ``layer_norm1``, ``self_attn`` with separate ``q_proj`` / ``k_proj`` / ``v_proj`` /
+    ``out_proj`` (packed here into the ``[q | k | v]`` in-projection the attention kernel reads), ``layer_norm2``,
+    ``mlp.fc1`` / ``mlp.fc2``."""
+    a = blk.self_attn
+    w = _BlockWeights(a.q_proj.in_features, heads, act)
+    w.ln1, w.ln2 = _ln(blk.layer_norm1, device), _ln(blk.layer_norm2, device)
+    w.w_qkv = torch.cat([_f32(p.weight, device) for p in (a.q_proj, a.k_proj, a.v_proj)], 0).contiguous()
+    w.b_qkv = torch.cat([_bias(p, device) for p in (a.q_proj, a.k_proj, a.v_proj)], 0).contiguous()
+    w.w_o, w.b_o = _f32(a.out_proj.weight, device), _bias(a.out_proj, device)
+    w.w_fc, w.b_fc = _f32(blk.mlp.fc1.weight, device), _bias(blk.mlp.fc1, device)
+    w.w_pr, w.b_pr = _f32(blk.mlp.fc2.weight, device), _bias(blk.mlp.fc2, device)
+    return w
+
+
+def _read_timm_block(blk: nn.Module, device) -> _BlockWeights:
+    """timm ``vision_transformer.Block``: ``norm1``, ``attn`` {``qkv`` (packed Linear), ``q_norm``, ``k_norm``, ``proj``,
+    ``num_heads``}, ``ls1``, ``norm2``, ``mlp`` {``fc1``, ``act``, ``norm``, ``fc2``}, ``ls2``."""
+    a = blk.attn
+    if not isinstance(getattr(a, "qkv", None), nn.Linear) or not isinstance(getattr(a, "proj", None), nn.Linear):
+        raise TypeError("expected timm Attention with packed `qkv` and `proj` Linear layers")
+    if not (_is_identity(getattr(a, "q_norm", None)) and _is_identity(getattr(a, "k_norm", None))):
+        raise TypeError("timm Attention with q/k normalisation is not built")
+    if not _is_identity(getattr(blk.mlp, "norm", None)):
+        raise TypeError("timm Mlp with an inner norm is not built")
+    w = _BlockWeights(a.qkv.in_features, a.num_heads, _act_code(blk.mlp.act))
+    w.ln1, w.ln2 = _ln(blk.norm1, device), _ln(blk.norm2, device)
+    w.w_qkv, w.b_qkv = _f32(a.qkv.weight, device), _bias(a.qkv, device)
+    w.w_o, w.b_o = _f32(a.proj.weight, device), _bias(a.proj, device)
+    w.w_fc, w.b_fc = _f32(blk.mlp.fc1.weight, device), _bias(blk.mlp.fc1, device)
+    w.w_pr, w.b_pr = _f32(blk.mlp.fc2.weight, device), _bias(blk.mlp.fc2, device)
+    return w.scale_branches(_layer_scale(getattr(blk, "ls1", None), device), _layer_scale(getattr(blk, "ls2", None), device))
 
 
 class _Tower:
     """L residual blocks over a (B*T, W) fp32 token matrix (the residual stream stays fp32 in both modes)."""
 
-    def __init__(self, blocks, device, split: bool):
+    def __init__(self, blocks: list, split: bool):
+        """``blocks``: `_BlockWeights` in execution order (built by one of the layout readers below)."""
+        if not blocks:
+            raise TypeError("the tower has no residual blocks")
         self.split = split
-        self.blocks = [_Block(b, device, split) for b in blocks]
+        self.blocks = [b.finish(split) for b in blocks]
         self.width = self.blocks[0].width
         self.heads = self.blocks[0].heads
 
@@ -130,24 +249,32 @@ class _Tower:
 
 
 class NativeVisionTower:
-    def __init__(self, visual: nn.Module, blocks, device, split: bool):
+    """open_clip ``VisionTransformer`` forward (class token + learned positions, pre-LN blocks) on the kernels.  ``pool``:
+    ``"tok"`` (class token) or ``"avg"`` (mean of the patch tokens); ``ln_after_pool`` = open_clip's ``final_ln_after_pool``;
+    ``ln_pre`` may be absent (``no_ln_pre``), ``proj`` too."""
+
+    def __init__(self, visual: nn.Module, blocks, device, split: bool, pool: str = "tok", ln_after_pool: bool = False):
         conv = visual.conv1
         if conv.bias is not None or conv.kernel_size != conv.stride:
             raise TypeError("NativeClip expects a bias-free patch embedding with stride == kernel size")
+        if pool not in ("tok", "avg"):
+            raise TypeError(f"visual.pool_type={pool!r}: only 'tok' and 'avg' are built")
         self.patch = conv.kernel_size[0]
         self.width = conv.out_channels
         self.w_patch = _f32(conv.weight.reshape(self.width, -1), device)  # (W, C*P*P)
         self.cls = _f32(visual.class_embedding, device)
         self.pos = _f32(_first(visual, "positional_embedding", "positional_embedding_v"), device)
-        ln_pre, ln_post = visual.ln_pre, visual.ln_post
-        self.ln_pre = (_f32(ln_pre.weight, device), _f32(ln_pre.bias, device), ln_pre.eps)
-        self.ln_post = (_f32(ln_post.weight, device), _f32(ln_post.bias, device), ln_post.eps)
-        proj = _first(visual, "proj", "proj_v")
-        self.w_proj = _f32(proj.t(), device)  # features = x @ proj  ->  Linear weight (D, W)
+        self.ln_pre = None if _is_identity(visual.ln_pre) else _ln(visual.ln_pre, device)
+        self.ln_post = _ln(visual.ln_post, device)
+        proj = getattr(visual, "proj", None)
+        if proj is None:
+            proj = getattr(visual, "proj_v", None)
+        self.w_proj = _f32(proj.t(), device) if proj is not None else None  # features = x @ proj -> Linear weight (D, W)
         self.split = split
         if split:
             self.s_patch = N.Split.of(self.w_patch)
-        self.tower = _Tower(blocks, device, split)
+        self.tower = _Tower([_read_mha_block(b, device) for b in blocks], split)
+        self.pool, self.ln_after_pool = pool, bool(ln_after_pool)
         self.pool_shortcut = True  # last block: out-proj / MLP for the class-token rows only (see _Tower.forward)
 
     @torch.no_grad()
@@ -168,27 +295,52 @@ class NativeVisionTower:
             patches = N.patchify(img, self.patch)
             N.linear(patches, self.w_patch, out=x, scatter=(n_patch, T, 1), rowadd=self.pos)
         N.broadcast_row(self.cls, self.pos[0], B, T * W, x)  # token 0 = class embedding + pos[0]
-        h = N.layernorm(x, *self.ln_pre)
-        if self.pool_shortcut:
-            cls_rows = torch.arange(B, device=img.device, dtype=torch.int64) * T
-            pooled = N.layernorm(self.tower.forward(h, B, T, causal=False, pool_rows=cls_rows), *self.ln_post)
-        else:
+        h = N.layernorm(x, *self.ln_pre) if self.ln_pre is not None else x
+        if self.pool == "tok":
+            # LayerNorm is per row, so ln_post before or after picking the class token gives the same bits
+            if self.pool_shortcut:
+                cls_rows = torch.arange(B, device=img.device, dtype=torch.int64) * T
+                pooled = N.layernorm(self.tower.forward(h, B, T, causal=False, pool_rows=cls_rows), *self.ln_post)
+            else:
+                h = self.tower.forward(h, B, T, causal=False)
+                pooled = N.layernorm(h, *self.ln_post, rows=B, x_row_stride=T * W)  # class-token rows only
+        else:  # "avg": mean over the patch tokens (K2's token mean on the (B, T-1, W) view), ln_post on either side of it
             h = self.tower.forward(h, B, T, causal=False)
-            pooled = N.layernorm(h, *self.ln_post, rows=B, x_row_stride=T * W)  # class-token rows only
-        return N.linear(pooled, self.w_proj)
+            if not self.ln_after_pool:
+                h = N.layernorm(h, *self.ln_post)
+            pooled = torch.empty((B, W), dtype=torch.float32, device=img.device)
+            N.reduce_tokens(h.view(B, T, W)[:, 1:], N.SL_TOK_MEAN, 0, None, pooled)
+            if self.ln_after_pool:
+                pooled = N.layernorm(pooled, *self.ln_post)
+        return N.linear(pooled, self.w_proj) if self.w_proj is not None else pooled
 
 
 class NativeTextTower:
-    def __init__(self, model: nn.Module, blocks, device, split: bool):
+    """open_clip text tower (``CLIP``'s flattened members or a ``TextTransformer``) on the kernels: token + position
+    embeddings, pre-LN blocks (causal iff the module carries an ``attn_mask``), ``ln_final``, pooling at the end-of-text
+    token (``"argmax"``: CLIP's tokenizer gives it the highest id), the first or the last position, then the projection
+    (a matrix, an ``nn.Linear`` with bias, or none)."""
+
+    def __init__(self, model: nn.Module, blocks, device, split: bool, pool: str = "argmax", causal: bool = True):
+        if pool not in ("argmax", "first", "last"):
+            raise TypeError(f"text pool_type={pool!r}: only 'argmax', 'first' and 'last' are built")
+        if getattr(model, "cls_emb", None) is not None:
+            raise TypeError("text towers with a learned class embedding (CoCa) are not built")
         self.table = _f32(model.token_embedding.weight, device)
         self.pos = _f32(_first(model, "positional_embedding", "positional_embedding_t"), device)
-        ln = model.ln_final
-        self.ln_final = (_f32(ln.weight, device), _f32(ln.bias, device), ln.eps)
-        proj = _first(model, "text_projection", "proj_t")
-        self.w_proj = _f32(proj.t(), device)
-        self.tower = _Tower(blocks, device, split)
+        self.ln_final = _ln(model.ln_final, device)
+        proj = getattr(model, "text_projection", None)
+        if proj is None:
+            proj = getattr(model, "proj_t", None)
+        self.b_proj = None
+        if isinstance(proj, nn.Linear):
+            self.w_proj, self.b_proj = _f32(proj.weight, device), (_f32(proj.bias, device) if proj.bias is not None else None)
+        else:
+            self.w_proj = _f32(proj.t(), device) if proj is not None else None
+        self.tower = _Tower([_read_mha_block(b, device) for b in blocks], split)
+        self.pool, self.causal = pool, bool(causal)
         self.truncate = True  # skip the positions after the batch's last end-of-text token (see __call__)
-        self.pool_shortcut = True  # last block: out-proj / MLP for the end-of-text rows only
+        self.pool_shortcut = True  # last block: out-proj / MLP for the pooled rows only
 
     @torch.no_grad()
     def __call__(self, tokens: torch.Tensor) -> torch.Tensor:
@@ -196,43 +348,40 @@ class NativeTextTower:
         B, T = tokens.shape
         if T > self.pos.shape[0]:
             raise ValueError(f"{T} tokens exceed the text tower's context length {self.pos.shape[0]}")
-        eot = tokens.argmax(dim=-1)  # end-of-text token (highest id): the position CLIP's text tower pools
-        if self.truncate and B > 0:
-            # the tower is causal: position t only sees positions <= t, so nothing after the last end-of-text token of
-            # the batch can reach a pooled feature.  Dropping those (padding) positions leaves every pooled value
-            # bit-identical and shrinks the work from context_length to the longest prompt (one scalar readback).
-            t_eff = int(eot.max().item()) + 1
-            if t_eff < T:
-                tokens, T = tokens[:, :t_eff].contiguous(), t_eff
-        x = N.embed_tokens(self.table, tokens, self.pos[:T].contiguous())
-        rows = torch.arange(B, device=tokens.device) * T + eot
-        if self.pool_shortcut:
-            picked = self.tower.forward(x, B, T, causal=True, pool_rows=rows)
+        if self.pool == "argmax":
+            at = tokens.argmax(dim=-1)  # end-of-text token (highest id): the position CLIP's text tower pools
+            if self.truncate and self.causal and B > 0:
+                # the tower is causal: position t only sees positions <= t, so nothing after the last end-of-text token of
+                # the batch can reach a pooled feature.  Dropping those (padding) positions leaves every pooled value
+                # bit-identical and shrinks the work from context_length to the longest prompt (one scalar readback).
+                t_eff = int(at.max().item()) + 1
+                if t_eff < T:
+                    tokens, T = tokens[:, :t_eff].contiguous(), t_eff
+        elif self.pool == "first":
+            at = torch.zeros(B, dtype=torch.int64, device=tokens.device)
         else:
-            picked = N.gather_rows(self.tower.forward(x, B, T, causal=True), rows, check=False)
+            at = torch.full((B,), T - 1, dtype=torch.int64, device=tokens.device)
+        x = N.embed_tokens(self.table, tokens, self.pos[:T].contiguous())
+        rows = torch.arange(B, device=tokens.device) * T + at
+        if self.pool_shortcut:
+            picked = self.tower.forward(x, B, T, causal=self.causal, pool_rows=rows)
+        else:
+            picked = N.gather_rows(self.tower.forward(x, B, T, causal=self.causal), rows, check=False)
         pooled = N.layernorm(picked, *self.ln_final)
-        return N.linear(pooled, self.w_proj)
+        return N.linear(pooled, self.w_proj, self.b_proj) if self.w_proj is not None else pooled
 
 
 def _require_clip_layout(model):
-    """open_clip builds many variants behind the same attribute names.  The native towers implement exactly one: class-token
-    pooling of the image tower, a causal text tower pooled at the end-of-text (argmax) token, no LayerScale, no attention
-    pooling.  Anything else is refused here instead of silently producing different features."""
+    """open_clip builds many variants behind the same attribute names.  What the native towers implement is listed in the
+    module docstring; anything else is refused here instead of silently producing different features."""
     v = model.visual
     problems = []
     if getattr(v, "attn_pool", None) is not None:
         problems.append("visual.attn_pool is set (attention pooling)")
-    if getattr(v, "pool_type", "tok") not in ("tok",):
-        problems.append(f"visual.pool_type={getattr(v, 'pool_type', None)!r} (only 'tok')")
-    if getattr(model, "text_pool_type", "argmax") not in ("argmax",):
-        problems.append(f"text_pool_type={getattr(model, 'text_pool_type', None)!r} (only 'argmax')")
-    for tower in (getattr(v, "transformer", None), getattr(model, "transformer", None)):
-        for blk in getattr(tower, "resblocks", []):
-            for ls in ("ls_1", "ls_2"):
-                if hasattr(blk, ls) and not isinstance(getattr(blk, ls), nn.Identity):
-                    problems.append(f"{ls} is not Identity (LayerScale)")
-    if getattr(model, "attn_mask", None) is None and hasattr(model, "attn_mask"):
-        problems.append("the text tower has no causal attn_mask")
+    if getattr(v, "pool_type", "tok") not in ("tok", "avg"):
+        problems.append(f"visual.pool_type={getattr(v, 'pool_type', None)!r} (only 'tok' and 'avg')")
+    if getattr(model, "text_pool_type", "argmax") not in ("argmax", "first", "last"):
+        problems.append(f"text_pool_type={getattr(model, 'text_pool_type', None)!r} (only 'argmax', 'first', 'last')")
     if problems:
         raise TypeError("NativeClip does not implement this open_clip variant: " + "; ".join(sorted(set(problems))))
 
@@ -254,18 +403,25 @@ class NativeClip(AbstractVLM):
             dev = N.default_device()
         self._device = dev
         base.to(dev)
-        if hasattr(model, "visual") and hasattr(model.visual, "conv1"):  # open_clip: CLIP.visual is the whole image tower
-            visual, vblocks = model.visual, _first(model.visual, "transformer.resblocks")
-            tblocks = _first(model, "transformer.resblocks")
+        visual = getattr(model, "visual", None)
+        if visual is not None and hasattr(visual, "conv1") and hasattr(visual, "transformer"):
+            # open_clip CLIP: `visual` is the whole image tower, the text tower's members sit on the model itself
+            # (CustomTextCLIP keeps them under `.text`)
             _require_clip_layout(model)
-        else:  # synth._ClipModel: embedding members on the model, block stacks in .visual / .text
-            visual, vblocks = _SynthVisual(model), model.visual.blocks
-            tblocks = model.text.blocks
-        self.vision = NativeVisionTower(visual, vblocks, dev, split)
-        try:
-            self.text = NativeTextTower(model, tblocks, dev, split)
-        except (AttributeError, TypeError, ValueError):
-            self.text = None  # text tower layout not recognised: encode_text stays on the wrapped torch model
+            self.vision = NativeVisionTower(visual, visual.transformer.resblocks, dev, split, pool=getattr(visual, "pool_type", "tok"),
+                                            ln_after_pool=getattr(visual, "final_ln_after_pool", False))
+            text = model.text if hasattr(model, "text") and hasattr(model.text, "transformer") else model
+            pool = getattr(text, "pool_type", None) or getattr(model, "text_pool_type", "argmax")
+            self.text = NativeTextTower(text, text.transformer.resblocks, dev, split, pool=pool,
+                                        causal=getattr(text, "attn_mask", None) is not None)
+        elif visual is not None and hasattr(model, "conv1") and hasattr(visual, "blocks"):
+            # synth._ClipModel: embedding members on the model, block stacks in .visual / .text
+            self.vision = NativeVisionTower(_SynthVisual(model), visual.blocks, dev, split)
+            self.text = NativeTextTower(model, model.text.blocks, dev, split)
+        else:
+            found = type(visual).__name__ if visual is not None else "no `visual` member"
+            raise TypeError(f"NativeClip reads open_clip's CLIP / VisionTransformer layout; {type(model).__name__} has {found} "
+                            "(timm trunks: NativeSigLip; convolutional / hybrid towers such as MobileCLIP are not built)")
         self.name = f"native-{gemm}-" + getattr(base, "name", type(base).__name__)
         if preprocess == "device":
             from semanticlens_amd.foundation_models.preprocess import DevicePreprocess
@@ -286,8 +442,6 @@ class NativeClip(AbstractVLM):
         return self.vision(img)
 
     def encode_text(self, tokens):
-        if self.text is None:
-            return self.base.encode_text(tokens)
         return self.text(tokens)
 
     def preprocess(self, img):
@@ -312,89 +466,106 @@ class _SynthVisual:
 # ------------------------------------------------------------------------------------------------------------------
 # SigLIP-layout towers (reference: foundation_models/clip.py:190-211 `SigLipV2`; BASELINE configs[3] names SigLIP-so400m)
 # ------------------------------------------------------------------------------------------------------------------
-def _act_code(name: str) -> int:
-    name = (name or "gelu").lower()
-    if "quick" in name:
-        return N.SL_ACT_QUICKGELU
-    if "tanh" in name:
-        return N.SL_ACT_GELU_TANH
-    return N.SL_ACT_GELU
+class _MapHead:
+    """Weights of a MAP head (one learned probe attends over all tokens, out-projection, LayerNorm + MLP residual branch):
+    transformers' ``SiglipMultiheadAttentionPoolingHead`` and timm's ``AttentionPoolLatent`` are the same computation."""
 
+    def __init__(self, probe, wq, bq, wkv, bkv, w_o, b_o, ln, w1, b1, w2, b2, heads: int, act: int):
+        W = probe.numel()
+        self.heads, self.head_dim, self.act = int(heads), W // int(heads), act
+        if self.head_dim not in _HEAD_DIMS or self.head_dim * self.heads != W:
+            raise ValueError(f"MAP head: head_dim {self.head_dim} is not supported (32 to 128 in steps of 8)")
+        # the probe is the same for every image: its query projection is a constant of the model
+        self.q_probe = N.linear(probe.reshape(1, W).contiguous(), wq, bq).reshape(W).contiguous()
+        self.w_kv, self.b_kv = wkv, bkv  # (2W, W): rows [k | v]
+        self.w_o, self.b_o, self.ln, self.w1, self.b1, self.w2, self.b2 = w_o, b_o, ln, w1, b1, w2, b2
 
-class _SigLipBlock:
-    """One pre-LN block of a SigLIP encoder in `_Block`'s field layout.  Source layout: ``layer_norm1``, ``self_attn`` with
-    separate ``q_proj`` / ``k_proj`` / ``v_proj`` / ``out_proj`` Linear layers (packed here into the ``[q | k | v]``
-    in-projection the attention kernel reads), ``layer_norm2``, ``mlp.fc1`` / ``mlp.fc2`` (transformers' ``SiglipEncoderLayer``)."""
+    @classmethod
+    def from_transformers(cls, head: nn.Module, act: int, device):
+        mha: nn.MultiheadAttention = head.attention
+        W = mha.embed_dim
+        ipw, ipb = _f32(mha.in_proj_weight, device), _f32(mha.in_proj_bias, device)
+        return cls(_f32(head.probe, device), ipw[:W].contiguous(), ipb[:W].contiguous(), ipw[W:].contiguous(), ipb[W:].contiguous(),
+                   _f32(mha.out_proj.weight, device), _bias(mha.out_proj, device), _ln(head.layernorm, device),
+                   _f32(head.mlp.fc1.weight, device), _bias(head.mlp.fc1, device), _f32(head.mlp.fc2.weight, device),
+                   _bias(head.mlp.fc2, device), mha.num_heads, act)
 
-    def __init__(self, blk: nn.Module, heads: int, act: int, device, split: bool):
-        a = blk.self_attn
-        self.width = a.q_proj.in_features
-        self.heads = heads
-        self.head_dim = self.width // heads
-        if self.head_dim not in (32, 64, 72, 80, 88, 96, 104, 128) or self.head_dim * heads != self.width:
-            raise ValueError(f"head_dim {self.head_dim} is not supported (32, 64, 72, 80, 88, 96, 104, 128)")
-        self.ln1 = (_f32(blk.layer_norm1.weight, device), _f32(blk.layer_norm1.bias, device), blk.layer_norm1.eps)
-        self.ln2 = (_f32(blk.layer_norm2.weight, device), _f32(blk.layer_norm2.bias, device), blk.layer_norm2.eps)
-        self.w_qkv = torch.cat([_f32(p.weight, device) for p in (a.q_proj, a.k_proj, a.v_proj)], 0).contiguous()
-        self.b_qkv = torch.cat([_f32(p.bias, device) for p in (a.q_proj, a.k_proj, a.v_proj)], 0).contiguous()
-        self.w_o, self.b_o = _f32(a.out_proj.weight, device), _f32(a.out_proj.bias, device)
-        self.w_fc, self.b_fc = _f32(blk.mlp.fc1.weight, device), _f32(blk.mlp.fc1.bias, device)
-        self.w_pr, self.b_pr = _f32(blk.mlp.fc2.weight, device), _f32(blk.mlp.fc2.bias, device)
-        self.act = act
-        if split:
-            self.s_qkv, self.s_o = N.Split.of(self.w_qkv), N.Split.of(self.w_o)
-            self.s_fc, self.s_pr = N.Split.of(self.w_fc), N.Split.of(self.w_pr)
-
-
-class _SigLipStack(_Tower):
-    def __init__(self, layers, heads: int, act: int, device, split: bool):
-        self.split = split
-        self.blocks = [_SigLipBlock(b, heads, act, device, split) for b in layers]
-        self.width = self.blocks[0].width
-        self.heads = heads
+    @classmethod
+    def from_timm(cls, pool: nn.Module, device):
+        """timm ``AttentionPoolLatent``: ``latent`` (1, 1, W), ``q``, ``kv`` (outputs ``[k | v]``), ``proj``, ``norm``, ``mlp``."""
+        if getattr(pool, "latent_len", 1) != 1 or getattr(pool, "pos_embed", None) is not None:
+            raise TypeError("timm AttentionPoolLatent with several latents or its own position embedding is not built")
+        if not (_is_identity(getattr(pool, "q_norm", None)) and _is_identity(getattr(pool, "k_norm", None))):
+            raise TypeError("timm AttentionPoolLatent with q/k normalisation is not built")
+        if getattr(pool, "pool", "token") != "token":
+            raise TypeError(f"timm AttentionPoolLatent pool={pool.pool!r}: only 'token'")
+        return cls(_f32(pool.latent, device), _f32(pool.q.weight, device), _bias(pool.q, device), _f32(pool.kv.weight, device),
+                   _bias(pool.kv, device), _f32(pool.proj.weight, device), _bias(pool.proj, device), _ln(pool.norm, device),
+                   _f32(pool.mlp.fc1.weight, device), _bias(pool.mlp.fc1, device), _f32(pool.mlp.fc2.weight, device),
+                   _bias(pool.mlp.fc2, device), pool.num_heads, _act_code(pool.mlp.act))
 
 
 class NativeSigLipVision:
-    """Image tower: patch embedding WITH bias, learned positions, no class token, non-causal blocks, ``post_layernorm``,
-    then the MAP head: one learned probe attends over all tokens (``sl_attention_pool``), out-projection, and a
-    LayerNorm + MLP residual branch; the pooled token is the image feature (no further projection)."""
+    """Image tower: patch embedding WITH bias, learned positions, no class token, non-causal blocks, a final LayerNorm,
+    then the MAP head (``sl_attention_pool``); the pooled token is the image feature, optionally followed by a Linear
+    (open_clip ``TimmModel.head.proj``)."""
 
-    def __init__(self, vm: nn.Module, cfg, device, split: bool):
-        emb = vm.embeddings
-        conv = emb.patch_embedding
+    def __init__(self, conv: nn.Conv2d, pos: torch.Tensor, blocks: list, ln_post, head: _MapHead, device, split: bool,
+                 final_proj: nn.Linear | None = None):
         if conv.kernel_size != conv.stride:
             raise TypeError("NativeSigLip expects a patch embedding with stride == kernel size")
         self.patch = conv.kernel_size[0]
         self.width = conv.out_channels
         self.w_patch = _f32(conv.weight.reshape(self.width, -1), device)
         self.b_patch = _f32(conv.bias, device) if conv.bias is not None else None
-        self.pos = _f32(emb.position_embedding.weight, device)  # (n_patches, W)
-        act = _act_code(getattr(cfg, "hidden_act", "gelu_pytorch_tanh"))
+        self.pos = _f32(pos.reshape(-1, self.width), device)  # (n_patches, W)
         self.split = split
         if split:
             self.s_patch = N.Split.of(self.w_patch)
-        self.tower = _SigLipStack(vm.encoder.layers, cfg.num_attention_heads, act, device, split)
-        ln = vm.post_layernorm
-        self.ln_post = (_f32(ln.weight, device), _f32(ln.bias, device), ln.eps)
-        head = vm.head
-        mha: nn.MultiheadAttention = head.attention
-        W = self.width
-        self.heads = mha.num_heads
-        self.head_dim = W // self.heads
-        wq, wk, wv = mha.in_proj_weight[:W], mha.in_proj_weight[W:2 * W], mha.in_proj_weight[2 * W:]
-        bq, bkv = mha.in_proj_bias[:W], mha.in_proj_bias[W:]
-        # the probe is the same for every image: its query projection is a constant of the model
-        probe = _f32(head.probe.reshape(1, W), device)
-        self.q_probe = N.linear(probe, _f32(wq, device), _f32(bq, device)).reshape(W).contiguous()
-        self.w_kv = torch.cat([_f32(wk, device), _f32(wv, device)], 0).contiguous()  # (2W, W): rows [k | v]
-        self.b_kv = _f32(bkv, device)
-        self.w_ho, self.b_ho = _f32(mha.out_proj.weight, device), _f32(mha.out_proj.bias, device)
-        self.ln_head = (_f32(head.layernorm.weight, device), _f32(head.layernorm.bias, device), head.layernorm.eps)
-        self.w_h1, self.b_h1 = _f32(head.mlp.fc1.weight, device), _f32(head.mlp.fc1.bias, device)
-        self.w_h2, self.b_h2 = _f32(head.mlp.fc2.weight, device), _f32(head.mlp.fc2.bias, device)
-        self.head_act = act
+        self.tower = _Tower(blocks, split)
+        self.ln_post = ln_post
+        self.head = head
         if split:
-            self.s_kv = N.Split.of(self.w_kv)
+            self.s_kv = N.Split.of(head.w_kv)
+        self.w_final = _f32(final_proj.weight, device) if final_proj is not None else None
+        self.b_final = _f32(final_proj.bias, device) if final_proj is not None and final_proj.bias is not None else None
+
+    @classmethod
+    def from_transformers(cls, vm: nn.Module, cfg, device, split: bool):
+        """transformers ``SiglipVisionTransformer``: ``embeddings``, ``encoder.layers``, ``post_layernorm``, ``head``."""
+        act = _act_code(getattr(cfg, "hidden_act", "gelu_pytorch_tanh"))
+        blocks = [_read_hf_siglip_block(b, cfg.num_attention_heads, act, device) for b in vm.encoder.layers]
+        return cls(vm.embeddings.patch_embedding, vm.embeddings.position_embedding.weight, blocks, _ln(vm.post_layernorm, device),
+                   _MapHead.from_transformers(vm.head, act, device), device, split)
+
+    @classmethod
+    def from_open_clip_timm(cls, visual: nn.Module, device, split: bool):
+        """open_clip ``TimmModel``: ``trunk`` = timm ``VisionTransformer`` built with ``global_pool="map"``, ``head`` = the
+        (possibly empty) projection ``nn.Sequential``."""
+        t = visual.trunk
+        problems = []
+        if getattr(t, "global_pool", "map") != "map" or getattr(t, "attn_pool", None) is None:
+            problems.append(f"trunk.global_pool={getattr(t, 'global_pool', None)!r} (only the MAP head 'map')")
+        if getattr(t, "cls_token", None) is not None or getattr(t, "reg_token", None) is not None:
+            problems.append("the trunk has class / register tokens")
+        for name in ("norm_pre", "fc_norm"):
+            if not _is_identity(getattr(t, name, None)):
+                problems.append(f"trunk.{name} is not Identity")
+        pe = t.patch_embed
+        if not _is_identity(getattr(pe, "norm", None)) or not isinstance(getattr(pe, "proj", None), nn.Conv2d):
+            problems.append("patch_embed is not a plain strided convolution")
+        if not _is_identity(getattr(t, "head", None)):
+            problems.append("trunk.head is not Identity (the classifier of the timm model)")
+        final = None
+        for name, m in (visual.head.named_children() if hasattr(visual, "head") else ()):
+            if isinstance(m, nn.Linear) and final is None:
+                final = m
+            elif not _is_identity(m):
+                problems.append(f"visual.head.{name} is a {type(m).__name__}")
+        if problems:
+            raise TypeError("NativeSigLip does not implement this timm trunk: " + "; ".join(problems))
+        blocks = [_read_timm_block(b, device) for b in t.blocks]
+        return cls(pe.proj, t.pos_embed, blocks, _ln(t.norm, device), _MapHead.from_timm(t.attn_pool, device), device, split, final)
 
     @torch.no_grad()
     def __call__(self, img: torch.Tensor) -> torch.Tensor:
@@ -404,6 +575,7 @@ class NativeSigLipVision:
         if T != self.pos.shape[0]:
             raise ValueError(f"image gives {T} patches, the positional embedding has {self.pos.shape[0]}")
         W = self.width
+        hd = self.head
         x = torch.empty((B * T, W), dtype=torch.float32, device=img.device)
         # patch embedding GEMM (+ bias); its epilogue writes row (b, p) to token row b*T + p and adds pos[p]
         if self.split:
@@ -414,25 +586,26 @@ class NativeSigLipVision:
         x = self.tower.forward(x, B, T, causal=False)
         if self.split:
             h = N.layernorm(x, *self.ln_post, out_split=N.Split(B * T, W, img.device))
-            kv = N.linear3(h, self.s_kv, self.b_kv)
+            kv = N.linear3(h, self.s_kv, hd.b_kv)
         else:
-            kv = N.linear(N.layernorm(x, *self.ln_post), self.w_kv, self.b_kv)
-        pooled = N.attention_pool(self.q_probe, kv, B, T, self.heads, self.head_dim)  # (B, W)
-        res = N.linear(pooled, self.w_ho, self.b_ho)
-        hid = N.linear(N.layernorm(res, *self.ln_head), self.w_h1, self.b_h1, act=self.head_act)
-        return N.linear(hid, self.w_h2, self.b_h2, residual=res, out=res)
+            kv = N.linear(N.layernorm(x, *self.ln_post), hd.w_kv, hd.b_kv)
+        pooled = N.attention_pool(hd.q_probe, kv, B, T, hd.heads, hd.head_dim)  # (B, W)
+        res = N.linear(pooled, hd.w_o, hd.b_o)
+        hid = N.linear(N.layernorm(res, *hd.ln), hd.w1, hd.b1, act=hd.act)
+        out = N.linear(hid, hd.w2, hd.b2, residual=res, out=res)
+        return N.linear(out, self.w_final, self.b_final) if self.w_final is not None else out
 
 
 class NativeSigLipText:
-    """Text tower: token + position embeddings, NON-causal blocks (SigLIP pads to the context length and does not mask),
-    ``final_layer_norm``, the LAST position pooled, then the ``head`` Linear (with bias)."""
+    """transformers ``SiglipTextTransformer``: token + position embeddings, NON-causal blocks (SigLIP pads to the context
+    length and does not mask), ``final_layer_norm``, the LAST position pooled, then the ``head`` Linear (with bias)."""
 
     def __init__(self, tm: nn.Module, cfg, device, split: bool):
         self.table = _f32(tm.embeddings.token_embedding.weight, device)
         self.pos = _f32(tm.embeddings.position_embedding.weight, device)
-        self.tower = _SigLipStack(tm.encoder.layers, cfg.num_attention_heads, _act_code(getattr(cfg, "hidden_act", "")), device, split)
-        ln = tm.final_layer_norm
-        self.ln_final = (_f32(ln.weight, device), _f32(ln.bias, device), ln.eps)
+        act = _act_code(getattr(cfg, "hidden_act", ""))
+        self.tower = _Tower([_read_hf_siglip_block(b, cfg.num_attention_heads, act, device) for b in tm.encoder.layers], split)
+        self.ln_final = _ln(tm.final_layer_norm, device)
         self.w_head, self.b_head = _f32(tm.head.weight, device), _f32(tm.head.bias, device)
 
     @torch.no_grad()
@@ -450,18 +623,21 @@ class NativeSigLipText:
 class NativeSigLip(AbstractVLM):
     """``AbstractVLM`` running the towers of a SigLIP-layout model on HIP kernels.
 
-    ``base`` is an ``AbstractVLM`` whose ``.model`` follows transformers' ``SiglipModel`` layout (``vision_model`` /
-    ``text_model``; the geometry of SigLIP-so400m — width 1152, head_dim 72, MAP pooling — is what BASELINE configs[3]
-    names).  Tokenizer and host preprocessing stay ``base``'s; ``preprocess`` as for :class:`NativeClip`.  open_clip's own
-    timm-based SigLIP modules use other attribute names and are not mapped (open_clip / timm are absent here, so such a
-    mapping could not be tested)."""
+    ``base.model`` is either what the reference's ``SigLipV2`` constructs (foundation_models/clip.py:190-211: open_clip's
+    ``CustomTextCLIP`` — ``visual`` = ``TimmModel`` around a timm ViT trunk with a MAP head, ``text`` = open_clip's
+    ``TextTransformer``, non-causal, pooled at the last position, projection with bias) or transformers' ``SiglipModel``
+    (``vision_model`` / ``text_model``; the geometry of SigLIP-so400m — width 1152, head_dim 72 — is what BASELINE
+    configs[3] names).  Tokenizer and host preprocessing stay ``base``'s; ``preprocess`` as for :class:`NativeClip`."""
 
     def __init__(self, base, device=None, gemm: str = "bf16x3", preprocess=None):
         if gemm not in ("bf16x3", "f32"):
             raise ValueError("gemm must be 'bf16x3' or 'f32'")
         model = base.model
-        if not (hasattr(model, "vision_model") and hasattr(model, "text_model") and hasattr(model.vision_model, "head")):
-            raise TypeError("NativeSigLip expects a model with `vision_model` (with a MAP `head`) and `text_model`")
+        hf = hasattr(model, "vision_model") and hasattr(model, "text_model") and hasattr(model.vision_model, "head")
+        oc = hasattr(model, "visual") and hasattr(model.visual, "trunk") and hasattr(model, "text") and hasattr(model.text, "transformer")
+        if not (hf or oc):
+            raise TypeError("NativeSigLip expects transformers' SiglipModel layout (`vision_model` with a MAP `head`, `text_model`) "
+                            "or open_clip's CustomTextCLIP layout (`visual.trunk` = timm ViT, `text` = TextTransformer)")
         dev = torch.device(device) if device is not None else next(model.parameters()).device
         if dev.type != "cuda":
             dev = N.default_device()
@@ -469,8 +645,14 @@ class NativeSigLip(AbstractVLM):
         self.base = base
         base.to(dev)
         split = gemm == "bf16x3"
-        self.vision = NativeSigLipVision(model.vision_model, model.config.vision_config, dev, split)
-        self.text = NativeSigLipText(model.text_model, model.config.text_config, dev, split)
+        if hf:
+            self.vision = NativeSigLipVision.from_transformers(model.vision_model, model.config.vision_config, dev, split)
+            self.text = NativeSigLipText(model.text_model, model.config.text_config, dev, split)
+        else:
+            self.vision = NativeSigLipVision.from_open_clip_timm(model.visual, dev, split)
+            text = model.text
+            self.text = NativeTextTower(text, text.transformer.resblocks, dev, split, pool=getattr(text, "pool_type", "argmax"),
+                                        causal=getattr(text, "attn_mask", None) is not None)
         self.name = f"native-{gemm}-" + getattr(base, "name", type(base).__name__)
         if preprocess == "device":
             from semanticlens_amd.foundation_models.preprocess import DevicePreprocess
@@ -501,3 +683,11 @@ class NativeSigLip(AbstractVLM):
 
     def tokenize(self, txt, *args, **kwargs):
         return self.base.tokenize(txt, *args, **kwargs)
+
+
+def native_model(base, gemm: str = "bf16x3", preprocess=None):
+    """The native counterpart of a wrapped open_clip / transformers model, chosen by its module layout."""
+    model = base.model
+    if hasattr(model, "vision_model") or hasattr(getattr(model, "visual", None), "trunk"):
+        return NativeSigLip(base, gemm=gemm, preprocess=preprocess)
+    return NativeClip(base, gemm=gemm, preprocess=preprocess)

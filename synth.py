@@ -360,3 +360,35 @@ class SyntheticSigLip(AbstractVLM):
             ids = [2 + (hash_str(w) % (self.vocab - 2)) for w in s_.lower().split()][:ctx]
             out[r, : len(ids)] = torch.tensor(ids, dtype=torch.int64)
         return out.to(self.device)
+
+
+# ------------------------------------------------------------------------------------------------
+# probed model of BASELINE configs[3]: ViT-B/16 (random init), encoder blocks named ``blocks.<i>``
+# ------------------------------------------------------------------------------------------------
+class VisionTransformer(nn.Module):
+    """ViT-B/16 classifier geometry: 16x16 patches of a 224x224 image + class token = 197 tokens of width 768, 12 pre-LN
+    blocks (12 heads, MLP 3072), LayerNorm, linear head.  Every ``blocks.<i>`` outputs ``(B, 197, 768)``."""
+
+    def __init__(self, image_size=224, patch=16, width=768, layers=12, heads=12, num_classes=1000):
+        super().__init__()
+        self.patch_embed = nn.Conv2d(3, width, patch, patch)
+        n_tok = (image_size // patch) ** 2 + 1
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, width))
+        self.pos_embed = nn.Parameter(0.02 * torch.randn(1, n_tok, width))
+        self.blocks = nn.ModuleList([_Block(width, heads) for _ in range(layers)])
+        self.norm = nn.LayerNorm(width)
+        self.head = nn.Linear(width, num_classes)
+
+    def forward(self, x):
+        x = self.patch_embed(x).flatten(2).transpose(1, 2)
+        x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], 1) + self.pos_embed
+        for blk in self.blocks:
+            x = blk(x)
+        return self.head(self.norm(x[:, 0]))
+
+
+def vit_b16(seed: int = 0, **arch) -> nn.Module:
+    torch.manual_seed(seed)
+    m = VisionTransformer(**arch).eval()
+    m.name = "vit-b16-random"
+    return m

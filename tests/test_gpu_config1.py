@@ -1,0 +1,100 @@
+"""BASELINE configs[1] end to end under pytest: ResNet-50 (random init) layer2-4 + CLIP ViT-B/32 (random init, native towers)
+through `Lens.compute_concept_db` — the reference's call (lens.py:278-329 -> activation_based.py:360-390) — over 768 synthetic
+images at the bench batch size, in both tie modes, against the CPU oracle:
+
+* top-k values and sample ids of every layer bit-equal to the oracle's aggregate + ActMax restatement fed the SAME device
+  activations (streamed out of the forward by tap hooks);
+* the returned concept_db equal to the oracle's gather of the embedding table;
+* the native encoder's embeddings within 1e-4 of the torch module's (north_star tolerance).
+
+`bench.py::self_check` runs the same comparison on the bench's own loop; this is the API path with host `Dataset`s."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import synth
+from semanticlens_amd import Lens
+from semanticlens_amd.component_visualization import ActivationComponentVisualizer, aggregators
+from semanticlens_amd.foundation_models.native_clip import NativeClip
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+LAYERS = ["layer2", "layer3", "layer4"]
+WIDTHS = {"layer2": 512, "layer3": 1024, "layer4": 2048}
+N_IMAGES, BATCH, K = 768, 256, 20
+
+
+@pytest.fixture(scope="module")
+def world():
+    model = synth.resnet50().to(DEV)
+    base = synth.SyntheticClip(device=DEV)
+    u8 = torch.cat([synth.synth_images_u8(torch.arange(s, s + BATCH, device=DEV)).cpu() for s in range(0, N_IMAGES, BATCH)])
+
+    class DS(torch.utils.data.Dataset):
+        def __init__(self, mode):
+            self.mode, self.name = mode, f"configs1-{N_IMAGES}"
+
+        def __len__(self):
+            return N_IMAGES
+
+        def __getitem__(self, i):
+            if self.mode == "model":
+                return synth.normalize_u8(u8[i:i + 1], synth.IMAGENET_MEAN, synth.IMAGENET_STD)[0], 0
+            return u8[i]
+
+    return model, base, DS
+
+
+@pytest.mark.parametrize("single_pass", [False, True])
+@pytest.mark.parametrize("tie_mode", ["aten", "total"])
+def test_configs1_concept_db_matches_oracle(world, tie_mode, single_pass):
+    model, base, DS = world
+    fm = NativeClip(base)
+    cv = ActivationComponentVisualizer(model, DS("model"), DS("fm"), LAYERS, num_samples=K, aggregate_fn=aggregators.aggregate_conv_max,
+                                       tie_mode=tie_mode)
+    mode = oracle.MODE_ATEN if tie_mode == "aten" else oracle.MODE_TOTAL
+    refs, seen = {}, {n: 0 for n in LAYERS}
+
+    def tap(name):
+        def fn(m, i, o):  # the oracle's side of the comparison, streamed: host aggregate + host top-k on the same activations
+            a = oracle.agg_conv(o.detach().cpu().numpy(), "max")
+            refs.setdefault(name, oracle.ActMaxOracle(K, a.shape[1], mode)).update(a, np.arange(seen[name], seen[name] + a.shape[0]))
+            seen[name] += a.shape[0]
+
+        return fn
+
+    taps = [getattr(model, n).register_forward_hook(tap(n)) for n in LAYERS]
+    try:
+        db = Lens(fm, device=DEV).compute_concept_db(cv, batch_size=BATCH, single_pass=single_pass)
+    finally:
+        for h in taps:
+            h.remove()
+    assert all(seen[n] == N_IMAGES for n in LAYERS)
+    embeds = cv._embed_vision_dataset(fm, BATCH).cpu().numpy()  # same batches, same kernels: the table the build gathered from
+    assert embeds.shape == (N_IMAGES, 512)
+    for name in LAYERS:
+        am, ref = cv.actmax_cache.cache[name], refs[name]
+        assert am.activations.shape == (WIDTHS[name], K)
+        assert np.array_equal(am.activations.view(torch.int16).numpy().view(np.uint16), ref.vals), (name, "values")
+        assert np.array_equal(am.sample_ids.numpy(), ref.ids), (name, "ids")
+        assert db[name].shape == (WIDTHS[name], K, 512) and db[name].device.type == "cpu"
+        assert np.array_equal(db[name].numpy(), oracle.gather_rows(embeds, ref.ids)), (name, "concept_db")
+    # every stored id is a real sample and no component lists a sample twice
+    for name in LAYERS:
+        ids = cv.get_max_reference(name).numpy()
+        assert ids.min() >= 0 and ids.max() < N_IMAGES
+        assert all(len(set(row)) == K for row in ids[:64])
+
+
+def test_configs1_native_embeddings_within_tolerance_of_the_torch_module(world):
+    """north_star: embedding values within 1e-4 (fp32) — NativeClip (split-bf16 x3 and fp32-MFMA GEMMs) vs the torch ViT-B/32."""
+    model, base, DS = world
+    ds = DS("fm")
+    u8 = torch.stack([ds[i] for i in range(BATCH)]).to(DEV)
+    x = base.preprocess(u8)
+    want = base.encode_image(x)
+    scale = want.abs().max().item()
+    for gemm in ("bf16x3", "f32"):
+        got = NativeClip(base, gemm=gemm).encode_image(x)
+        assert (got - want).abs().max().item() < 1e-4 * scale, gemm

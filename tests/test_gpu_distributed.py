@@ -138,11 +138,11 @@ def _bench_line(extra_env, args, nproc):
 def test_bench_two_ranks_sharing_one_gpu_over_gloo():
     """BASELINE configs[2] code path (`bench.py --gpus N`): per-rank collect, packed all-gather, K4 merge, sharded K5
     gather + all-reduce, max-over-ranks timing — with two ranks on ONE GPU and gloo as the transport."""
-    line = _bench_line({"SL_BENCH_BACKEND": "gloo", "SL_BENCH_SHARE_GPU": "1"}, ["--steps", "3", "--warmup", "1", "--batch", "64", "--min-warmup-seconds", "0.3"], 2)
+    line = _bench_line({"SL_BENCH_BACKEND": "gloo", "SL_BENCH_SHARE_GPU": "1"}, ["--steps", "3", "--batches-per-step", "2", "--warmup", "1", "--batch", "64", "--min-warmup-seconds", "0.3"], 2)
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
-    assert line["config"]["images_total"] == 2 * 3 * 64 and line["value"] > 0
+    assert line["config"]["images_total"] == 2 * 3 * 2 * 64 and line["value"] > 0
     line = _bench_line({"SL_BENCH_BACKEND": "gloo", "SL_BENCH_SHARE_GPU": "1"},
-                       ["--scaling", "strong", "--images", "500", "--warmup", "1", "--batch", "64", "--min-warmup-seconds", "0"], 2)
+                       ["--scaling", "strong", "--images", "500", "--batches-per-step", "1", "--warmup", "1", "--batch", "64", "--min-warmup-seconds", "0"], 2)
     assert line["scaling"] == "strong" and line["config"]["images_total"] == 500 and line["steps"] == 4
 
 
@@ -244,3 +244,70 @@ def test_sharded_probing_and_scores_equal_single_process(world, tmp_path):
         for k, v in want.items():
             assert got[k].shape == v.shape, (world, r, k)
             assert np.array_equal(got[k], v), (world, r, k, np.abs(got[k] - v).max())
+
+
+# ---- the RCCL transport on ONE GPU: a world_size=1 "nccl" process group ------------------------------------------------
+def _nccl_single_worker(rank, world, port, out_dir):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(__file__))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(__file__)))
+    from semanticlens_amd import distributed as sld
+    from semanticlens_amd import scores
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        assert dist.get_backend() == "nccl" and not sld._host_staged(None)
+        cv, fm = _build(device=dev)
+        db = sld.compute_concept_db_sharded(cv, fm, batch_size=8)
+        cv2, fm2 = _build(device=dev)
+        db_ref = sld.compute_concept_db_sharded(cv2, fm2, batch_size=8, referenced_only=True)
+        # the collectives themselves, on device buffers: packed-state all-gather, sharded gather + all-reduce, row all-gather
+        states = [cv.actmax_cache.cache[k].device_state(dev) for k in ("0", "2")]
+        gathered = sld.all_gather_states(states)
+        assert all(g[0].is_cuda and g[0].shape[0] == 1 for g in gathered)
+        for (v, i), (gv, gi) in zip(states, gathered):
+            assert torch.equal(gv[0].view(torch.int16), v.view(torch.int16)) and torch.equal(gi[0], i)
+        rows = torch.arange(35, dtype=torch.float32, device=dev).reshape(7, 5)
+        assert torch.equal(sld.all_gather_rows(rows, 7), rows)
+        fm_a, db_a, V, queries, templates = _analysis_inputs()
+        out = {f"tpl_{k}": v.cpu().numpy() for k, v in sld.text_probing_sharded(fm_a, queries, db_a, templates=templates, batch_size=3).items()}
+        out["clarity"] = sld.eval_sharded(scores.clarity_score, V).cpu().numpy()
+        np.savez(os.path.join(out_dir, "nccl1.npz"), **{f"db_{k}": v.cpu().numpy() for k, v in db.items()},
+                 **{f"dbref_{k}": v.cpu().numpy() for k, v in db_ref.items()},
+                 **{f"ids_{k}": cv.get_max_reference(k).numpy() for k in db}, **out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_build_over_rccl_world_size_one(tmp_path):
+    """The device-buffer branch of `distributed.py` (`all_gather_states`, `gather_concept_db_sharded`, `all_gather_rows`:
+    collectives issued on HBM tensors, no host staging) under the production backend "nccl" (= RCCL) with a one-rank
+    group — what a 1-GPU box can execute of configs[2]'s transport.  Results equal the plain single-process build."""
+    from semanticlens_amd import Lens, scores
+
+    cv, fm = _build()
+    want = cv._compute_concept_db(fm, batch_size=8)
+    mp.spawn(_nccl_single_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    got = np.load(tmp_path / "nccl1.npz")
+    for k in ("0", "2"):
+        assert np.array_equal(got[f"ids_{k}"], cv.get_max_reference(k).numpy()), k
+        assert np.array_equal(got[f"db_{k}"], want[k].numpy()), k
+        assert np.array_equal(got[f"dbref_{k}"], want[k].numpy()), (k, "referenced_only")
+    fm_a, db_a, V, queries, templates = _analysis_inputs()
+    probe = Lens(fm_a, device="cuda:0").text_probing(queries, db_a, templates=templates, batch_size=3)
+    for k, v in probe.items():
+        assert np.array_equal(got[f"tpl_{k}"], v.cpu().numpy()), k
+    assert np.array_equal(got["clarity"], scores.clarity_score(V).cpu().numpy())
+
+
+def test_bench_distributed_path_over_rccl_on_one_gpu():
+    """`bench.py` with SL_BENCH_FORCE_DIST=1: a one-rank nccl group, so the N > 1 code of the bench (barriers, packed all-gather,
+    K4 merge, sharded K5 + all-reduce, max-over-ranks timing) runs over RCCL on the 1-GPU box."""
+    line = _bench_line({"SL_BENCH_FORCE_DIST": "1"}, ["--steps", "2", "--batches-per-step", "2", "--warmup", "1", "--batch", "64",
+                                                        "--min-warmup-seconds", "0.3", "--quick"], 1)
+    assert line["n_gpus"] == 1 and line["config"]["collectives"].startswith("torch.distributed (RCCL)")
+    assert line["config"]["images_total"] == 2 * 2 * 64 and line["value"] > 0 and line["self_check"] == "ok"

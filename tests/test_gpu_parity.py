@@ -343,6 +343,40 @@ def test_token_reduce_vs_oracle(shape):
         assert feq(agg.aggregate_transformer_max(sl).numpy(), oracle.agg_tokens(x[:, :, : F // 2].contiguous().numpy(), "max"))
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("T", [8, 24, 48, 144, 197, 576, 1024, 7, 13])
+def test_token_reduce_transposed_half_precision(T, dt):
+    """(B, T, F) views with the TOKEN axis contiguous (timm / ViT `patch_embed`: `flatten(2).transpose(1, 2)`) in fp16 /
+    bf16 run rowreduce_h over rows of T elements.  T % 8 == 0 takes the whole-piece path, where lanes without a piece
+    contribute a fill value: it must be neutral for every aggregator (round 2 filled absmax with |-inf| = +inf when
+    T / 8 was not a power of two).  max / absmax exact, means within one ulp of the activation dtype."""
+    B, F = 3, 40
+    rng = np.random.RandomState(T + (0 if dt == torch.float16 else 1))
+    base = torch.from_numpy(rng.randn(B, F, T).astype(np.float32)).to(dt)  # (B, F, T) contiguous
+    base[0, 1, T // 2] = float("nan")
+    base[1, 2, :] = -float("inf")
+    base[2, 3, T - 1] = -float("inf")
+    base[2, 5, 0] = float("inf")
+    x = base.transpose(1, 2)  # (B, T, F) with st == 1, sf == T
+    xd = base.to(DEV).transpose(1, 2)
+    assert xd.stride() == (F * T, 1, T)
+    ulp = 2.0 ** -10 if dt == torch.float16 else 2.0 ** -7
+    xf = x.float().contiguous().numpy()
+    for name in ("max", "absmax", "mean", "absmean"):
+        got = getattr(agg, f"aggregate_transformer_{name}")(xd)
+        assert got.dtype == dt
+        got = got.float().numpy()
+        want = oracle.agg_tokens(xf, name)
+        if "mean" in name:
+            want = torch.from_numpy(want).to(dt).float().numpy()  # one rounding to the activation dtype
+            assert np.array_equal(np.isnan(got), np.isnan(want)), (name, T)
+            fin = np.isfinite(want)
+            np.testing.assert_allclose(got[fin], want[fin], rtol=ulp, atol=1e-6, err_msg=f"{name} T={T}")
+            assert np.array_equal(got[~fin & ~np.isnan(want)], want[~fin & ~np.isnan(want)]), (name, T)
+        else:
+            assert feq(got, want), (name, T, dt)
+
+
 def test_aggregator_goldens(golden):
     g = golden("aggregators")
     for tag in ("x4a", "x4b", "x4c", "x4n"):
@@ -647,6 +681,34 @@ def test_polysemanticity_any_n_clusters_vs_sklearn(C, n, D, k, kind):
     assert_polysemanticity_matches(got, V, f"{kind} k={k}", n_clusters=k)
     with pytest.raises(ValueError):  # sklearn: n_samples should be >= n_clusters
         scores.polysemanticity_score(torch.from_numpy(V[:, :2]).to(DEV), n_clusters=3)
+
+
+def test_polysemanticity_chunks_components_and_reports_limits(monkeypatch):
+    """The reference loops over components on the host and has no size limit (scores.py:167).  The device kernels take
+    <= 65 535 components per launch inside a workspace budget: the wrapper chunks the component axis — same scores as one
+    launch — and the two limits that remain (n_samples > 1024, n_clusters > 16) are ValueErrors, not native failures."""
+    rng = np.random.RandomState(5)
+    V = torch.from_numpy(rng.randn(150, 12, 16).astype(np.float32)).to(DEV)
+    Vdup = V.clone()
+    Vdup[:20, 1:] = Vdup[:20, :1]  # all-duplicate rows (dead components: every reference sample the same)
+    for X in (V, Vdup):
+        for k in (2, 3):
+            monkeypatch.delenv("SL_POLY_WS_GB", raising=False)
+            whole = scores.polysemanticity_score(X, n_clusters=k)
+            whole_raw = scores.polysemanticity_score(X, n_clusters=k, replace_empty_clusters=False)
+            monkeypatch.setenv("SL_POLY_WS_GB", "1e-4")  # ~100 KB: a handful of components per launch
+            assert torch.equal(scores.polysemanticity_score(X, n_clusters=k), whole)
+            monkeypatch.setattr(N, "POLYK_MAX_COMPONENTS", 7)
+            assert torch.equal(scores.polysemanticity_score(X, n_clusters=k, replace_empty_clusters=False), whole_raw)
+            monkeypatch.undo()
+    # every centre of an all-duplicate component coincides: polysemanticity 0 without the fallback, for any k
+    raw = scores.polysemanticity_score(Vdup[:20], n_clusters=4, replace_empty_clusters=False).cpu().numpy()
+    np.testing.assert_allclose(raw, 0.0, atol=1e-9)
+    with pytest.raises(ValueError, match="n_clusters=17"):
+        scores.polysemanticity_score(torch.zeros(2, 40, 4, device=DEV), n_clusters=17)
+    with pytest.raises(ValueError, match="n_samples=1025"):
+        scores.polysemanticity_score(torch.zeros(1, 1025, 4, device=DEV), n_clusters=3)
+    assert scores.polysemanticity_score(torch.zeros(0, 5, 4, device=DEV)).shape == (0,)
 
 
 def test_probe_dict_uses_one_native_call_and_matches_per_layer():
