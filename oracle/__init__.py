@@ -108,11 +108,13 @@ def agg_tokens(x, agg: str, pos: int = 0) -> np.ndarray:
 class ActMaxOracle:
     """ActMax (activation_caching.py:64-141) with bf16 values kept as uint16 bit patterns."""
 
-    def __init__(self, n_collect: int, n_latents: int, mode: int = MODE_ATEN):
+    def __init__(self, n_collect: int, n_latents: int, mode: int = MODE_ATEN, init_value: float | None = None):
         self.k, self.C, self.mode = int(n_collect), int(n_latents), mode
         self.vals = np.empty((self.C, self.k), dtype=np.uint16)
         self.ids = np.empty((self.C, self.k), dtype=np.int64)
         lib().orc_actmax_init(_p(self.vals), _p(self.ids), _I(self.C), _I(self.k))
+        if init_value is not None:  # the build's relevance visualizer starts signed quantities at -inf (reference: -0.0)
+            self.vals[:] = f32_to_bf16(np.full((1,), init_value, dtype=np.float32))[0]
 
     def update(self, acts, sample_ids):
         acts = _f32(acts)

@@ -80,11 +80,13 @@ def test_configs1_concept_db_matches_oracle(world, tie_mode, single_pass):
         assert np.array_equal(am.sample_ids.numpy(), ref.ids), (name, "ids")
         assert db[name].shape == (WIDTHS[name], K, 512) and db[name].device.type == "cpu"
         assert np.array_equal(db[name].numpy(), oracle.gather_rows(embeds, ref.ids)), (name, "concept_db")
-    # every stored id is a real sample and no component lists a sample twice
+    # every stored id is a real sample (or the -1 of a never-filled slot: a dead ReLU channel's +0.0 does not beat the -0.0
+    # sentinel, as in the reference) and no component lists a sample twice
     for name in LAYERS:
         ids = cv.get_max_reference(name).numpy()
-        assert ids.min() >= 0 and ids.max() < N_IMAGES
-        assert all(len(set(row)) == K for row in ids[:64])
+        assert ids.min() >= -1 and ids.max() < N_IMAGES
+        assert all(len(set(row[row >= 0])) == (row >= 0).sum() for row in ids)
+        assert (ids >= 0).mean() > 0.9
 
 
 def test_configs1_native_embeddings_within_tolerance_of_the_torch_module(world):

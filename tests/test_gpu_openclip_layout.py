@@ -17,7 +17,9 @@ from semanticlens_amd.foundation_models.native_clip import NativeClip, NativeSig
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-TOL = 1e-5
+# fp32-MFMA GEMMs: 1e-5 of the feature scale.  split-bf16 x3 drops the lo*lo term (2^-16 per product): 1.0-1.9e-5 on these
+# towers, whose weights are drawn larger than a trained model's to make every bias / gamma count; north_star allows 1e-4.
+TOL = {"f32": 1e-5, "bf16x3": 3e-5}
 
 SMALL = dict(embed_dim=64, image_size=64, patch=16, v_width=128, v_layers=2, v_heads=2, ctx=16, vocab=1000, t_width=128, t_layers=2, t_heads=2)
 
@@ -48,7 +50,7 @@ class Wrapped:
 PROMPTS = ["a photo of a cat", "dog", "a very long prompt with many many words in it " * 3, "two red wheels on a cart"]
 
 
-def check_towers(base, nat, image_size, embed_dim):
+def check_towers(base, nat, image_size, embed_dim, tol):
     g = torch.Generator(device=DEV).manual_seed(1)
     img = torch.randn(6, 3, image_size, image_size, device=DEV, generator=g)
     with torch.no_grad():
@@ -58,8 +60,8 @@ def check_towers(base, nat, image_size, embed_dim):
     got_i, got_t = nat.encode_image(img), nat.encode_text(tok)
     assert got_i.shape == want_i.shape == (6, embed_dim) and got_i.dtype == torch.float32
     assert got_t.shape == want_t.shape == (len(PROMPTS), embed_dim)
-    assert rel_err(got_i, want_i) < TOL, ("image", rel_err(got_i, want_i))
-    assert rel_err(got_t, want_t) < TOL, ("text", rel_err(got_t, want_t))
+    assert rel_err(got_i, want_i) < tol, ("image", rel_err(got_i, want_i))
+    assert rel_err(got_t, want_t) < tol, ("text", rel_err(got_t, want_t))
     return got_i, got_t
 
 
@@ -86,7 +88,7 @@ def test_native_clip_reads_the_open_clip_attribute_tree(variant, gemm):
     assert type(nat.vision).__name__ == "NativeVisionTower" and nat.text is not None
     assert nat.vision.pool == cfg.get("pool_type", "tok") and nat.text.pool == cfg.get("text_pool_type", "argmax")
     assert nat.text.causal == (not cfg.get("no_causal_mask", False))
-    check_towers(base, nat, cfg["image_size"], cfg["embed_dim"])
+    check_towers(base, nat, cfg["image_size"], cfg["embed_dim"], TOL[gemm])
     if nat.text.pool == "argmax":  # truncation after the last end-of-text token and the pooled-row shortcut keep every bit
         tok = base.tokenize(PROMPTS[:2])
         fast = nat.encode_text(tok)
@@ -113,7 +115,7 @@ def test_open_clip_wrapper_native_full_vit_b32(monkeypatch, gemm):
     assert tok.shape == (4, 77)
     want_i, want_t = fm.encode_image(img), fm.encode_text(tok)
     got_i, got_t = nat.encode_image(img), nat.encode_text(tok)
-    assert rel_err(got_i, want_i) < TOL and rel_err(got_t, want_t) < TOL, (rel_err(got_i, want_i), rel_err(got_t, want_t))
+    assert rel_err(got_i, want_i) < TOL[gemm] and rel_err(got_t, want_t) < TOL[gemm], (rel_err(got_i, want_i), rel_err(got_t, want_t))
     cos = torch.nn.functional.cosine_similarity(got_i, want_i, dim=-1)
     assert (1 - cos).abs().max().item() < 1e-6
     # host preprocessing and tokenizer stay the wrapped object's
@@ -136,7 +138,7 @@ def test_native_siglip_reads_custom_text_clip_with_timm_trunk(geom, gemm):
     base = Wrapped(model, geom["ctx"], geom["vocab"], eot=None)
     nat = NativeSigLip(base, gemm=gemm)
     assert nat.text.pool == "last" and not nat.text.causal and nat.text.b_proj is not None
-    check_towers(base, nat, geom["image_size"], geom["embed_dim"])
+    check_towers(base, nat, geom["image_size"], geom["embed_dim"], TOL[gemm])
     assert isinstance(native_model(base, gemm=gemm), NativeSigLip)
 
 
@@ -160,7 +162,7 @@ def test_siglipv2_wrapper_native_b16_geometry(monkeypatch):
     assert tok.shape == (4, 64)
     want_i, want_t = fm.encode_image(img), fm.encode_text(tok)
     got_i, got_t = nat.encode_image(img), nat.encode_text(tok)
-    assert rel_err(got_i, want_i) < TOL and rel_err(got_t, want_t) < TOL, (rel_err(got_i, want_i), rel_err(got_t, want_t))
+    assert rel_err(got_i, want_i) < TOL["bf16x3"] and rel_err(got_t, want_t) < TOL["bf16x3"], (rel_err(got_i, want_i), rel_err(got_t, want_t))
     db = {"layer": torch.randn(50, 768, generator=torch.Generator().manual_seed(0))}
     p_nat = Lens(nat, device=DEV).text_probing(["cat", "dog", "zebra"], db)["layer"]
     p_ref = Lens(fm, device=DEV).text_probing(["cat", "dog", "zebra"], db)["layer"]

@@ -81,8 +81,8 @@ def test_collect_at_convnext_l_stage_shapes_vs_oracle(shape, abs_norm):
     model.name = "stub"
     ds = TensorPairDataset(torch.zeros(3 * B, 3, 2, 2))
     cv = RelevanceComponentVisualizer(model.to(DEV), ds, ds, ["0"], num_samples=k, abs_norm=abs_norm, tie_mode="aten")
-    ref_rel = oracle.ActMaxOracle(k, C, oracle.MODE_ATEN)
-    ref_act = oracle.ActMaxOracle(k, C, oracle.MODE_ATEN)
+    ref_rel = oracle.ActMaxOracle(k, C, oracle.MODE_ATEN, init_value=-np.inf)  # signed quantities: empty slots start at -inf
+    ref_act = oracle.ActMaxOracle(k, C, oracle.MODE_ATEN, init_value=-np.inf)
     g = torch.Generator().manual_seed(C)
     for step in range(3):
         rel = torch.randint(-3, 4, shape, generator=g).to(torch.float32)
@@ -105,7 +105,7 @@ def test_end_to_end_gradient_x_activation_equals_cpu_autograd_plus_oracle(tmp_pa
     layers = ["relu1", "relu2"]
     # CPU: plain autograd with the same attribution rule, then the oracle
     cpu_model = _IntNet()
-    refs = {name: (oracle.ActMaxOracle(k, c, oracle.MODE_ATEN), oracle.ActMaxOracle(k, c, oracle.MODE_ATEN))
+    refs = {name: (oracle.ActMaxOracle(k, c, oracle.MODE_ATEN, init_value=-np.inf), oracle.ActMaxOracle(k, c, oracle.MODE_ATEN, init_value=-np.inf))
             for name, c in (("relu1", 6), ("relu2", 5))}
     mods = {nme: m for nme, m in cpu_model.named_modules() if nme in layers}
     for s in range(0, n, bs):
@@ -171,9 +171,30 @@ def test_token_layers_and_label_targets():
     cv.run(batch_size=5)
     per = gradient_x_activation(ref_model, {"proj": ref_model.proj}, x, torch.arange(10) % 3)
     act, rel = per["proj"]
-    want = oracle.ActMaxOracle(4, 8, oracle.MODE_TOTAL)
+    want = oracle.ActMaxOracle(4, 8, oracle.MODE_TOTAL, init_value=-np.inf)
     want.update(rel.sum(1).numpy(), np.arange(10))
     got = cv.actmax_cache.cache["proj"]
     # real-valued: compare the kept values to 1 bf16 ulp and the ids wherever the kept values are not tied
     gv, wv = got.activations.float().numpy(), oracle.bf16_to_f32(want.vals)
     assert np.allclose(gv, wv, rtol=2 ** -7, atol=1e-6)
+
+
+def test_negative_relevance_is_ranked_not_padded_with_minus_one():
+    """Relevance is signed.  With the reference's -0.0 initial state a component with fewer than `num_samples` non-negative
+    relevances kept id -1 in the remaining slots (which the concept-DB gather wraps to the LAST dataset row); crp ranks the
+    negative values (argsort descending).  The relevance-mode and activation-mode states start at -inf."""
+    model = nn.Sequential(nn.Conv2d(3, 4, 1))
+    model.name = "stub"
+    ds = TensorPairDataset(torch.zeros(12, 3, 2, 2))
+    for mode in ("aten", "total"):
+        cv = RelevanceComponentVisualizer(model.to(DEV), ds, ds, ["0"], num_samples=5, abs_norm=True, tie_mode=mode)
+        rel = -(torch.arange(12 * 3, dtype=torch.float32).reshape(12, 3, 1, 1) + 1)  # every relevance negative, all distinct
+        rel[:, 2] *= -1  # one positive component
+        cv.collect_relevance("0", rel.abs().to(DEV), rel.to(DEV), torch.arange(12))
+        ids = cv.get_max_reference("0")
+        assert ids.min().item() >= 0, mode
+        vals = cv.actmax_cache.cache["0"].activations.float()
+        assert (vals[:2] < 0).all() and (vals[2] > 0).all() and torch.isfinite(vals).all()
+        want = oracle.ActMaxOracle(5, 3, oracle.MODE_ATEN if mode == "aten" else oracle.MODE_TOTAL, init_value=-np.inf)
+        want.update(oracle.abs_norm_rows(rel.reshape(12, 3).numpy()), np.arange(12))
+        assert np.array_equal(ids.numpy(), want.ids) and np.array_equal(bits(cv.actmax_cache.cache["0"].activations), want.vals)
