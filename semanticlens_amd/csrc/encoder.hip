@@ -45,7 +45,22 @@ struct LinearEpi {
   const float* rowadd;         // REMAP: (roff + r % rpg, col) of this (T, N) table is added (positional embedding)
   int64_t N;
   __device__ inline float column(int64_t col) const { return bias ? bias[col] : 0.f; }
-  __device__ inline void store(int64_t row, int64_t col, float acc, float b) const {
+  // what `store` adds from memory, fetched ahead of the stores by kernels that batch their epilogue (gemm_8phase.hpp);
+  // `store_fetched(..., fetch(row, col))` == `store(...)` bit for bit (same operands, same order of additions)
+  static constexpr bool kFetches = RES || REMAP;
+  __device__ inline int64_t out_row(int64_t row) const {
+    if constexpr (REMAP) return (row / rpg) * gstride + roff + row % rpg;
+    return row;
+  }
+  __device__ inline float2 fetch(int64_t row, int64_t col) const {  // (positional-table value, residual value)
+    float2 f = make_float2(0.f, 0.f);
+    if constexpr (REMAP) {
+      if (rowadd) f.x = rowadd[(roff + row % rpg) * N + col];
+    }
+    if constexpr (RES) f.y = res[out_row(row) * ldo + col];
+    return f;
+  }
+  __device__ inline void store_fetched(int64_t row, int64_t col, float acc, float b, float2 f) const {
     float v = acc + b;
     if constexpr (ACT == SL_ACT_GELU) v = 0.5f * v * (1.f + erf_as(v * 0.70710678118654752440f));
     if constexpr (ACT == SL_ACT_QUICKGELU) v = v * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v));
@@ -53,16 +68,15 @@ struct LinearEpi {
       const float u = 0.79788456080286535588f * (v + 0.044715f * v * v * v);
       v = 0.5f * v * (2.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * u)));  // 1 + tanh(u); exp overflow -> 2, underflow -> 0
     }
-    int64_t orow = row;
+    const int64_t orow = out_row(row);
     if constexpr (REMAP) {
-      const int64_t g = row / rpg, i = row % rpg;
-      orow = g * gstride + roff + i;
-      if (rowadd) v += rowadd[(roff + i) * N + col];
+      if (rowadd) v += f.x;
     }
-    if constexpr (RES) v += res[orow * ldo + col];
+    if constexpr (RES) v += f.y;
     if constexpr (SPLIT) store_split(v, orow, col, out_kp, out_sp);
     else out[orow * ldo + col] = v;
   }
+  __device__ inline void store(int64_t row, int64_t col, float acc, float b) const { store_fetched(row, col, acc, b, fetch(row, col)); }
 };
 
 template <int ACT, bool RES, bool REMAP>
