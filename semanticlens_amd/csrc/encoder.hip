@@ -26,11 +26,20 @@ using gemm3::store_split4;
 // with erff cost 25 K cycles per tile next to a k loop of 52-78 K (K = 512 / 768): fc1 ran 29 % slower per tile than the
 // plain GEMM.  max |gelu - exact| over [-8, 8] stays 4.7e-7, the same as with a correctly rounded fp32 erf (the final
 // products round at that level).
+// Every multiply-add below is written as an explicit fma and contraction is off: left to the compiler, which mul + add pairs
+// fuse depends on how the surrounding (unrolled) epilogue code was vectorised, so the SAME value came out 1 ulp apart
+// depending on the row's position inside the 256-row tile — and an embedding depended on where its sample sat in the batch
+// (found when a batch was cut in two: rows 4800.. of a 9600-row GEMM vs rows 0.. of a 4800-row one).
 __device__ inline float erf_as(float z) {
+#pragma clang fp contract(off)
   const float a = __builtin_fabsf(z);
-  const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * a);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  return __builtin_copysignf(1.f - poly * __expf(-a * a), z);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, a, 1.f));
+  float p = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+  p = __builtin_fmaf(t, p, 1.421413741f);
+  p = __builtin_fmaf(t, p, -0.284496736f);
+  p = __builtin_fmaf(t, p, 0.254829592f);
+  const float poly = t * p;
+  return __builtin_copysignf(__builtin_fmaf(-poly, __expf(-(a * a)), 1.f), z);
 }
 
 template <int ACT, bool RES, bool REMAP, bool SPLIT = false>
@@ -61,12 +70,17 @@ struct LinearEpi {
     return f;
   }
   __device__ inline void store_fetched(int64_t row, int64_t col, float acc, float b, float2 f) const {
+#pragma clang fp contract(off)  // see erf_as: one rounding sequence per element, whatever code surrounds it
     float v = acc + b;
-    if constexpr (ACT == SL_ACT_GELU) v = 0.5f * v * (1.f + erf_as(v * 0.70710678118654752440f));
+    if constexpr (ACT == SL_ACT_GELU) {
+      const float hv = 0.5f * v;
+      v = __builtin_fmaf(hv, erf_as(v * 0.70710678118654752440f), hv);  // 0.5 v (1 + erf(v / sqrt 2))
+    }
     if constexpr (ACT == SL_ACT_QUICKGELU) v = v * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v));
     if constexpr (ACT == SL_ACT_GELU_TANH) {  // torch gelu(approximate="tanh"): SigLIP's "gelu_pytorch_tanh"
-      const float u = 0.79788456080286535588f * (v + 0.044715f * v * v * v);
-      v = 0.5f * v * (2.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * u)));  // 1 + tanh(u); exp overflow -> 2, underflow -> 0
+      const float u = 0.79788456080286535588f * __builtin_fmaf(0.044715f * v, v * v, v);
+      // 0.5 v (1 + tanh u) = v - v / (1 + exp(2 u)); exp overflow -> v, underflow -> 0
+      v = __builtin_fmaf(-v, __builtin_amdgcn_rcpf(1.f + __expf(2.f * u)), v);
     }
     const int64_t orow = out_row(row);
     if constexpr (REMAP) {

@@ -41,6 +41,7 @@
 // part is power-limited: the 256 x 128 kernel runs 0.60 duty at 2.0 GHz).
 #pragma once
 #include "common.hpp"
+#include "gemm_epilogue.hpp"
 
 namespace sl {
 namespace gemm8 {
@@ -66,15 +67,6 @@ struct IntC {
 
 // An epilogue that reads memory per element (LinearEpi with a residual / positional table) exposes
 // `static constexpr bool kFetches = true`, `fetch(row, col)` and `store_fetched(row, col, acc, column, fetched)`.
-template <class E, class = void>
-struct EpiFetches {
-  static constexpr bool value = false;
-};
-template <class E>
-struct EpiFetches<E, decltype((void)E::kFetches)> {
-  static constexpr bool value = E::kFetches;
-};
-
 __device__ __forceinline__ void wait_vm_pieces(int n) {  // at most n pieces (2 loads each) of this wave still in flight
   switch (n) {
     case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -343,55 +335,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_8phase_kernel(const unsigned c
 #endif
 
   // C/D layout of the 32 x 32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  // (gemm_epilogue.hpp: epilogues that read memory per element fetch the 16 values of an MFMA tile ahead of its stores)
   if (m0 + BM <= M && n0 + BN <= N) {  // interior tile: no per-element predicates
-    if constexpr (EpiFetches<Epi>::value) {
-      // The epilogue adds a value it reads from memory (residual stream, positional rows) and the output may alias that
-      // memory (x += W h in place): written element by element the compiler has to keep every load behind the store in
-      // front of it — 128 dependent round trips per lane, +35 us on a 150-tile GEMM.  Fetch the 16 values of an MFMA
-      // tile first (16 loads in flight), then add and store; each element is still read and written by one lane only.
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int64_t col = n0 + wc * 64 + j * 32 + li;
-          const auto cv = epi.column(col);
-          const int64_t row_base = m0 + wr * 128 + i * 32 + 4 * lh;
-          decltype(epi.fetch(row_base, col)) pre[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) pre[r] = epi.fetch(row_base + ((r & 3) + 8 * (r >> 2)), col);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) epi.store_fetched(row_base + ((r & 3) + 8 * (r >> 2)), col, acc[i][j][r], cv, pre[r]);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int64_t col = n0 + wc * 64 + j * 32 + li;
-          const auto cv = epi.column(col);
-          const int64_t row_base = m0 + wr * 128 + i * 32 + 4 * lh;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) epi.store(row_base + ((r & 3) + 8 * (r >> 2)), col, acc[i][j][r], cv);
-        }
-      }
-    }
+      for (int j = 0; j < 2; ++j)
+        store_mfma_tile<false>(epi, m0 + wr * 128 + i * 32 + 4 * lh, n0 + wc * 64 + j * 32 + li, acc[i][j], M, N);
   } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int64_t col = n0 + wc * 64 + j * 32 + li;
-        decltype(epi.column(col)) cv{};  // float, or a small struct (cosine.hip MultiCosineEpi)
-        if (col < N) cv = epi.column(col);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t row = m0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (row < M && col < N) epi.store(row, col, acc[i][j][r], cv);
-        }
-      }
-    }
+      for (int j = 0; j < 2; ++j)
+        store_mfma_tile<true>(epi, m0 + wr * 128 + i * 32 + 4 * lh, n0 + wc * 64 + j * 32 + li, acc[i][j], M, N);
   }
 #ifdef SL_GEMM_CLOCKPROBE
   if (tid == 0) {

@@ -193,18 +193,10 @@ __global__ __launch_bounds__(256, SL_G3_WAVES) void gemm3_nt_kernel(const uint16
 #undef SL_G3_STAGE
 
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int64_t col = n0 + wn * 64 + j * 32 + li;
-      const float cv = col < N ? epi.column(col) : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < M && col < N) epi.store(row, col, acc[i][j][r], cv);
-      }
-    }
-  }
+    for (int j = 0; j < 2; ++j)
+      store_mfma_tile<true>(epi, m0 + wm * 64 + i * 32 + 4 * lh, n0 + wn * 64 + j * 32 + li, acc[i][j], M, N);
 #ifdef SL_GEMM_CLOCKPROBE
   if (tid == 0) {
     epi.probe[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - probe_c0;
@@ -333,18 +325,10 @@ __global__ __launch_bounds__(256, 2) void gemm3_nt_dma256_kernel(const uint16_t*
   }
 
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int64_t col = n0 + wn * 64 + j * 32 + li;
-      const float cv = col < N ? epi.column(col) : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < M && col < N) epi.store(row, col, acc[i][j][r], cv);
-      }
-    }
-  }
+    for (int j = 0; j < 2; ++j)
+      store_mfma_tile<true>(epi, m0 + wm * 128 + i * 32 + 4 * lh, n0 + wn * 64 + j * 32 + li, acc[i][j], M, N);
 #ifdef SL_GEMM_CLOCKPROBE
   if (tid == 0) {
     epi.probe[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - probe_c0;
@@ -521,18 +505,10 @@ __global__ __launch_bounds__(512, 2) void gemm3_nt_pingpong_kernel(const uint16_
   }
 
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int64_t col = n0 + grp * 128 + wn * 64 + j * 32 + li;
-      const float cv = col < N ? epi.column(col) : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < M && col < N) epi.store(row, col, acc[i][j][r], cv);
-      }
-    }
-  }
+    for (int j = 0; j < 2; ++j)
+      store_mfma_tile<true>(epi, m0 + wm * 128 + i * 32 + 4 * lh, n0 + grp * 128 + wn * 64 + j * 32 + li, acc[i][j], M, N);
 #ifdef SL_GEMM_CLOCKPROBE
   if (tid == 0) {
     epi.probe[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - probe_c0;

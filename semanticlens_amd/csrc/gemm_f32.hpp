@@ -171,19 +171,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
 
   // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int64_t col = n0 + wn * 64 + j * 32 + li;
-      decltype(epi.column(col)) cv{};  // float, or a small struct (cosine.hip MultiCosineEpi)
-      if (col < N) cv = epi.column(col);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < M && col < N) epi.store(row, col, acc[i][j][r], cv);
-      }
-    }
-  }
+    for (int j = 0; j < 2; ++j)
+      store_mfma_tile<true>(epi, m0 + wm * 64 + i * 32 + 4 * lh, n0 + wn * 64 + j * 32 + li, acc[i][j], M, N);
 #ifdef SL_GEMM_CLOCKPROBE
   if (tid == 0) {
     epi.probe[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - probe_c0;

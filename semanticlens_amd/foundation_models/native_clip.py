@@ -248,6 +248,48 @@ class _Tower:
         return x if pool_rows is None else N.gather_rows(x, pool_rows, check=False)
 
 
+# ---- a batch as several chunks on several HIP streams (off by default) ---------------------------------------------------
+# At B = 256 the ViT-B/32 tower's GEMMs have 150-600 tiles of 256 x 256 for 256 CUs: the out-projection and fc2 fill 59 %
+# of the chip, fc1 78 % of its last round.  The samples of a batch are independent all the way through the tower (GEMM
+# rows, attention per image), so the batch can be cut in SL_ENC_STREAMS chunks that each run the whole tower on a stream
+# of their own, the idle CUs of one chunk's kernel running another's.  Every feature keeps its bits
+# (tests/test_gpu_native_clip.py).  Measured (tools/encoder_bench.py, B = 256): 8.56 -> 8.11 ms in round 2, but 7.99 ->
+# 8.25 ms once the residual epilogue stopped serialising its loads (round 3): a half batch's GEMMs are 75-300 tiles and run
+# the 128 x 128 kernel (o-proj 65 us for HALF the rows against 63 us for all of them).  Default: one stream.
+_SIDE_STREAMS: dict = {}
+
+
+def _enc_streams() -> int:
+    import os
+
+    return max(1, min(4, int(os.environ.get("SL_ENC_STREAMS", "1"))))
+
+
+def _in_chunks(fn, batch: torch.Tensor, rows_per_sample: int, min_rows: int = 4096) -> torch.Tensor:
+    """``fn(batch)`` computed as ``SL_ENC_STREAMS`` (default 1 = off) chunks on side streams when every chunk still has at least
+    ``min_rows`` token rows; otherwise one call on the current stream."""
+    n = _enc_streams()
+    B = batch.shape[0]
+    if n == 1 or B < 2 * n or (B // n) * rows_per_sample < min_rows:
+        return fn(batch)
+    dev = batch.device
+    key = (dev.index, n)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = [torch.cuda.Stream(dev) for _ in range(n)]
+    cur = torch.cuda.current_stream(dev)
+    outs = []
+    for st, part in zip(_SIDE_STREAMS[key], batch.chunk(n)):
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            part.record_stream(st)
+            out = fn(part)
+        out.record_stream(cur)
+        outs.append(out)
+    for st in _SIDE_STREAMS[key]:
+        cur.wait_stream(st)
+    return torch.cat(outs)
+
+
 class NativeVisionTower:
     """open_clip ``VisionTransformer`` forward (class token + learned positions, pre-LN blocks) on the kernels.  ``pool``:
     ``"tok"`` (class token) or ``"avg"`` (mean of the patch tokens); ``ln_after_pool`` = open_clip's ``final_ln_after_pool``;
@@ -280,6 +322,13 @@ class NativeVisionTower:
     @torch.no_grad()
     def __call__(self, img: torch.Tensor) -> torch.Tensor:
         img = N.to_device(img).to(torch.float32).contiguous()
+        return _in_chunks(self._encode, img, self.chunk_rows(img))
+
+    def chunk_rows(self, img) -> int:
+        """Token rows one image contributes (what `_in_chunks` sizes its split by)."""
+        return (img.shape[2] // self.patch) * (img.shape[3] // self.patch) + 1
+
+    def _encode(self, img: torch.Tensor) -> torch.Tensor:
         B = img.shape[0]
         n_patch = (img.shape[2] // self.patch) * (img.shape[3] // self.patch)
         T = n_patch + 1
@@ -570,6 +619,9 @@ class NativeSigLipVision:
     @torch.no_grad()
     def __call__(self, img: torch.Tensor) -> torch.Tensor:
         img = N.to_device(img).to(torch.float32).contiguous()
+        return _in_chunks(self._encode, img, (img.shape[2] // self.patch) * (img.shape[3] // self.patch))
+
+    def _encode(self, img: torch.Tensor) -> torch.Tensor:
         B = img.shape[0]
         T = (img.shape[2] // self.patch) * (img.shape[3] // self.patch)
         if T != self.pos.shape[0]:

@@ -293,3 +293,25 @@ def test_config3_end_to_end_vit_probe_siglip_embed_text_probing():
         assert (dbs["native"][name] - dbs["torch"][name]).abs().max().item() < 1e-4 * scale
         assert probes["native"][name].shape == (10000, 768)
         assert (probes["native"][name] - probes["torch"][name]).abs().max().item() < 1e-4  # north_star: cosines within 1e-4
+
+
+def test_half_batches_on_two_streams_keep_every_bit(monkeypatch):
+    """The image tower can cut a large batch in SL_ENC_STREAMS chunks, one HIP stream each.  Samples are independent through
+    the tower — GEMM rows, attention per image — and every kernel rounds an element the same way wherever its row sits in a
+    tile (the GELU epilogue did not: fma contraction differed between unrolled copies), so: same bits either way, also at a
+    chunk boundary (96 x 50 rows) that is not a multiple of the 256-row tile."""
+    from semanticlens_amd.foundation_models import native_clip as nc
+
+    fm = synth.SyntheticClip(device=DEV, seed=3)
+    nat = NativeClip(fm)
+    x = fm.preprocess(synth.synth_images_u8(torch.arange(192, device=DEV)))
+    monkeypatch.setenv("SL_ENC_STREAMS", "1")
+    one = nat.encode_image(x)
+    monkeypatch.setenv("SL_ENC_STREAMS", "2")
+    assert 96 * nat.vision.chunk_rows(x) >= 4096  # the split is taken
+    two = nat.encode_image(x)
+    assert torch.equal(one, two)
+    monkeypatch.setenv("SL_ENC_STREAMS", "3")
+    three = nc._in_chunks(nat.vision._encode, x, nat.vision.chunk_rows(x), min_rows=0)
+    assert torch.equal(one, three)
+    assert torch.equal(nat.encode_image(x[:5]), one[:5])  # small batches: one call on the current stream
