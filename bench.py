@@ -735,7 +735,7 @@ def main():
     if single and not args.no_tokens_leg:
         # BASELINE configs[3]'s collect stage: ViT-B/16 probed model, all 12 encoder blocks, token-max aggregator -> K2 (colreduce)
         vit = synth.vit_b16().to(dev)
-        Bt = min(B, 128)
+        Bt = B
         line["tokens_collect"] = collect_leg(
             dev, fm, args, vit, [f"blocks.{i}" for i in range(12)], aggregators.aggregate_transformer_max,
             "colreduce (K2, (B, 197, 768) token activations, component axis contiguous)",

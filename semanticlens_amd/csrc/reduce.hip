@@ -502,6 +502,62 @@ __global__ __launch_bounds__(256) void rowreduce_fast_kernel(const float* __rest
   }
 }
 
+// streaming (read-once) 16-byte load with the nt cache policy, like the buffer loads of rowreduce_fast
+__device__ inline float4 nt_load4(const float* p) {
+  const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// ---- 2-byte activations (fp16 / bf16 models): element tags are _Float16 and uint16_t (bf16 bits) ---------------------
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ inline void unpack2(uint32_t w, float& lo, float& hi);
+template <>
+__device__ inline void unpack2<uint16_t>(uint32_t w, float& lo, float& hi) {
+  lo = bits_f32(w << 16);
+  hi = bits_f32(w & 0xFFFF0000u);
+}
+template <>
+__device__ inline void unpack2<_Float16>(uint32_t w, float& lo, float& hi) {
+  const f16x2 h = __builtin_bit_cast(f16x2, w);
+  lo = (float)h[0];
+  hi = (float)h[1];
+}
+template <typename T>
+__device__ inline float elem_as_f32(T v) {
+  if constexpr (sizeof(T) == 4) {
+    return v;
+  } else {
+    float lo, hi;
+    unpack2<T>((uint32_t)__builtin_bit_cast(uint16_t, v), lo, hi);
+    return lo;
+  }
+}
+// four consecutive elements as floats: one 16-byte (fp32) or 8-byte (fp16 / bf16) load, streaming policy or default
+template <typename T, bool NT>
+__device__ inline float4 load4_as_f32(const T* p) {
+  if constexpr (sizeof(T) == 4) {
+    if constexpr (NT) return nt_load4(reinterpret_cast<const float*>(p));
+    else return *reinterpret_cast<const float4*>(p);
+  } else {
+    u32x2 w;
+    if constexpr (NT) w = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
+    else w = *reinterpret_cast<const u32x2*>(p);
+    float4 r;
+    unpack2<T>(w[0], r.x, r.y);
+    unpack2<T>(w[1], r.z, r.w);
+    return r;
+  }
+}
+// round to the activation dtype first (the reference aggregates in that dtype), then report
+template <typename T>
+__device__ inline float round_to_dtype(float v) { return v; }
+template <>
+__device__ inline float round_to_dtype<_Float16>(float v) { return (float)(_Float16)v; }
+template <>
+__device__ inline float round_to_dtype<uint16_t>(float v) { return bf16_to_f32(f32_to_bf16_rne(v)); }
+
 // ---- rowreduce_dma: the same row arithmetic fed through a wave-private LDS ring ----------------------------------
 // rowreduce_fast maps G lanes onto a row and loads the row's 16-byte pieces straight into VGPRs, so a row of 49 (196, 784)
 // floats keeps 13 of 16 (49 of 64, 196 of 256) load lanes busy: ~23 % of every wave-load re-reads a clamped piece, and a
@@ -537,11 +593,15 @@ constexpr int kDmaMaxBatch = 4096;  // bytes: four 1-KiB LDS-DMA instructions
 constexpr int kDmaDepth = 2;        // slots per wave: one batch in flight while one is reduced
 constexpr int kDmaLdsPerCu = 160 * 1024;
 
-template <int G, int U, int OP, bool ALIGNED>
-__global__ __launch_bounds__(256) void rowreduce_dma_kernel(const float* __restrict__ x, int64_t R, int S, float denom, int slot_bytes,
+// T = float, _Float16 or uint16_t (bf16 bits): a 16-byte piece holds EPP = 4 or 8 elements; 2-byte rows start on any
+// 2-byte boundary, so the element masks of an unaligned row cover eight positions instead of four (round 3: fp16 / bf16
+// NCHW activations took rowreduce_h's VGPR loads, 3.5-3.7 TB/s at 14 x 14 and 7 x 7).
+template <typename T, int G, int U, int OP, bool ALIGNED>
+__global__ __launch_bounds__(256) void rowreduce_dma_kernel(const T* __restrict__ x, int64_t R, int S, float denom, int slot_bytes,
                                                              int64_t tail_from, uint16_t* __restrict__ cand,
                                                              float* __restrict__ outf) {
   constexpr int RPT = kWave / G;
+  constexpr int EPP = 16 / (int)sizeof(T);  // elements per 16-byte piece
   constexpr bool SUMOP = (OP == OP_SUM || OP == OP_ABSSUM);
   constexpr bool ABS = (OP == OP_ABSMAX || OP == OP_ABSSUM);
   extern __shared__ __align__(1024) unsigned char smem[];  // 4 waves x kDmaDepth slots of `slot_bytes` + 1 KiB (masked tail)
@@ -553,14 +613,15 @@ __global__ __launch_bounds__(256) void rowreduce_dma_kernel(const float* __restr
   const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
-  const int npieces = ALIGNED ? S / 4 : (S + 6) / 4;
+  const int npieces = ALIGNED ? S / EPP : (S + 2 * EPP - 2) / EPP;
   const int nsteps = ALIGNED ? (npieces + G - 1) / G : 1;
-  const int h = ALIGNED ? 0 : ((g * S) & 3);
-  const uint32_t row_byte0 = (uint32_t)(((g * S) >> 2) * 16);
-  const uint32_t task_bytes = (uint32_t)(RPT * S) * 4u;  // multiple of 16
-  const int pos0 = li * 4 - h;
-  const bool k0 = (unsigned)(pos0 + 0) < (unsigned)S, k1 = (unsigned)(pos0 + 1) < (unsigned)S;
-  const bool k2 = (unsigned)(pos0 + 2) < (unsigned)S, k3 = (unsigned)(pos0 + 3) < (unsigned)S;
+  const int h = ALIGNED ? 0 : ((g * S) & (EPP - 1));
+  const uint32_t row_byte0 = (uint32_t)(((g * S) / EPP) * 16);
+  const uint32_t task_bytes = (uint32_t)(RPT * S) * (uint32_t)sizeof(T);  // multiple of 16
+  const int pos0 = li * EPP - h;
+  bool km[EPP];  // element e of this lane's piece belongs to the lane's row (unaligned rows; constant per lane)
+#pragma unroll
+  for (int e = 0; e < EPP; ++e) km[e] = (unsigned)(pos0 + e) < (unsigned)S;
   unsigned char* ring = smem + wave_in_block * (kDmaDepth * slot_bytes);
   unsigned char* spare = smem + 4 * kDmaDepth * slot_bytes;
   typedef __attribute__((address_space(3))) void lds_void;
@@ -675,21 +736,28 @@ __global__ __launch_bounds__(256) void rowreduce_dma_kernel(const float* __restr
       for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const f32x4*>(sl_ + (uint32_t)u * task_bytes + off);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        float e0 = v[u][0], e1 = v[u][1], e2 = v[u][2], e3 = v[u][3];
-        if constexpr (ABS) {
-          e0 = __builtin_fabsf(e0); e1 = __builtin_fabsf(e1); e2 = __builtin_fabsf(e2); e3 = __builtin_fabsf(e3);
-        }
-        if constexpr (!ALIGNED) {
-          e0 = k0 ? e0 : fill; e1 = k1 ? e1 : fill; e2 = k2 ? e2 : fill; e3 = k3 ? e3 : fill;
-        }
-        if constexpr (SUMOP) {
-          if constexpr (ALIGNED) {
-            e0 = piece_ok ? e0 : 0.f; e1 = piece_ok ? e1 : 0.f; e2 = piece_ok ? e2 : 0.f; e3 = piece_ok ? e3 : 0.f;
-          }
-          sum2[u] += f32x2{e0, e1} + f32x2{e2, e3};
+        float e[EPP];
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) e[i] = v[u][i];
         } else {
-          m[u] = v_max3(v_max3(m[u], e0, e1), e2, e3);
-          if (!(SL_REDUCE_LAB & 2)) sum2[u] += f32x2{e0, e1} + f32x2{e2, e3};  // NaN detector only
+#pragma unroll
+          for (int d = 0; d < 4; ++d) unpack2<T>(f32_bits(v[u][d]), e[2 * d], e[2 * d + 1]);
+        }
+#pragma unroll
+        for (int i = 0; i < EPP; ++i) {
+          if constexpr (ABS) e[i] = __builtin_fabsf(e[i]);
+          if constexpr (!ALIGNED) e[i] = km[i] ? e[i] : fill;
+          if constexpr (SUMOP && ALIGNED) e[i] = piece_ok ? e[i] : 0.f;
+        }
+        f32x2 ps = f32x2{e[0], e[1]} + f32x2{e[2], e[3]};
+        if constexpr (EPP == 8) ps += f32x2{e[4], e[5]} + f32x2{e[6], e[7]};
+        if constexpr (SUMOP) {
+          sum2[u] += ps;
+        } else {
+          m[u] = v_max3(v_max3(m[u], e[0], e[1]), e[2], e[3]);
+          if constexpr (EPP == 8) m[u] = v_max3(v_max3(m[u], e[4], e[5]), e[6], e[7]);
+          if (!(SL_REDUCE_LAB & 2)) sum2[u] += ps;  // NaN detector only
         }
       }
     }
@@ -708,7 +776,8 @@ __global__ __launch_bounds__(256) void rowreduce_dma_kernel(const float* __restr
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if constexpr (SUMOP) {
-        r[u] = group_allreduce_bcast<G, true>(sum[u], lane) / denom;
+        // sums accumulate in fp32 and are rounded ONCE to the activation dtype, like torch's (identity for fp32)
+        r[u] = round_to_dtype<T>(group_allreduce_bcast<G, true>(sum[u], lane) / denom);
       } else {
         r[u] = group_allreduce_bcast<G, false>(m[u], lane);
         const bool row_ok = u < nu;
@@ -717,8 +786,11 @@ __global__ __launch_bounds__(256) void rowreduce_dma_kernel(const float* __restr
           const float sred = group_allreduce_f<G, true>(sum[u]);
           bool nan = false;
           if (row_ok && sred != sred) {
-            const float* rowp = x + ((int64_t)(task0 + u) * RPT + g) * (int64_t)S;
-            for (int i = li; i < S; i += G) nan |= (rowp[i] != rowp[i]);
+            const T* rowp = x + ((int64_t)(task0 + u) * RPT + g) * (int64_t)S;
+            for (int i = li; i < S; i += G) {
+              const float ev = elem_as_f32<T>(rowp[i]);
+              nan |= (ev != ev);
+            }
           }
           const float f = group_allreduce_f<G, false>(nan ? 1.f : 0.f);
           if (f > 0.f) r[u] = bits_f32(0x7FC00000u);
@@ -735,52 +807,6 @@ __global__ __launch_bounds__(256) void rowreduce_dma_kernel(const float* __restr
     }
   }
 }
-
-// streaming (read-once) 16-byte load with the nt cache policy, like the buffer loads of rowreduce_fast
-__device__ inline float4 nt_load4(const float* p) {
-  const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
-  return make_float4(v[0], v[1], v[2], v[3]);
-}
-
-// ---- 2-byte activations (fp16 / bf16 models): element tags are _Float16 and uint16_t (bf16 bits) ---------------------
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-template <typename T>
-__device__ inline void unpack2(uint32_t w, float& lo, float& hi);
-template <>
-__device__ inline void unpack2<uint16_t>(uint32_t w, float& lo, float& hi) {
-  lo = bits_f32(w << 16);
-  hi = bits_f32(w & 0xFFFF0000u);
-}
-template <>
-__device__ inline void unpack2<_Float16>(uint32_t w, float& lo, float& hi) {
-  const f16x2 h = __builtin_bit_cast(f16x2, w);
-  lo = (float)h[0];
-  hi = (float)h[1];
-}
-// four consecutive elements as floats: one 16-byte (fp32) or 8-byte (fp16 / bf16) load, streaming policy or default
-template <typename T, bool NT>
-__device__ inline float4 load4_as_f32(const T* p) {
-  if constexpr (sizeof(T) == 4) {
-    if constexpr (NT) return nt_load4(reinterpret_cast<const float*>(p));
-    else return *reinterpret_cast<const float4*>(p);
-  } else {
-    u32x2 w;
-    if constexpr (NT) w = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
-    else w = *reinterpret_cast<const u32x2*>(p);
-    float4 r;
-    unpack2<T>(w[0], r.x, r.y);
-    unpack2<T>(w[1], r.z, r.w);
-    return r;
-  }
-}
-// round to the activation dtype first (the reference aggregates in that dtype), then report
-template <typename T>
-__device__ inline float round_to_dtype(float v) { return v; }
-template <>
-__device__ inline float round_to_dtype<_Float16>(float v) { return (float)(_Float16)v; }
-template <>
-__device__ inline float round_to_dtype<uint16_t>(float v) { return bf16_to_f32(f32_to_bf16_rne(v)); }
 
 // ---- colreduce: out[b][f] = op_t x[b][t][f], f contiguous ------------------------------------
 // One workgroup (NW = 4 waves, or 16 when there are too few (b, chunk) tasks to fill the chip — small batches of long
@@ -1047,11 +1073,12 @@ void launch_rowreduce_fast(ProfScope& prof, const float* x, int64_t R, int S, fl
   }
 }
 
-template <int G, int U, int OP, bool ALIGNED>
-void launch_rowreduce_dma(ProfScope& prof, const float* x, int64_t R, int S, float denom, uint16_t* cand, float* outf, hipStream_t st) {
+template <typename T, int G, int U, int OP, bool ALIGNED>
+void launch_rowreduce_dma(ProfScope& prof, const T* x, int64_t R, int S, float denom, uint16_t* cand, float* outf, hipStream_t st) {
   constexpr int RPT = kWave / G;
+  constexpr int ES = (int)sizeof(T);
   const int64_t nbatch = (R / RPT + U - 1) / U;
-  const int slot = U * RPT * S * 4;                       // one batch, a multiple of 16 bytes
+  const int slot = U * RPT * S * ES;                      // one batch, a multiple of 16 bytes
   const int lds = 4 * kDmaDepth * slot + 1024;            // + 1 KiB: the masked tail of the last slot's last instruction
   int per_cu = kDmaLdsPerCu / lds;
   if (per_cu > 8) per_cu = 8;                             // 32 waves per CU
@@ -1060,28 +1087,30 @@ void launch_rowreduce_dma(ProfScope& prof, const float* x, int64_t R, int S, flo
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   const int64_t nt_min_bytes = nt_min_bytes_(), tail_bytes = tail_bytes_();  // cache policy: see the top of this file
-  const int64_t bytes = R * (int64_t)S * 4;
+  const int64_t bytes = R * (int64_t)S * ES;
   int64_t tail_from = 0;  // tasks from here on use the default policy
-  if (bytes >= nt_min_bytes) tail_from = tail_bytes > 0 ? (bytes > tail_bytes ? (bytes - tail_bytes) / ((int64_t)RPT * S * 4) : 0) : INT64_MAX;
-  SL_LAUNCH(prof, (rowreduce_dma_kernel<G, U, OP, ALIGNED>), dim3((unsigned)blocks), dim3(256), (size_t)lds, st, x, R, S, denom,
+  if (bytes >= nt_min_bytes) tail_from = tail_bytes > 0 ? (bytes > tail_bytes ? (bytes - tail_bytes) / ((int64_t)RPT * S * ES) : 0) : INT64_MAX;
+  SL_LAUNCH(prof, (rowreduce_dma_kernel<T, G, U, OP, ALIGNED>), dim3((unsigned)blocks), dim3(256), (size_t)lds, st, x, R, S, denom,
             slot, tail_from, cand, outf);
 }
 
 // U = tasks per batch (<= 4) so that a batch is at most 4 KiB; false when a task alone is larger
-template <int G, int OP, bool ALIGNED>
-bool try_rowreduce_dma(ProfScope& prof, const float* x, int64_t R, int S, float denom, uint16_t* cand, float* outf, hipStream_t st) {
+template <int G, int OP, bool ALIGNED, typename T>
+bool try_rowreduce_dma(ProfScope& prof, const T* x, int64_t R, int S, float denom, uint16_t* cand, float* outf, hipStream_t st) {
   static const bool enabled = [] {
     const char* e = getenv("SL_REDUCE_DMA");  // 0: always the VGPR-load kernels (A/B measurements)
     return !(e && atoi(e) == 0);
   }();
   constexpr int RPT = kWave / G;
-  const int64_t task_bytes = (int64_t)RPT * S * 4;
-  if (!enabled || task_bytes > kDmaMaxBatch || R * (int64_t)S * 4 < (8ll << 20) || R > 0x7fffffffll) return false;  // small inputs: launch-bound either way; the kernel indexes tasks with 32 bits
+  const int64_t task_bytes = (int64_t)RPT * S * (int64_t)sizeof(T);
+  if (!enabled || task_bytes > kDmaMaxBatch || (task_bytes & 15) != 0 || R % RPT != 0 || R * (int64_t)S * (int64_t)sizeof(T) < (8ll << 20) ||
+      R > 0x7fffffffll)
+    return false;  // small inputs: launch-bound either way; the kernel indexes tasks with 32 bits
   const int u = (int)(kDmaMaxBatch / task_bytes);
-  if (u >= 4) launch_rowreduce_dma<G, 4, OP, ALIGNED>(prof, x, R, S, denom, cand, outf, st);
-  else if (u == 3) launch_rowreduce_dma<G, 3, OP, ALIGNED>(prof, x, R, S, denom, cand, outf, st);
-  else if (u == 2) launch_rowreduce_dma<G, 2, OP, ALIGNED>(prof, x, R, S, denom, cand, outf, st);
-  else launch_rowreduce_dma<G, 1, OP, ALIGNED>(prof, x, R, S, denom, cand, outf, st);
+  if (u >= 4) launch_rowreduce_dma<T, G, 4, OP, ALIGNED>(prof, x, R, S, denom, cand, outf, st);
+  else if (u == 3) launch_rowreduce_dma<T, G, 3, OP, ALIGNED>(prof, x, R, S, denom, cand, outf, st);
+  else if (u == 2) launch_rowreduce_dma<T, G, 2, OP, ALIGNED>(prof, x, R, S, denom, cand, outf, st);
+  else launch_rowreduce_dma<T, G, 1, OP, ALIGNED>(prof, x, R, S, denom, cand, outf, st);
   return true;
 }
 
@@ -1164,6 +1193,18 @@ template <typename T, int OP>
 void dispatch_rowreduce_h(ProfScope& prof, const T* x, int64_t R, int S, float denom, uint16_t* cand, float* outf, hipStream_t st) {
   const bool al = S % 8 == 0;
   const int np = al ? S / 8 : (S + 14) / 8;
+  // LDS-DMA ring kernel first (rowreduce_dma_kernel<T>: the fp32 kernel's feed with 8-element pieces); it takes inputs of
+  // >= 8 MB whose tasks (64 / G rows) are whole 16-byte pieces
+  if (al) {
+    if (np > 4 && np <= 64 && try_rowreduce_dma<16, OP, true>(prof, x, R, S, denom, cand, outf, st)) return;
+    if (np <= 4 && try_rowreduce_dma<4, OP, true>(prof, x, R, S, denom, cand, outf, st)) return;
+    if (np > 64 && try_rowreduce_dma<64, OP, true>(prof, x, R, S, denom, cand, outf, st)) return;
+  } else {
+    if (np <= 4 && try_rowreduce_dma<4, OP, false>(prof, x, R, S, denom, cand, outf, st)) return;
+    if (np <= 8 && try_rowreduce_dma<8, OP, false>(prof, x, R, S, denom, cand, outf, st)) return;
+    if (np <= 16 && try_rowreduce_dma<16, OP, false>(prof, x, R, S, denom, cand, outf, st)) return;
+    if (np <= 32 && try_rowreduce_dma<32, OP, false>(prof, x, R, S, denom, cand, outf, st)) return;
+  }
 #define SL_ROWH(G, U, J)                                                                          \
   do {                                                                                            \
     if (al) launch_rowreduce_h<T, G, U, J, OP, true>(prof, x, R, S, denom, cand, outf, st);       \
