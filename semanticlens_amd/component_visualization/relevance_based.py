@@ -8,10 +8,12 @@ therefore unpinned**; what is kept is the procedure zennit-crp 0.6.0 runs for th
 kernels, and the reference's constructor vocabulary (``aggregation_fn="sum"``, ``abs_norm=True``,
 ``num_samples=100``, ``relevance_based.py:104-149``):
 
-* per batch, one forward + one backward of the probed model; the relevance of a hooked layer's output is
-  ``activation * d(target logit) / d(activation)`` (gradient x activation: what an LRP-epsilon / -0 composite yields
-  on a ReLU network; the reference's default composite ``EpsilonPlusFlat`` is zennit's, not reproduced here — pass
-  ``attribution=`` to plug in any callable that returns per-layer relevance tensors);
+* per batch, one forward + one backward of the probed model under an *attribution*:
+  ``composite="epsilon_plus_flat"`` (default, the composite the reference names, ``relevance_based.py:19``): LRP with the
+  z+ rule for convolutions, the epsilon rule for dense layers, the flat rule for the first layer and pass-through for
+  activations / batch norm, restated on PyTorch autograd in ``lrp.py`` (zennit's own code is not reproduced);
+  ``composite="gradient_x_activation"``: ``activation * d(target logit) / d(activation)`` (what LRP-0 yields on a ReLU
+  network); or any callable ``attribution(model, {name: module}, images, targets) -> {name: (activation, relevance)}``;
 * ``(B, C, H, W) -> (B, C)`` by **sum** over H x W — K1 with ``SL_CONV_SUM`` (crp ``ChannelConcept.reference_sampling``
   with ``max_target="sum"``), for tokens ``(B, T, F)`` the sum over T;
 * ``abs_norm``: every sample's row divided by ``sum_c |r_c| + 1e-10`` (``sl_abs_norm_rows``);
@@ -96,20 +98,31 @@ class RelevanceComponentVisualizer(ActivationComponentVisualizer):
 
     Parameters follow ``ActivationComponentVisualizer`` (model, the two datasets, layer names, cache directory) and the
     reference's relevance class: ``aggregation_fn`` (only ``"sum"``, the reference's default, is provided), ``abs_norm``
-    (default True), ``num_samples`` (default 100), ``attribution`` (callable as :func:`gradient_x_activation`),
+    (default True), ``num_samples`` (default 100), ``composite`` (``"epsilon_plus_flat"`` — default —,
+    ``"gradient_x_activation"``, or a callable) / ``attribution`` (a callable as :func:`gradient_x_activation`; wins),
     ``use_labels`` (take the targets from the dataset's labels instead of the model's prediction; crp conditions on the
     label).
     """
 
     def __init__(self, model: nn.Module, dataset_model, dataset_fm, layer_names, num_samples: int = 100,
                  aggregation_fn: str = "sum", abs_norm: bool = True, attribution=None, use_labels: bool = False,
-                 device=None, cache_dir: str | None = None, tie_mode: str | None = None):
+                 device=None, cache_dir: str | None = None, tie_mode: str | None = None, composite="epsilon_plus_flat"):
         if aggregation_fn != "sum":
             raise ValueError("only aggregation_fn='sum' (the reference's default max_target) is provided")
         layer_names = [layer_names] if not isinstance(layer_names, list) else layer_names
         self.abs_norm = bool(abs_norm)
         self.aggregation_fn = aggregation_fn
-        self.attribution = attribution or gradient_x_activation
+        if attribution is None:
+            if callable(composite):
+                attribution = composite
+            elif composite == "epsilon_plus_flat":
+                from semanticlens_amd.component_visualization.lrp import lrp_epsilon_plus_flat as attribution
+            elif composite == "gradient_x_activation":
+                attribution = gradient_x_activation
+            else:
+                raise ValueError(f"composite must be 'epsilon_plus_flat', 'gradient_x_activation' or a callable, got {composite!r}")
+        self.composite = getattr(attribution, "__name__", type(attribution).__name__)
+        self.attribution = attribution
         self.use_labels = use_labels
         # the parent builds `actmax_cache` (relevance mode here) and loads an existing cache
         super().__init__(model, dataset_model, dataset_fm, layer_names, num_samples, device=device,
@@ -207,8 +220,8 @@ class RelevanceComponentVisualizer(ActivationComponentVisualizer):
 
     @property
     def metadata(self) -> dict[str, str]:
-        return {**self.actmax_cache.metadata, "abs_norm": str(self.abs_norm), "dataset": self.dataset.name,
-                "model": self.model.name}
+        return {**self.actmax_cache.metadata, "abs_norm": str(self.abs_norm), "composite": str(self.composite),
+                "dataset": self.dataset.name, "model": self.model.name}
 
     def _compute_concept_db(self, fm, batch_size=32, keep_on_device: bool = False, **kwargs):
         """``{layer: (n_components, num_samples, D)}`` of the relevance-mode reference samples."""

@@ -117,7 +117,8 @@ def test_end_to_end_gradient_x_activation_equals_cpu_autograd_plus_oracle(tmp_pa
             refs[name][1].update(oracle.agg_conv(act.numpy(), "sum"), ids)
     # device: the visualizer
     ds = TensorPairDataset(x, name="int10")
-    cv = RelevanceComponentVisualizer(_IntNet().to(DEV), ds, ds, layers, num_samples=k, cache_dir=str(tmp_path), tie_mode="aten")
+    cv = RelevanceComponentVisualizer(_IntNet().to(DEV), ds, ds, layers, num_samples=k, cache_dir=str(tmp_path), tie_mode="aten",
+                                      composite="gradient_x_activation")
     assert cv.num_samples == k and cv.abs_norm and not cv.check_if_preprocessed()
     cv.run(batch_size=bs)
     assert cv.check_if_preprocessed()
@@ -130,7 +131,8 @@ def test_end_to_end_gradient_x_activation_equals_cpu_autograd_plus_oracle(tmp_pa
     # caches: both modes written in the ActMaxCache layout, a fresh visualizer loads them instead of collecting
     files = sorted(p.name for p in tmp_path.rglob("*.safetensors"))
     assert files == sorted(f"{a}-{k}-{l}.safetensors" for a in ("activation_sum", "relevance_sum_absnorm") for l in layers)
-    cv2 = RelevanceComponentVisualizer(_IntNet().to(DEV), ds, ds, layers, num_samples=k, cache_dir=str(tmp_path), tie_mode="aten")
+    cv2 = RelevanceComponentVisualizer(_IntNet().to(DEV), ds, ds, layers, num_samples=k, cache_dir=str(tmp_path), tie_mode="aten",
+                                       composite="gradient_x_activation")
     assert cv2.check_if_preprocessed()
     assert torch.equal(cv2.get_max_reference("relu2"), cv.get_max_reference("relu2"))
     # the three abstract members Lens needs: concept DB = embeddings of the relevance-mode reference samples
@@ -167,7 +169,8 @@ def test_token_layers_and_label_targets():
             return self.x[i], i % 3
 
     ds = DS(x, name="tokds")
-    cv = RelevanceComponentVisualizer(model.to(DEV), ds, ds, ["proj"], num_samples=4, use_labels=True, abs_norm=False, tie_mode="total")
+    cv = RelevanceComponentVisualizer(model.to(DEV), ds, ds, ["proj"], num_samples=4, use_labels=True, abs_norm=False, tie_mode="total",
+                                      composite="gradient_x_activation")
     cv.run(batch_size=5)
     per = gradient_x_activation(ref_model, {"proj": ref_model.proj}, x, torch.arange(10) % 3)
     act, rel = per["proj"]
@@ -198,3 +201,77 @@ def test_negative_relevance_is_ranked_not_padded_with_minus_one():
         want = oracle.ActMaxOracle(5, 3, oracle.MODE_ATEN if mode == "aten" else oracle.MODE_TOTAL, init_value=-np.inf)
         want.update(oracle.abs_norm_rows(rel.reshape(12, 3).numpy()), np.arange(12))
         assert np.array_equal(ids.numpy(), want.ids) and np.array_equal(bits(cv.actmax_cache.cache["0"].activations), want.vals)
+
+
+def test_epsilon_plus_flat_composite_end_to_end_on_a_resnet_style_network(tmp_path):
+    """The reference's composite (`zennit.composites.EpsilonPlusFlat`, relevance_based.py:19) as restated in `lrp.py`, through
+    the whole visualizer on the device: conv / batch norm / ReLU (in place) / residual add / max pool / average pool / dense.
+    The same attribution on a CPU copy of the model feeds the oracle (sum over H x W, abs-norm, top-k); real-valued data:
+    kept values within one bf16 ulp, ids equal wherever the kept values are distinct.  Parity vs zennit itself: unpinned."""
+    import copy
+
+    from semanticlens_amd.component_visualization.lrp import lrp_epsilon_plus_flat
+
+    class Block(nn.Module):
+        def __init__(self, c):
+            super().__init__()
+            self.conv1, self.bn1 = nn.Conv2d(c, c, 3, padding=1, bias=False), nn.BatchNorm2d(c)
+            self.conv2, self.bn2 = nn.Conv2d(c, c, 3, padding=1, bias=False), nn.BatchNorm2d(c)
+            self.relu = nn.ReLU(inplace=True)
+
+        def forward(self, x):
+            out = self.relu(self.bn1(self.conv1(x)))
+            return self.relu(self.bn2(self.conv2(out)) + x)
+
+    class TinyResNet(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.stem = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1, bias=False), nn.BatchNorm2d(8), nn.ReLU(inplace=True), nn.MaxPool2d(2))
+            self.layer1, self.layer2 = Block(8), Block(8)
+            self.pool, self.fc = nn.AdaptiveAvgPool2d(1), nn.Linear(8, 5)
+            self.name = "tiny-resnet"
+
+        def forward(self, x):
+            return self.fc(self.pool(self.layer2(self.layer1(self.stem(x)))).flatten(1))
+
+    torch.manual_seed(4)
+    model = TinyResNet().eval()
+    with torch.no_grad():
+        for mod in model.modules():
+            if isinstance(mod, nn.BatchNorm2d):
+                mod.running_mean.normal_(0, 0.1), mod.running_var.uniform_(0.5, 1.5), mod.weight.uniform_(0.5, 1.5), mod.bias.normal_(0, 0.1)
+    ref_model = copy.deepcopy(model)
+    n, k, bs = 37, 6, 8
+    x = torch.randn(n, 3, 12, 12)
+    layers = ["layer1", "layer2.conv1"]
+    ds = TensorPairDataset(x, name="lrp37")
+    cv = RelevanceComponentVisualizer(model.to(DEV), ds, ds, layers, num_samples=k, tie_mode="total", cache_dir=str(tmp_path))
+    assert cv.composite == "lrp_epsilon_plus_flat" and cv.metadata["composite"] == "lrp_epsilon_plus_flat"
+    cv.run(batch_size=bs)
+    assert all(mod.inplace for mod in model.modules() if isinstance(mod, nn.ReLU))  # the caller's model is as it was
+    mods = {nme: m for nme, m in ref_model.named_modules() if nme in layers}
+    want = {name: oracle.ActMaxOracle(k, 8, oracle.MODE_TOTAL, init_value=-np.inf) for name in layers}
+    want_act = {name: oracle.ActMaxOracle(k, 8, oracle.MODE_TOTAL, init_value=-np.inf) for name in layers}
+    for s0 in range(0, n, bs):
+        per = lrp_epsilon_plus_flat(ref_model, mods, x[s0:s0 + bs], None)
+        ids = np.arange(s0, min(n, s0 + bs))
+        for name in layers:
+            act, rel = per[name]
+            want[name].update(oracle.abs_norm_rows(oracle.agg_conv(rel.numpy(), "sum")), ids)
+            want_act[name].update(oracle.agg_conv(act.numpy(), "sum"), ids)
+    for name in layers:
+        for got, ref in ((cv.actmax_cache.cache[name], want[name]), (cv.activation_cache.cache[name], want_act[name])):
+            gv, wv = got.activations.float().numpy(), oracle.bf16_to_f32(ref.vals)
+            assert np.isfinite(gv).all() and got.sample_ids.min().item() >= 0
+            assert np.allclose(gv, wv, rtol=2 ** -7, atol=1e-6), name
+            distinct = np.ones_like(wv, dtype=bool)  # a slot whose value differs from both neighbours has a unique owner
+            distinct[:, 1:] &= wv[:, 1:] != wv[:, :-1]
+            distinct[:, :-1] &= wv[:, :-1] != wv[:, 1:]
+            exact = distinct & (gv == wv)
+            assert exact.mean() > 0.8 and np.array_equal(got.sample_ids.numpy()[exact], ref.ids[exact]), name
+    assert sorted(p.name for p in tmp_path.rglob("*.safetensors")) == sorted(
+        f"{a}-{k}-{l}.safetensors" for a in ("activation_sum", "relevance_sum_absnorm") for l in layers)
+    # relevance is not the activation: the two modes rank different samples somewhere
+    assert not torch.equal(cv.get_max_reference("layer1"), cv.get_act_max_sample_ids("layer1"))
+    with pytest.raises(ValueError, match="composite"):
+        RelevanceComponentVisualizer(model, ds, ds, layers, composite="lrp-gamma")

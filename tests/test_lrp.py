@@ -1,0 +1,136 @@
+"""`semanticlens_amd.component_visualization.lrp` — the EpsilonPlusFlat rule set restated on PyTorch autograd.
+
+zennit / zennit-crp (what the reference's relevance visualizer wraps, relevance_based.py:16-19) are absent, so these tests
+pin the rules against their published definitions computed by hand, and against properties LRP guarantees: conservation on
+bias-free networks and LRP-0 == gradient x input on ReLU networks.  Pure PyTorch: runs on the CPU."""
+import pytest
+import torch
+from torch import nn
+
+from semanticlens_amd.component_visualization.lrp import epsilon_plus_flat, lrp_epsilon_plus_flat
+from semanticlens_amd.component_visualization.relevance_based import gradient_x_activation
+
+
+class Net(nn.Module):
+    def __init__(self, bias=False):
+        super().__init__()
+        self.c1 = nn.Conv2d(3, 4, 3, bias=bias)
+        self.r1 = nn.ReLU(inplace=True)
+        self.c2 = nn.Conv2d(4, 5, 3, bias=bias)
+        self.bn = nn.BatchNorm2d(5)
+        self.r2 = nn.ReLU()
+        self.pool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Linear(5, 3, bias=bias)
+
+    def forward(self, x):
+        return self.fc(self.pool(self.r2(self.bn(self.c2(self.r1(self.c1(x)))))).flatten(1))
+
+
+def _net(bias=False, seed=0):
+    torch.manual_seed(seed)
+    m = Net(bias).eval()
+    with torch.no_grad():  # identity batch norm so that the pass-through rule stays conservative in this test
+        m.bn.weight.fill_(1.0), m.bn.bias.zero_(), m.bn.running_mean.zero_(), m.bn.running_var.fill_(1.0 - m.bn.eps)
+    return m
+
+
+def test_relevance_is_conserved_and_matches_the_rules_written_out():
+    m = _net()
+    x = torch.rand(3, 3, 8, 8)
+    layers = {n: mod for n, mod in m.named_modules() if n in ("r1", "c2", "r2", "fc")}
+    out = lrp_epsilon_plus_flat(m, layers, x, None)
+    assert m.r1.inplace and all(p.grad is None for p in m.parameters())  # nothing of the caller's model is left modified
+    with torch.no_grad():
+        a1 = m.c1(x).clamp(min=0)
+        a2 = m.c2(a1).clamp(min=0)
+        p = a2.mean((2, 3))
+        y = p @ m.fc.weight.T
+    t = y.argmax(1)
+    idx = torch.arange(3)
+    for name, (act, rel) in out.items():  # bias-free: every layer carries exactly the target logit
+        assert act.shape == rel.shape
+        assert torch.allclose(rel.flatten(1).sum(1), y[idx, t], rtol=1e-3, atol=1e-6), name
+    assert torch.equal(out["r1"][0], a1) and torch.allclose(out["fc"][0], y)
+    # the rules, written out: epsilon at fc, norm at the pooling, z+ at c2
+    sgn = lambda z: torch.where(z >= 0, torch.ones_like(z), -torch.ones_like(z))  # noqa: E731
+    r_y = torch.zeros_like(y)
+    r_y[idx, t] = y[idx, t]
+    assert torch.allclose(out["fc"][1], r_y)
+    r_p = p * ((r_y / (y + 1e-6 * sgn(y))) @ m.fc.weight)
+    r_a2 = a2 * (r_p / (p + 1e-6))[:, :, None, None] / (a2.shape[2] * a2.shape[3])
+    assert torch.allclose(out["r2"][1], r_a2, rtol=1e-5, atol=1e-8)
+    wp = m.c2.weight.detach().clamp(min=0)
+    z = nn.functional.conv2d(a1, wp)  # a1 >= 0: the (a-, w-) pass contributes nothing
+    r_a1 = a1 * nn.functional.conv_transpose2d(r_a2 / (z + 1e-6 * sgn(z)), wp)
+    assert torch.allclose(out["r1"][1], r_a1, rtol=1e-5, atol=1e-8)
+    # explicit targets condition on the label
+    lab = torch.tensor([0, 1, 2])
+    out_l = lrp_epsilon_plus_flat(m, {"fc": m.fc}, x, lab)
+    assert torch.allclose(out_l["fc"][1].sum(1), y[idx, lab])
+
+
+def test_flat_rule_spreads_relevance_evenly_over_the_first_layers_receptive_fields():
+    m = _net()
+    x = torch.rand(2, 3, 8, 8)
+    with epsilon_plus_flat(m):
+        xx = x.clone().requires_grad_(True)
+        y = m(xx)
+        start = torch.zeros_like(y)
+        start[:, 0] = y[:, 0].detach()
+        (r_x,) = torch.autograd.grad(y, xx, grad_outputs=start)
+    assert torch.allclose(r_x.flatten(1).sum(1), y[:, 0].detach(), rtol=1e-2, atol=1e-6)  # the 1e-6 stabilisers absorb a little
+    assert torch.allclose(r_x[:, 0], r_x[:, 1]) and torch.allclose(r_x[:, 0], r_x[:, 2])  # independent of the pixel values / channel
+    # outside the context the model differentiates normally again
+    xx = x.clone().requires_grad_(True)
+    (g,) = torch.autograd.grad(m(xx)[:, 0].sum(), xx)
+    with torch.no_grad():
+        eps_ = 1e-3
+        d = torch.zeros_like(x)
+        d[0, 1, 3, 4] = eps_
+        fd = (m(x + d)[0, 0] - m(x - d)[0, 0]) / (2 * eps_)
+    assert abs(g[0, 1, 3, 4].item() - fd.item()) < 1e-3
+
+
+def test_epsilon_rule_everywhere_equals_gradient_x_activation_on_a_relu_network():
+    """LRP-0 / LRP-epsilon with eps -> 0 on a ReLU network is gradient x input (Ancona et al. 2018): dense ReLU stack,
+    epsilon rule on every layer (an all-`nn.Linear` network, no flat first layer) against plain autograd."""
+    torch.manual_seed(1)
+    m = nn.Sequential(nn.Linear(7, 9), nn.ReLU(), nn.Linear(9, 6), nn.ReLU(), nn.Linear(6, 4)).eval()
+    x = torch.randn(5, 7)
+    layers = {"1": m[1], "3": m[3]}
+    want = gradient_x_activation(m, layers, x, None)
+    kept = {}
+    hooks = []
+    with epsilon_plus_flat(m, epsilon=1e-9, first_layer_flat=False):
+        hooks = [mod.register_forward_hook(lambda mo, i, o, n=n: kept.__setitem__(n, o)) for n, mod in layers.items()]
+        xx = x.clone().requires_grad_(True)
+        y = m(xx)
+        t = y.argmax(1)
+        start = torch.zeros_like(y).scatter_(1, t[:, None], 1.0) * y.detach()
+        grads = torch.autograd.grad(y, [kept["1"], kept["3"]], grad_outputs=start)
+    for h in hooks:
+        h.remove()
+    # biases absorb relevance under the epsilon rule, so compare on the bias-free part: R = a * grad holds when b = 0
+    with torch.no_grad():
+        for mod in m:
+            if isinstance(mod, nn.Linear):
+                mod.bias.zero_()
+    want = gradient_x_activation(m, layers, x, None)
+    kept.clear()
+    with epsilon_plus_flat(m, epsilon=1e-9, first_layer_flat=False):
+        hooks = [mod.register_forward_hook(lambda mo, i, o, n=n: kept.__setitem__(n, o)) for n, mod in layers.items()]
+        xx = x.clone().requires_grad_(True)
+        y = m(xx)
+        t = y.argmax(1)
+        start = torch.zeros_like(y).scatter_(1, t[:, None], 1.0) * y.detach()
+        grads = torch.autograd.grad(y, [kept["1"], kept["3"]], grad_outputs=start)
+    for h in hooks:
+        h.remove()
+    for name, g in zip(("1", "3"), grads):
+        assert torch.allclose(g, want[name][1], rtol=1e-4, atol=1e-6), name
+
+
+def test_unsupported_padding_mode_is_reported():
+    m = nn.Sequential(nn.Conv2d(3, 2, 3, padding=1, padding_mode="reflect"), nn.ReLU(), nn.Flatten(), nn.Linear(2 * 16, 2)).eval()
+    with pytest.raises(NotImplementedError, match="padding_mode"):
+        lrp_epsilon_plus_flat(m, {"1": m[1]}, torch.rand(1, 3, 4, 4), None)
