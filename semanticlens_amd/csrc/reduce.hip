@@ -1163,8 +1163,22 @@ void launch_colreduce(ProfScope& prof, const T* x, int64_t B, int T_, int64_t F,
   const int64_t nchunk = (F + 255) / 256, per_b = (int64_t)T_ * F * (int64_t)sizeof(T), bytes = B * per_b;
   int64_t tail_from = 0;  // everything with the default policy
   if (bytes >= nt_min_bytes) tail_from = tail_bytes > 0 ? (bytes > tail_bytes ? (bytes - tail_bytes) / per_b * nchunk : 0) : INT64_MAX;
-  if (B * nchunk < 2 * (int64_t)num_cus() && t1 - t0 >= 128)  // too few tasks for 4-wave workgroups: 16 waves split T
+  // waves per task (they split the reduced axis): enough of them that a CU holds ~24 waves with 8 loads in flight each.
+  // (B, 197, 768) at B = 256 is 768 tasks: 4-wave workgroups put 12 waves on a CU (5.4 TB/s cold), 8-wave ones 24.
+  static const int forced_nw = [] {
+    const char* e = getenv("SL_COLREDUCE_NW");
+    return e ? atoi(e) : 0;
+  }();
+  const int64_t tasks = B * nchunk, rows = t1 - t0, cus = num_cus();
+  int nw = 4;
+  if (tasks < 2 * cus && rows >= 128) nw = 16;
+  else if (tasks * 4 < 24 * cus && rows >= 64) nw = 8;
+  if (forced_nw == 4 || forced_nw == 8 || forced_nw == 16) nw = forced_nw;
+  if (nw == 16)
     SL_LAUNCH(prof, (colreduce_kernel<T, OP, 16>), dim3((unsigned)blocks), dim3(1024), 0, st, x, B, T_, F, sb, st_, t0, t1, denom,
+              tail_from, cand, outf);
+  else if (nw == 8)
+    SL_LAUNCH(prof, (colreduce_kernel<T, OP, 8>), dim3((unsigned)blocks), dim3(512), 0, st, x, B, T_, F, sb, st_, t0, t1, denom,
               tail_from, cand, outf);
   else
     SL_LAUNCH(prof, (colreduce_kernel<T, OP, 4>), dim3((unsigned)blocks), dim3(256), 0, st, x, B, T_, F, sb, st_, t0, t1, denom,

@@ -3,6 +3,7 @@
 //   reduce_lab pipe       in-pipeline: an in-place ReLU over the input (what torchvision's Bottleneck ends with) runs on
 //                         the same stream right before every reduce; the reduce's own dispatch time comes from sl_prof;
 //                         sweeps sl_set_reduce_policy(nt_min_bytes, tail_bytes)
+//   reduce_lab pipe1      the same with the SHIPPED policy only (48 launches per shape): the run to put under rocprofv3
 // Build: tools/native/build_reduce_lab.sh [-DSL_REDUCE_LAB=n] [-DSL_REDUCE_LAB_HEAD_AUX=a -DSL_REDUCE_LAB_TAIL_AUX=b -DSL_REDUCE_LAB_TAIL_FIRST=1]
 #include "../../semanticlens_amd/csrc/reduce.hip"
 
@@ -99,7 +100,7 @@ static void producer_mode(const std::vector<float*>& bufs, uint16_t* cand) {
   sl_set_reduce_policy(-1, -1);
 }
 
-static void pipe_mode(const std::vector<float*>& bufs, uint16_t* cand) {
+static void pipe_mode(const std::vector<float*>& bufs, uint16_t* cand, bool shipped_only = false) {
   const Shape shapes[] = {{256, 512, 784}, {256, 1024, 196}, {256, 2048, 49}};
   struct Pol { int64_t nt_min, tail; const char* name; };
   const Pol pols[] = {{-1, -1, "default (256 MiB / 240 MiB)"}, {0, 0, "all nt"}, {1ll << 40, 0, "all default-policy"},
@@ -109,6 +110,7 @@ static void pipe_mode(const std::vector<float*>& bufs, uint16_t* cand) {
                       {64ll << 20, 64ll << 20, "nt_min 64, tail 64"}};
   CK(hipDeviceSynchronize());
   for (const Pol& p : pols) {
+    if (shipped_only && &p != &pols[0]) break;  // `pipe1`: the shipped policy only, so that a kernel trace of the run holds one regime
     sl_set_reduce_policy(p.nt_min, p.tail);
     double tot_b = 0, tot_ms = 0;
     printf("policy %-40s", p.name);
@@ -116,7 +118,7 @@ static void pipe_mode(const std::vector<float*>& bufs, uint16_t* cand) {
       const int64_t n = s.B * s.C * s.S, bytes = n * 4;
       sl_prof_enable(1);
       sl_prof_reset();
-      const int iters = 12;
+      const int iters = shipped_only ? 48 : 12;
       for (int i = 0; i < iters; ++i) {
         float* x = bufs[i % bufs.size()];
         hipLaunchKernelGGL(relu_inplace_kernel, dim3((unsigned)((n / 4 + 1023) / 1024)), dim3(256), 0, nullptr, (float4*)x, n / 4);
@@ -144,6 +146,7 @@ int main(int argc, char** argv) {
   for (auto& b : bufs) { CK(hipMalloc(&b, maxbytes)); CK(hipMemcpy(b, h.data(), maxbytes, hipMemcpyHostToDevice)); }
   uint16_t* cand; CK(hipMalloc(&cand, 64 << 20));
   if (argc > 1 && !strcmp(argv[1], "pipe")) { pipe_mode(bufs, cand); return 0; }
+  if (argc > 1 && !strcmp(argv[1], "pipe1")) { pipe_mode(bufs, cand, true); return 0; }
   if (argc > 1 && !strcmp(argv[1], "fixed")) { fixed_mode(bufs, cand); return 0; }
   if (argc > 1 && !strcmp(argv[1], "producer")) { producer_mode(bufs, cand); return 0; }
   sl_set_reduce_policy(0, 0);  // cold inputs: every byte with the streaming policy

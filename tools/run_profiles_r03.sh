@@ -20,6 +20,10 @@ python bench.py --steps 20 --warmup 3 > $O/${R}_bench_line.json 2> $O/${R}_bench
 python bench.py --steps 20 --warmup 3 --quick > $O/${R}_bench_line_quick.json 2>> $O/${R}_bench_line.err
 trace k1_inpipeline python bench.py --steps 20 --warmup 3 --quick
 mv $O/${R}_k1_inpipeline.stdout $O/${R}_bench_line_quick_profiled.json
+# one stream (no encoder beside K1): the tool's host-side launch cost cannot shift the overlap of two streams
+python bench.py --steps 20 --warmup 3 --quick --no-overlap > $O/${R}_bench_line_quick1s.json 2>> $O/${R}_bench_line.err
+trace k1_inpipeline1s python bench.py --steps 20 --warmup 3 --quick --no-overlap
+mv $O/${R}_k1_inpipeline1s.stdout $O/${R}_bench_line_quick1s_profiled.json
 python tools/k1_cold_target.py > $O/${R}_k1_cold_events.json 2>> $O/${R}_bench_line.err
 trace k1_cold python tools/k1_cold_target.py
 mv $O/${R}_k1_cold.stdout $O/${R}_k1_cold_events_profiled.json
@@ -27,9 +31,10 @@ trace enc python tools/encoder_prof.py
 rm -f $O/${R}_enc.stdout
 (cd tools/native && ./build_reduce_lab.sh > /dev/null 2>&1)
 if [ -x tools/native/reduce_lab ]; then
-  tools/native/reduce_lab pipe > $O/${R}_reduce_pipe_lab.log 2>&1
-  trace reduce_pipe tools/native/reduce_lab pipe
-  mv $O/${R}_reduce_pipe.stdout $O/${R}_reduce_pipe_lab_profiled.log
+  tools/native/reduce_lab pipe > $O/${R}_reduce_pipe_lab.log 2>&1        # policy sweep (no tool)
+  tools/native/reduce_lab pipe1 > $O/${R}_reduce_pipe1_lab.log 2>&1      # shipped policy only (no tool)
+  trace reduce_pipe1 tools/native/reduce_lab pipe1                       # the same under the kernel trace
+  mv $O/${R}_reduce_pipe1.stdout $O/${R}_reduce_pipe1_lab_profiled.log
 fi
 python tools/roofline_check.py $O $R > $O/${R}_roofline_check.txt 2>&1
 pmc() {  # name target counters...
