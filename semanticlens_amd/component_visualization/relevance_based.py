@@ -53,6 +53,21 @@ def activation_sum(tensor):
     raise RuntimeError("activation_sum labels the activation cache; the reduction runs inside RelevanceComponentVisualizer")
 
 
+def relevance_max(tensor):
+    raise RuntimeError("relevance_max labels the relevance cache; the reduction runs inside RelevanceComponentVisualizer")
+
+
+def relevance_max_absnorm(tensor):
+    raise RuntimeError("relevance_max_absnorm labels the relevance cache; the reduction runs inside RelevanceComponentVisualizer")
+
+
+def activation_max(tensor):
+    raise RuntimeError("activation_max labels the activation cache; the reduction runs inside RelevanceComponentVisualizer")
+
+
+_LABELS = {"sum": (relevance_sum, relevance_sum_absnorm, activation_sum), "max": (relevance_max, relevance_max_absnorm, activation_max)}
+
+
 def gradient_x_activation(model: nn.Module, layers: dict[str, nn.Module], images: torch.Tensor, targets: torch.Tensor | None):
     """``{layer: (activation, relevance)}`` for one batch: relevance = activation * d sum_b logit[b, target_b] / d activation.
 
@@ -97,7 +112,7 @@ class RelevanceComponentVisualizer(ActivationComponentVisualizer):
     """Reference samples per component by summed relevance (and by summed activation).
 
     Parameters follow ``ActivationComponentVisualizer`` (model, the two datasets, layer names, cache directory) and the
-    reference's relevance class: ``aggregation_fn`` (only ``"sum"``, the reference's default, is provided), ``abs_norm``
+    reference's relevance class: ``aggregation_fn`` (``"sum"``, the reference's default, or ``"max"``: crp's ``max_target``), ``abs_norm``
     (default True), ``num_samples`` (default 100), ``composite`` (``"epsilon_plus_flat"`` — default —,
     ``"gradient_x_activation"``, or a callable) / ``attribution`` (a callable as :func:`gradient_x_activation`; wins),
     ``use_labels`` (take the targets from the dataset's labels instead of the model's prediction; crp conditions on the
@@ -107,8 +122,8 @@ class RelevanceComponentVisualizer(ActivationComponentVisualizer):
     def __init__(self, model: nn.Module, dataset_model, dataset_fm, layer_names, num_samples: int = 100,
                  aggregation_fn: str = "sum", abs_norm: bool = True, attribution=None, use_labels: bool = False,
                  device=None, cache_dir: str | None = None, tie_mode: str | None = None, composite="epsilon_plus_flat"):
-        if aggregation_fn != "sum":
-            raise ValueError("only aggregation_fn='sum' (the reference's default max_target) is provided")
+        if aggregation_fn not in _LABELS:  # crp's `max_target`: "sum" (the reference's default) or "max" over the spatial / token axis
+            raise ValueError(f"aggregation_fn must be 'sum' or 'max' (crp's max_target), got {aggregation_fn!r}")
         layer_names = [layer_names] if not isinstance(layer_names, list) else layer_names
         self.abs_norm = bool(abs_norm)
         self.aggregation_fn = aggregation_fn
@@ -125,9 +140,9 @@ class RelevanceComponentVisualizer(ActivationComponentVisualizer):
         self.attribution = attribution
         self.use_labels = use_labels
         # the parent builds `actmax_cache` (relevance mode here) and loads an existing cache
+        rel_label, rel_norm_label, act_label = _LABELS[aggregation_fn]
         super().__init__(model, dataset_model, dataset_fm, layer_names, num_samples, device=device,
-                         aggregate_fn=relevance_sum_absnorm if self.abs_norm else relevance_sum, cache_dir=cache_dir,
-                         tie_mode=tie_mode)
+                         aggregate_fn=rel_norm_label if self.abs_norm else rel_label, cache_dir=cache_dir, tie_mode=tie_mode)
         self.num_samples = num_samples
         # relevance is signed (more so after abs_norm): empty slots start at -inf, not at the reference's -0.0, so that a
         # component with fewer than num_samples non-negative relevances ranks its negative ones (crp: argsort descending)
@@ -136,7 +151,7 @@ class RelevanceComponentVisualizer(ActivationComponentVisualizer):
         for state in self.actmax_cache.cache.values():  # not yet set up (n_latents unknown), or loaded from a cache
             state.init_value = -float("inf")
         # activation mode: crp's ActMax with abs_norm=False (relevance_based.py:140-145)
-        self.activation_cache = ActMaxCache(self.layer_names, n_collect=num_samples, aggregation_fn=activation_sum,
+        self.activation_cache = ActMaxCache(self.layer_names, n_collect=num_samples, aggregation_fn=act_label,
                                             tie_mode=self.actmax_cache.tie_mode, init_value=-float("inf"))
         if self.caching:
             try:
@@ -147,16 +162,18 @@ class RelevanceComponentVisualizer(ActivationComponentVisualizer):
 
     # ---- collection ------------------------------------------------------------------------------------------------
     def _summed(self, t: torch.Tensor) -> torch.Tensor:
-        """(B, C, H, W) or (B, T, F) -> (B, C) fp32 sums on the device (K1 / K2 arithmetic, no bf16 rounding yet)."""
+        """(B, C, H, W) or (B, T, F) -> (B, C) fp32 sums (or maxima, ``aggregation_fn="max"``) on the device (K1 / K2
+        arithmetic, no bf16 rounding yet)."""
+        code = N.SL_CONV_SUM if self.aggregation_fn == "sum" else N.SL_CONV_MAX
         t = N.to_device(t.detach(), self.device).to(torch.float32)
         if t.ndim == 4:
             out = torch.empty(t.shape[:2], dtype=torch.float32, device=t.device)
-            N.reduce_conv(t, N.SL_CONV_SUM, None, out)
+            N.reduce_conv(t, code, None, out)
             return out
         if t.ndim == 3:  # tokens: sum over T = mean * T would round twice; use the (B, F, T) view of K1
             tt = t.transpose(1, 2).unsqueeze(2)  # (B, F, 1, T) strided view: no copy, K1's component-contiguous path
             out = torch.empty((t.shape[0], t.shape[2]), dtype=torch.float32, device=t.device)
-            N.reduce_conv(tt, N.SL_CONV_SUM, None, out)
+            N.reduce_conv(tt, code, None, out)
             return out
         if t.ndim == 2:
             return t.contiguous()

@@ -1171,7 +1171,10 @@ void launch_colreduce(ProfScope& prof, const T* x, int64_t B, int T_, int64_t F,
   }();
   const int64_t tasks = B * nchunk, rows = t1 - t0, cus = num_cus();
   int nw = 4;
-  if (tasks < 2 * cus && rows >= 128) nw = 16;
+  // measured cold (tools/reduce_dtype_bench.py, SL_COLREDUCE_NW = 4 / 8 / 16): (256, 197, 768) fp32 5.52 / 5.63 / 5.46 TB/s,
+  // (48, 729, 1152) fp32 5.46 / 5.73 / 5.45 and fp16 3.7 / 5.45 / 5.03, channels_last 14 x 14 fp16 5.74 / 5.94 / 4.0;
+  // short reduced axes (7 x 7 = 49 rows, 50 tokens) lose with more than four waves
+  if (tasks * 2 < cus && rows >= 128) nw = 16;
   else if (tasks * 4 < 24 * cus && rows >= 64) nw = 8;
   if (forced_nw == 4 || forced_nw == 8 || forced_nw == 16) nw = forced_nw;
   if (nw == 16)

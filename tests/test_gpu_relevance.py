@@ -275,3 +275,28 @@ def test_epsilon_plus_flat_composite_end_to_end_on_a_resnet_style_network(tmp_pa
     assert not torch.equal(cv.get_max_reference("layer1"), cv.get_act_max_sample_ids("layer1"))
     with pytest.raises(ValueError, match="composite"):
         RelevanceComponentVisualizer(model, ds, ds, layers, composite="lrp-gamma")
+    with pytest.raises(ValueError, match="aggregation_fn"):
+        RelevanceComponentVisualizer(model, ds, ds, layers, aggregation_fn="mean")
+
+
+def test_max_target_max_aggregates_with_the_spatial_maximum():
+    """crp's `max_target="max"` (the reference forwards `aggregation_fn` to it, relevance_based.py:124): the spatial maximum
+    instead of the sum, then the same abs-norm and top-k; cache files carry the aggregator in their name."""
+    model = nn.Sequential(nn.Conv2d(3, 4, 1))
+    model.name = "stub"
+    ds = TensorPairDataset(torch.zeros(20, 3, 2, 2))
+    cv = RelevanceComponentVisualizer(model.to(DEV), ds, ds, ["0"], num_samples=4, aggregation_fn="max", tie_mode="aten")
+    g = torch.Generator().manual_seed(2)
+    ref_rel = oracle.ActMaxOracle(4, 6, oracle.MODE_ATEN, init_value=-np.inf)
+    ref_act = oracle.ActMaxOracle(4, 6, oracle.MODE_ATEN, init_value=-np.inf)
+    for step in range(2):
+        rel = torch.randint(-9, 10, (10, 6, 5, 5), generator=g).to(torch.float32)
+        act = torch.randint(0, 9, (10, 6, 5, 5), generator=g).to(torch.float32)
+        ids = torch.arange(step * 10, step * 10 + 10)
+        cv.collect_relevance("0", act.to(DEV), rel.to(DEV), ids)
+        ref_rel.update(oracle.abs_norm_rows(oracle.agg_conv(rel.numpy(), "max")), ids.numpy())
+        ref_act.update(oracle.agg_conv(act.numpy(), "max"), ids.numpy())
+    am, aa = cv.actmax_cache.cache["0"], cv.activation_cache.cache["0"]
+    assert np.array_equal(bits(am.activations), ref_rel.vals) and np.array_equal(am.sample_ids.numpy(), ref_rel.ids)
+    assert np.array_equal(bits(aa.activations), ref_act.vals) and np.array_equal(aa.sample_ids.numpy(), ref_act.ids)
+    assert cv.actmax_cache.agg_fn_name == "relevance_max_absnorm" and cv.activation_cache.agg_fn_name == "activation_max"
