@@ -297,6 +297,74 @@ def test_conv_reduce_half_precision_fast_paths(shape, dt):
                 assert np.array_equal(got[~fin & ~np.isnan(want)], want[~fin & ~np.isnan(want)]), (tag, shape)
 
 
+DMA_HALF_SHAPES = [(128, 1024, 7, 7), (64, 512, 14, 14), (16, 512, 28, 28), (256, 2048, 3, 3), (128, 512, 9, 10), (512, 1024, 4, 4),
+                   (256, 512, 8, 8), (16, 256, 32, 32), (131, 1001, 7, 7), (512, 1024, 2, 4)]
+
+
+@pytest.mark.parametrize("shape", DMA_HALF_SHAPES)
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_conv_reduce_half_precision_dma_ring_special_values(shape, dt):
+    """fp16 / bf16 NCHW inputs of >= 8 MB take `rowreduce_dma_kernel<T>` (round 3): aligned rows in one and in several steps
+    (4 x 4, 8 x 8, 28 x 28, 32 x 32), unaligned rows with per-lane element masks (3 x 3, 7 x 7, 9 x 10, 14 x 14), and a row count
+    the task rule excludes (131 x 1001 rows, not a multiple of eight: back to rowreduce_h).  NaN, +-inf, all -inf rows, values at a row's first and last
+    element and in the tensor's last row; max exact (NaN propagates like torch.amax), mean within one ulp of the dtype."""
+    rng = np.random.RandomState(sum(shape) + (3 if dt == torch.float16 else 4))
+    B, C, H, W = shape
+    assert B * C * H * W * 2 >= 8 << 20
+    x = torch.from_numpy(rng.randn(B * C, H * W).astype(np.float32)).to(dt)
+    R, S = x.shape
+    rows = np.unique(np.concatenate([rng.choice(R, size=200, replace=False), [0, 1, R - 2, R - 1]]))
+    for i, r in enumerate(rows):
+        kind, c = i % 7, rng.randint(S)
+        if kind == 0:
+            x[r, c] = float("nan")
+        elif kind == 1:
+            x[r, c] = float("inf")
+            x[r, (c + 1) % S] = -float("inf")
+        elif kind == 2:
+            x[r, :] = -float("inf")
+        elif kind == 3:
+            x[r, S - 1] = float("nan")
+        elif kind == 4:
+            x[r, 0] = float("inf")
+        elif kind == 5:
+            x[r, :] = -3.0
+            x[r, S - 1] = 5.0  # the maximum in the row's last element: an edge piece of the next lane group
+        else:
+            x[r, :] = -3.0
+            x[r, 0] = 7.0
+    xd = x.view(shape).to(DEV)
+    xf = x.float().numpy().reshape(shape)
+    ulp = 2.0 ** -10 if dt == torch.float16 else 2.0 ** -7
+    for name, code in (("max", N.SL_CONV_MAX), ("mean", N.SL_CONV_MEAN)):
+        want = oracle.agg_conv(xf, name)
+        cand = torch.empty((B, C), dtype=torch.bfloat16, device=DEV)
+        out = torch.empty((B, C), dtype=torch.float32, device=DEV)
+        N.reduce_conv(xd, code, cand, out)
+        got = out.cpu().numpy()
+        if name == "max":
+            assert feq(got, want), shape
+            assert np.array_equal(bits(cand), oracle.f32_to_bf16(want)), shape
+        else:
+            want = torch.from_numpy(want).to(dt).float().numpy()
+            assert np.array_equal(np.isnan(got), np.isnan(want)), shape
+            fin = np.isfinite(want)
+            np.testing.assert_allclose(got[fin], want[fin], rtol=ulp, atol=1e-6)
+            assert np.array_equal(got[~fin & ~np.isnan(want)], want[~fin & ~np.isnan(want)]), shape
+    # absmax / absmean through the token entry point on the transposed view (B, T = S, F = C) with the token axis contiguous
+    xt = xd.view(B, C, H * W).transpose(1, 2)
+    for name in ("absmax", "absmean"):
+        got = getattr(agg, f"aggregate_transformer_{name}")(xt).float().numpy()
+        want = oracle.agg_tokens(np.ascontiguousarray(xf.reshape(B, C, H * W).transpose(0, 2, 1)), name)
+        if name == "absmax":
+            assert feq(got, want), (shape, name)
+        else:
+            want = torch.from_numpy(want).to(dt).float().numpy()
+            assert np.array_equal(np.isnan(got), np.isnan(want)), (shape, name)
+            fin = np.isfinite(want)
+            np.testing.assert_allclose(got[fin], want[fin], rtol=ulp, atol=1e-6)
+
+
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_half_precision_full_size_equals_torch(dt):
     """ResNet-50 layer shapes at the bench batch size: the kernels' max equals torch.amax bit for bit in both layouts."""
