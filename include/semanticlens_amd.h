@@ -237,6 +237,12 @@ int sl_layernorm(const float* d_x, int64_t rows, int64_t cols, int64_t x_row_str
  * head_dim in {32, 64, 72, 80, 88, 96, 104, 128}; any sequence length (K/V stream through LDS in chunks). */
 int sl_attention(const float* d_qkv, int64_t B, int64_t T, int64_t H, int64_t head_dim, int causal, float* d_out,
                  uint16_t* d_out_split, void* stream);
+/* sl_attention in the split-bf16 x3 arithmetic of sl_linear_bf16x3: both products (q k^T and p v) as a_lo b_hi + a_hi b_lo +
+ * a_hi b_hi on the bf16 matrix cores, fp32 softmax and accumulation (~1e-5 relative); same layouts, arguments and head_dims.
+ * What NativeClip / NativeSigLip call between two sl_linear_bf16x3 (reference: the attention inside open_clip's towers,
+ * foundation_models/clip.py:103-135). */
+int sl_attention_bf16x3(const float* d_qkv, int64_t B, int64_t T, int64_t H, int64_t head_dim, int causal, float* d_out,
+                        uint16_t* d_out_split, void* stream);
 /* Attention pooling with one query per head (the MAP head of SigLIP image towers, clip.py:190-211 SigLipV2 /
  * open_clip attn_pool): out (B, H*head_dim) = softmax(q k_t / sqrt(head_dim)) v over the T tokens of each image.
  * d_q (H*head_dim) is the projected probe; key row (b, t) is d_kv + (b*T + t) * kv_row_stride, its value row v_offset

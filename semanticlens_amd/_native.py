@@ -69,6 +69,7 @@ SIGNATURES = {
     "sl_linear": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "sl_layernorm": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, ctypes.c_float, _vp, _vp, _i64, _vp]),
     "sl_attention": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp]),
+    "sl_attention_bf16x3": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp]),
     "sl_patchify": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "sl_attention_pool": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
     "sl_split_elems": (_sz, [_i64, _i64]),
@@ -578,13 +579,16 @@ def layernorm(x, gamma, beta, eps, out=None, rows=None, x_row_stride=None, out_s
     return out if out is not None else out_split
 
 
-def attention(qkv, B, T, H, head_dim, causal, out=None, out_split: Split | None = None):
+def attention(qkv, B, T, H, head_dim, causal, out=None, out_split: Split | None = None, bf16x3: bool = False):
+    """softmax(q k^T / sqrt(d)) v per (batch, head).  ``bf16x3``: both products in the split-bf16 x3 arithmetic of
+    :func:`linear3` (``sl_attention_bf16x3``) instead of fp32-input MFMAs."""
     _need_f32("attention", qkv, out)
     if out is None and out_split is None:
         out = torch.empty((B * T, H * head_dim), dtype=torch.float32, device=qkv.device)
+    fn = lib().sl_attention_bf16x3 if bf16x3 else lib().sl_attention
     with torch.cuda.device(qkv.device):
-        rc = lib().sl_attention(_ptr(qkv), B, T, H, head_dim, 1 if causal else 0, _ptr(out), _split_ptr(out_split), _stream(qkv))
-    _check(rc, "sl_attention")
+        rc = fn(_ptr(qkv), B, T, H, head_dim, 1 if causal else 0, _ptr(out), _split_ptr(out_split), _stream(qkv))
+    _check(rc, "sl_attention_bf16x3" if bf16x3 else "sl_attention")
     return out if out is not None else out_split
 
 

@@ -426,6 +426,253 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
   }
 }
 
+// ---- the same attention with split-bf16 x3 products on the bf16 matrix cores (round 3) ---------------------------------
+// attention_mfma_kernel issues fp32-input MFMAs: 16 K matrix-pipe cycles per (image, head) at T = 50 — a 24 µs floor per
+// ViT-B/32 block, 69 µs measured, 0.85 ms per encode.  In the bf16x3 arithmetic mode of the towers (every GEMM around this
+// kernel already computes a*b as a_lo*b_hi + a_hi*b_lo + a_hi*b_hi) the two products of attention take the same form on
+// v_mfma_f32_32x32x16_bf16: 96 cycles per 16 k instead of 512.
+//   S^T (keys x queries) = K Q^T : A = K rows from LDS (lane l: key l % 32, dims 16 s + 8 (l / 32) + [0, 8), hi and lo planes),
+//                                  B = Q^T from registers (lane l: query l % 32, the same dims, pre-scaled, split once)
+//   O^T (dims x queries) += V^T P^T : B = P^T straight from the score accumulator: k-step s2 of a 32-key tile takes, for the
+//                                  lane half h, the keys (r & 3) + 8 (r >> 2) + 4 h of registers r = 8 s2 .. 8 s2 + 7 — the rows
+//                                  those registers hold — so P never moves between lanes; A = V^T from LDS, stored
+//                                  TRANSPOSED ([dim][key]) with the keys of a tile permuted into that order, 16 bytes per read.
+// Online softmax, masking, chunking over the keys and the output layout are those of the fp32 kernel.  K rows and V^T rows
+// carry 16 bytes of padding: a 16-lane group's ds_read_b128 then covers the 64 banks once.
+typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
+typedef float afloatx16 __attribute__((ext_vector_type(16)));
+
+__host__ __device__ constexpr int attn3_dp(int D) { return (D + 15) / 16 * 16; }   // dims per K row (k-steps of 16)
+__host__ __device__ constexpr int attn3_kc() { return 128; }                       // keys in LDS at a time
+
+// position of key `kk` (0..31 of its tile) in a V^T row: block (2 s2 + h) of eight, j-th of the block
+__device__ inline int attn3_vpos(int kk) {
+  const int r = (kk & 3) + 4 * (kk >> 3), h = (kk >> 2) & 1;
+  return (2 * (r >> 3) + h) * 8 + (r & 7);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attention_bf16x3_kernel(const float* __restrict__ qkv, int T, int H, int causal, float scale,
+                                                                float* __restrict__ out, uint16_t* __restrict__ osp) {
+  constexpr int kDh = D;
+  constexpr int DP = attn3_dp(D), NS = DP / 16;  // k-steps of the score product
+  constexpr int NT = (D + 31) / 32;              // output tiles of 32 dims
+  constexpr int KROW = DP * 2 + 16;              // bytes per K row (one plane)
+  extern __shared__ __align__(16) unsigned char smem3[];
+  const int Tp = (T + 31) & ~31;
+  const int KC = Tp < attn3_kc() ? Tp : attn3_kc();
+  const int VROW = KC * 2 + 16;  // bytes per V^T row (one plane)
+  unsigned char* sKh = smem3;
+  unsigned char* sKl = sKh + (size_t)KC * KROW;
+  unsigned char* sVh = sKl + (size_t)KC * KROW;
+  unsigned char* sVl = sVh + (size_t)(NT * 32) * VROW;
+  const int tid = threadIdx.x;
+  const int nwaves = blockDim.x >> 6;
+  const int w = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int64_t b = blockIdx.x / H;
+  const int h = blockIdx.x % H;
+  const int64_t ld = 3ll * H * kDh;
+  const float* base = qkv + b * T * ld + h * kDh;
+  const int nqt = Tp / 32, kct = KC / 32;
+  int loaded = -1;
+  auto split8 = [](const float* v, abf16x8& hi, abf16x8& lo) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const __bf16 hb = (__bf16)v[j];
+      hi[j] = hb;
+      lo[j] = (__bf16)(v[j] - (float)hb);
+    }
+  };
+  for (int qt0 = 0; qt0 < nqt; qt0 += nwaves) {
+    const int qt = qt0 + w;
+    const bool active = qt < nqt;
+    const int q = qt * 32 + li;
+    // the query's dims are only REQUESTED here; they are scaled and split after the first K / V chunk has been staged, so
+    // that the wave does not sit out one memory round trip for Q before it asks for K and V
+    float4 qraw[NS][2];
+    {
+      const float* qp = base + (int64_t)(q < T ? q : T - 1) * ld;
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int d0 = 16 * s + 8 * lh + 4 * c;
+          qraw[s][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (d0 < D) qraw[s][c] = *reinterpret_cast<const float4*>(qp + d0);  // D % 8 == 0: whole float4s
+        }
+    }
+    abf16x8 qh[NS], ql[NS];
+    bool q_ready = false;
+    afloatx16 o[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
+    float m = -__builtin_huge_valf(), l = 0.f;
+    const int round_last = qt0 + nwaves < nqt ? qt0 + nwaves : nqt;
+    const int nkt_round = causal ? round_last : nqt;
+    const int nkt = !active ? 0 : (causal ? qt + 1 : nqt);
+    for (int kc0 = 0; kc0 < nkt_round; kc0 += kct) {
+      if (kc0 != loaded) {
+        if (loaded >= 0) __syncthreads();
+        // K rows: [hi(DP) | pad] and [lo(DP) | pad]; V^T rows per dim: keys of the chunk in `attn3_vpos` order.  Zero past D / T.
+        // A thread takes FOUR consecutive keys x four dims: eight 16-byte global loads in flight, and — four aligned keys
+        // are four consecutive V^T positions — the 4 x 4 transpose leaves as 8-byte LDS stores (one key x four dims per
+        // thread meant eight serial round trips per thread and 2-byte stores: 50 -> 3x µs per ViT-B/32 block).
+        constexpr int C4 = NT * 8;  // float4 chunks per source row that any plane needs (dims < NT * 32 >= DP)
+        for (int e = tid; e < (KC / 4) * C4; e += blockDim.x) {
+          const int tl0 = (e / C4) * 4, c = e % C4;
+          float4 kv[4], vv[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int t = kc0 * 32 + tl0 + i;
+            kv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            vv[i] = kv[i];
+            if (t < T && c * 4 < D) {
+              kv[i] = *reinterpret_cast<const float4*>(base + t * ld + (int64_t)H * kDh + c * 4);
+              vv[i] = *reinterpret_cast<const float4*>(base + t * ld + 2ll * H * kDh + c * 4);
+            }
+          }
+          auto pack4 = [](float a, float b2, float c2, float d2, uint2& hi, uint2& lo) __attribute__((always_inline)) {
+            const float f[4] = {a, b2, c2, d2};
+            uint16_t hb[4], lb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const __bf16 hh = (__bf16)f[j];
+              hb[j] = __builtin_bit_cast(uint16_t, hh);
+              lb[j] = __builtin_bit_cast(uint16_t, (__bf16)(f[j] - (float)hh));
+            }
+            hi = make_uint2(hb[0] | ((uint32_t)hb[1] << 16), hb[2] | ((uint32_t)hb[3] << 16));
+            lo = make_uint2(lb[0] | ((uint32_t)lb[1] << 16), lb[2] | ((uint32_t)lb[3] << 16));
+          };
+          if (c * 4 < DP) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              uint2 hi, lo;
+              pack4(kv[i].x, kv[i].y, kv[i].z, kv[i].w, hi, lo);
+              *reinterpret_cast<uint2*>(sKh + (size_t)(tl0 + i) * KROW + c * 8) = hi;
+              *reinterpret_cast<uint2*>(sKl + (size_t)(tl0 + i) * KROW + c * 8) = lo;
+            }
+          }
+          const int pos0 = (tl0 & ~31) + attn3_vpos(tl0 & 31);  // keys tl0 .. tl0 + 3 sit at pos0 .. pos0 + 3
+          const float vt[4][4] = {{vv[0].x, vv[1].x, vv[2].x, vv[3].x}, {vv[0].y, vv[1].y, vv[2].y, vv[3].y},
+                                  {vv[0].z, vv[1].z, vv[2].z, vv[3].z}, {vv[0].w, vv[1].w, vv[2].w, vv[3].w}};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            uint2 hi, lo;
+            pack4(vt[j][0], vt[j][1], vt[j][2], vt[j][3], hi, lo);
+            const size_t off = (size_t)(c * 4 + j) * VROW + pos0 * 2;
+            *reinterpret_cast<uint2*>(sVh + off) = hi;
+            *reinterpret_cast<uint2*>(sVl + off) = lo;
+          }
+        }
+        loaded = kc0;
+        __syncthreads();
+      }
+      if (!q_ready) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const float v[8] = {qraw[s][0].x * scale, qraw[s][0].y * scale, qraw[s][0].z * scale, qraw[s][0].w * scale,
+                              qraw[s][1].x * scale, qraw[s][1].y * scale, qraw[s][1].z * scale, qraw[s][1].w * scale};
+          split8(v, qh[s], ql[s]);
+        }
+        q_ready = true;
+      }
+      const int kt_end = kc0 + kct < nkt ? kc0 + kct : nkt;
+      for (int kt = kc0; kt < kt_end; ++kt) {
+        const int kl = (kt - kc0) * 32;
+        afloatx16 st;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) st[e] = 0.f;
+        const unsigned char* kph = sKh + (size_t)(kl + li) * KROW + lh * 16;
+        const unsigned char* kpl = sKl + (size_t)(kl + li) * KROW + lh * 16;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const abf16x8 kh = *reinterpret_cast<const abf16x8*>(kph + s * 32);
+          const abf16x8 klo = *reinterpret_cast<const abf16x8*>(kpl + s * 32);
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klo, qh[s], st, 0, 0, 0);  // small terms first, as in the GEMMs
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[s], st, 0, 0, 0);
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[s], st, 0, 0, 0);
+        }
+        float mx = -__builtin_huge_valf();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const bool masked = key >= T || (causal && key > q);
+          st[r] = masked ? -__builtin_huge_valf() : st[r];
+          mx = fmaxf(mx, st[r]);
+        }
+        mx = fmaxf(mx, xhalf(mx));
+        const float mn = fmaxf(m, mx);
+        const float alpha = expf(m - mn);
+        float ps = 0.f;
+        float pv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          pv[r] = expf(st[r] - mn);
+          ps += pv[r];
+        }
+        ps += xhalf(ps);
+        l = l * alpha + ps;
+        m = mn;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          abf16x8 ph, pl;
+          split8(pv + 8 * s2, ph, pl);
+          const size_t col = (size_t)(kl + (2 * s2 + lh) * 8) * 2;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const abf16x8 vh = *reinterpret_cast<const abf16x8*>(sVh + (size_t)(32 * t + li) * VROW + col);
+            const abf16x8 vl = *reinterpret_cast<const abf16x8*>(sVl + (size_t)(32 * t + li) * VROW + col);
+            o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, o[t], 0, 0, 0);
+            o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, o[t], 0, 0, 0);
+            o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // Output.  In the accumulator a lane owns ONE query (row of the output) and 4-dim groups of it, so stored directly every
+    // store instruction scatters 16-byte fragments over 32 different rows.  The tile goes through LDS instead (the K planes
+    // are free once every wave has left the key loop): [query][dim] fp32 with padded rows, read back so that the lanes of a
+    // 16-lane group (D = 64) cover one token's dims in order — whole 64-byte runs of the split layout / 256-byte fp32 rows.
+    __syncthreads();
+    {
+      constexpr int SROW = D * 4 + 16;  // staging row: D floats + 16 bytes (bank spread)
+      unsigned char* stage = smem3 + (size_t)w * 32 * SROW;
+      const float inv = 1.f / l;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = 32 * t + 8 * g + 4 * lh;
+          if (d < D)
+            *reinterpret_cast<float4*>(stage + (size_t)li * SROW + d * 4) =
+                make_float4(o[t][4 * g] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave reads only what it wrote itself: no barrier needed
+      constexpr int CPR = D / 4;  // 16-byte chunks per row
+      if (active) {
+        for (int e = lane; e < 32 * CPR; e += 64) {
+          const int row = e / CPR, c = e % CPR;
+          const int qq = qt * 32 + row;
+          if (qq < T) {
+            const float4 v = *reinterpret_cast<const float4*>(stage + (size_t)row * SROW + c * 16);
+            if (out) *reinterpret_cast<float4*>(out + (b * T + qq) * (int64_t)H * kDh + h * kDh + c * 4) = v;
+            if (osp) store_split4(v, b * T + qq, h * kDh + c * 4, split_kp((int64_t)H * kDh), osp);
+          }
+        }
+      }
+    }
+    __syncthreads();  // the next round's K / V fill may overwrite the staging area
+    loaded = -1;
+  }
+}
+
 // ---- patch extraction: (B, C, Hi, Wi) -> (B * gh * gw, C * P * P), k = c*P*P + py*P + px (conv weight order) --
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, int64_t B, int C, int Hi, int Wi,
                                                         int P, float* __restrict__ out, uint16_t* __restrict__ osp) {
@@ -661,6 +908,45 @@ SL_API int sl_attention(const float* d_qkv, int64_t B, int64_t T, int64_t H, int
                      d_out_split);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+template <int D>
+static int launch_attention_bf16x3(const float* qkv, int64_t B, int64_t T, int64_t H, int causal, float* out, uint16_t* osp,
+                                   hipStream_t st) {
+  const int64_t Tp = (T + 31) & ~(int64_t)31;
+  const int64_t kc = Tp < attn3_kc() ? Tp : attn3_kc();
+  const int NT = (D + 31) / 32;
+  const size_t smem = 2 * (size_t)kc * (attn3_dp(D) * 2 + 16) + 2 * (size_t)(NT * 32) * (kc * 2 + 16);
+  const int waves = (int)(Tp / 32 < 4 ? Tp / 32 : 4);
+  if (smem > 64 * 1024)
+    SL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_bf16x3_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  const float scale = (float)(1.0 / sqrt((double)D));
+  hipLaunchKernelGGL(attention_bf16x3_kernel<D>, dim3((unsigned)(B * H)), dim3(64 * waves), smem, st, qkv, (int)T, (int)H, causal,
+                     scale, out, osp);
+  SL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+SL_API int sl_attention_bf16x3(const float* d_qkv, int64_t B, int64_t T, int64_t H, int64_t head_dim, int causal, float* d_out,
+                               uint16_t* d_out_split, void* stream) {
+  SL_REQUIRE(B >= 0 && T >= 1 && H >= 1, "sl_attention_bf16x3: bad shape");
+  SL_REQUIRE(T < (1 << 24), "sl_attention_bf16x3: sequence length %lld too long", (long long)T);
+  if (B == 0) return 0;
+  SL_REQUIRE(d_qkv && (d_out || d_out_split), "sl_attention_bf16x3: null pointer");
+  SL_REQUIRE(B * H < (1ll << 31), "sl_attention_bf16x3: too many heads");
+  hipStream_t st = (hipStream_t)stream;
+  switch (head_dim) {
+    case 32: return launch_attention_bf16x3<32>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
+    case 64: return launch_attention_bf16x3<64>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
+    case 72: return launch_attention_bf16x3<72>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
+    case 80: return launch_attention_bf16x3<80>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
+    case 88: return launch_attention_bf16x3<88>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
+    case 96: return launch_attention_bf16x3<96>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
+    case 104: return launch_attention_bf16x3<104>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
+    case 128: return launch_attention_bf16x3<128>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
+    default: break;
+  }
+  SL_REQUIRE(false, "sl_attention_bf16x3: head_dim=%lld (built: 32, 64, 72, 80, 88, 96, 104, 128)", (long long)head_dim);
 }
 
 SL_API int sl_attention_pool(const float* d_q, const float* d_kv, int64_t kv_row_stride, int64_t v_offset, int64_t B, int64_t T,

@@ -215,14 +215,14 @@ class _Tower:
                 N.layernorm(x, *blk.ln1, out_split=h)
                 N.linear3(h, blk.s_qkv, blk.b_qkv, out=qkv)
                 if i == last and pool_rows is not None:
-                    att32 = N.attention(qkv, B, T, blk.heads, blk.head_dim, causal)
+                    att32 = N.attention(qkv, B, T, blk.heads, blk.head_dim, causal, bf16x3=True)
                     xp = N.gather_rows(x, pool_rows, check=False)
                     N.linear3(N.Split.of(N.gather_rows(att32, pool_rows, check=False)), blk.s_o, blk.b_o, residual=xp, out=xp)
                     hp = N.layernorm(xp, *blk.ln2, out_split=N.Split(B, W, x.device))
                     hidp = N.linear3(hp, blk.s_fc, blk.b_fc, act=blk.act, out_split=N.Split(B, F, x.device))
                     N.linear3(hidp, blk.s_pr, blk.b_pr, residual=xp, out=xp)
                     return xp
-                N.attention(qkv, B, T, blk.heads, blk.head_dim, causal, out_split=att)
+                N.attention(qkv, B, T, blk.heads, blk.head_dim, causal, out_split=att, bf16x3=True)  # both products split-bf16 x3
                 N.linear3(att, blk.s_o, blk.b_o, residual=x, out=x)  # x += out_proj(attn)
                 N.layernorm(x, *blk.ln2, out_split=h)
                 N.linear3(h, blk.s_fc, blk.b_fc, act=blk.act, out_split=hid)  # GELU output leaves as split bf16

@@ -151,6 +151,15 @@ def test_attention_matches_fp32_softmax_reference(T, causal, D):
     assert (sp.hi.float() + sp.lo.float() - got).abs().max().item() <= 2.0 ** -16 * got.abs().max().item() + 1e-9
     with pytest.raises(ValueError):
         N.attention(qkv, B, T, H, 48, causal)
+    # the split-bf16 x3 form (sl_attention_bf16x3: what the towers run between two bf16x3 GEMMs): both products as
+    # a_lo b_hi + a_hi b_lo + a_hi b_hi on the bf16 matrix cores — the dropped lo*lo terms are 2^-18 per product
+    got3 = N.attention(qkv, B, T, H, D, causal, bf16x3=True)
+    assert (got3 - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item()), (T, causal, D, (got3 - want).abs().max().item())
+    sp3 = N.Split(B * T, H * D, DEV)
+    N.attention(qkv, B, T, H, D, causal, out_split=sp3, bf16x3=True)
+    assert (sp3.hi.float() + sp3.lo.float() - got3).abs().max().item() <= 2.0 ** -16 * got3.abs().max().item() + 1e-9
+    with pytest.raises(ValueError):
+        N.attention(qkv, B, T, H, 48, causal, bf16x3=True)
 
 
 @pytest.mark.parametrize("cols", [4, 130, 200, 768, 1024, 1028, 2048])

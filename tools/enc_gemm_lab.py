@@ -81,4 +81,5 @@ def wall(fn, reps=50):
 print(f"layernorm -> split: {wall(lambda: N.layernorm(x, gam, bet, 1e-5, out_split=h)):.1f} us (wall, back to back)")
 T = 50
 B = M // T
-print(f"attention (B={B}, T={T}, 12 x 64) -> split: {wall(lambda: N.attention(qkv, B, T, 12, 64, False, out_split=o_split)):.1f} us")
+print(f"attention (B={B}, T={T}, 12 x 64) -> split: {wall(lambda: N.attention(qkv, B, T, 12, 64, False, out_split=o_split)):.1f} us (fp32 MFMA)  "
+      f"{wall(lambda: N.attention(qkv, B, T, 12, 64, False, out_split=o_split, bf16x3=True)):.1f} us (bf16x3)")
