@@ -196,6 +196,29 @@ __global__ __launch_bounds__(256) void norm_split_rows_kernel(RowSources src, in
   for (int64_t r = wave; r < rows; r += nw) {
     while (l + 1 < src.n && r >= src.start[l + 1]) ++l;  // rows ascend within a wave
     const float* p = src.ptr[l] + (r - src.start[l]) * K;
+    if ((K & 3) == 0 && K <= 2048 && (((uintptr_t)p) & 15) == 0) {
+      // rows of up to 2048 floats: read ONCE as 16-byte pieces into registers (two rows of the wave in flight would not fit),
+      // sum of squares in the scalar kernel's per-lane order (element i belongs to lane i % 64 there: here lane = (i / 4) % 64,
+      // so the sum is a different fp32 order — the inverse norm may differ in the last bit from row_inv_norm_kernel's)
+      float4 v[8];
+      float s4 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int64_t c = ((int64_t)j * 64 + lane) * 4;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < K) v[j] = *reinterpret_cast<const float4*>(p + c);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s4 += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+      for (int off = 32; off > 0; off >>= 1) s4 += __shfl_xor(s4, off, 64);
+      const float rinv4 = 1.f / fmaxf(sqrtf(s4), eps);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int64_t c = ((int64_t)j * 64 + lane) * 4;
+        if (c < Kp) gemm3::store_split4(make_float4(v[j].x * rinv4, v[j].y * rinv4, v[j].z * rinv4, v[j].w * rinv4), r, c, Kp, sp);
+      }
+      continue;
+    }
     float s = 0.f;
     for (int64_t i = lane; i < K; i += 64) s += p[i] * p[i];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
