@@ -518,6 +518,22 @@ def test_open_clip_wrappers_shapes_and_plumbing(fake_open_clip):
     assert ClipMobile(version="s2").url == "MobileCLIP-S2"
 
 
+def test_open_clip_preprocess_keeps_a_batch_the_transform_returns(fake_open_clip):
+    """clip.py:157-162: a non-list input goes through the preprocessor as is and only a 3-D result gains the batch axis; a
+    transform that already returns (B, 3, S, S) must not be stacked into 5-D."""
+    from PIL import Image
+
+    from semanticlens_amd.foundation_models import OpenClip
+
+    fm = OpenClip(url="x", device="cpu")
+    img = Image.new("RGB", (16, 16))
+    single = fm.preprocessor
+    assert fm.preprocess(img).shape == (1, 3, 8, 8)
+    fm.preprocessor = lambda im: torch.stack([single(im), single(im)])  # a batching transform
+    assert fm.preprocess(img).shape == (2, 3, 8, 8)
+    assert fm.preprocess([img, img, img]).shape == (3, 2, 3, 8, 8)  # the reference stacks whatever the transform gave, too
+
+
 def test_open_clip_missing_raises_import_error():
     from semanticlens_amd.foundation_models import OpenClip
 
