@@ -300,3 +300,63 @@ def test_max_target_max_aggregates_with_the_spatial_maximum():
     assert np.array_equal(bits(am.activations), ref_rel.vals) and np.array_equal(am.sample_ids.numpy(), ref_rel.ids)
     assert np.array_equal(bits(aa.activations), ref_act.vals) and np.array_equal(aa.sample_ids.numpy(), ref_act.ids)
     assert cv.actmax_cache.agg_fn_name == "relevance_max_absnorm" and cv.activation_cache.agg_fn_name == "activation_max"
+
+
+def test_epsilon_plus_flat_on_a_convnext_style_network_configs4():
+    """BASELINE configs[4] names ConvNeXt-L: depthwise 7 x 7 convolution, channels-last LayerNorm, Linear - GELU - Linear with
+    layer scale, residual add, strided downsampling convolutions.  The relevance visualizer with the LRP composite on the device
+    against the same attribution on a CPU copy + the oracle (sum, abs-norm, top-k), hooked at the stage outputs."""
+    import copy
+
+    from semanticlens_amd.component_visualization.lrp import lrp_epsilon_plus_flat
+
+    class Block(nn.Module):
+        def __init__(self, c):
+            super().__init__()
+            self.dwconv = nn.Conv2d(c, c, 7, padding=3, groups=c)
+            self.norm = nn.LayerNorm(c, eps=1e-6)
+            self.pwconv1, self.act, self.pwconv2 = nn.Linear(c, 4 * c), nn.GELU(), nn.Linear(4 * c, c)
+            self.gamma = nn.Parameter(0.5 * torch.ones(c))
+
+        def forward(self, x):
+            y = self.dwconv(x).permute(0, 2, 3, 1)
+            y = self.gamma * self.pwconv2(self.act(self.pwconv1(self.norm(y))))
+            return x + y.permute(0, 3, 1, 2)
+
+    class TinyConvNeXt(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.stem = nn.Conv2d(3, 8, 4, 4)
+            self.stage1 = nn.Sequential(Block(8), Block(8))
+            self.down = nn.Conv2d(8, 16, 2, 2)
+            self.stage2 = nn.Sequential(Block(16))
+            self.head = nn.Linear(16, 4)
+            self.name = "tiny-convnext"
+
+        def forward(self, x):
+            x = self.stage2(self.down(self.stage1(self.stem(x))))
+            return self.head(x.mean((2, 3)))
+
+    torch.manual_seed(6)
+    model = TinyConvNeXt().eval()
+    ref_model = copy.deepcopy(model)
+    n, k, bs = 29, 5, 8
+    x = torch.randn(n, 3, 32, 32)
+    layers = ["stage1", "stage2"]
+    ds = TensorPairDataset(x, name="cnx29")
+    cv = RelevanceComponentVisualizer(model.to(DEV), ds, ds, layers, num_samples=k, tie_mode="total")
+    cv.run(batch_size=bs)
+    mods = {nme: m for nme, m in ref_model.named_modules() if nme in layers}
+    widths = {"stage1": 8, "stage2": 16}
+    want = {name: oracle.ActMaxOracle(k, widths[name], oracle.MODE_TOTAL, init_value=-np.inf) for name in layers}
+    for s0 in range(0, n, bs):
+        per = lrp_epsilon_plus_flat(ref_model, mods, x[s0:s0 + bs], None)
+        for name in layers:
+            want[name].update(oracle.abs_norm_rows(oracle.agg_conv(per[name][1].numpy(), "sum")), np.arange(s0, min(n, s0 + bs)))
+    for name in layers:
+        got = cv.actmax_cache.cache[name]
+        gv, wv = got.activations.float().numpy(), oracle.bf16_to_f32(want[name].vals)
+        assert got.activations.shape == (widths[name], k) and np.isfinite(gv).all() and got.sample_ids.min().item() >= 0
+        assert np.allclose(gv, wv, rtol=2 ** -6, atol=1e-5), name  # GPU vs CPU convolutions: a few fp32 ulps before the bf16 rounding
+    db = Lens(FakeVLM(img_numel=3 * 32 * 32).to(DEV), device=DEV).compute_concept_db(cv, batch_size=bs)
+    assert db["stage1"].shape == (8, k, 16) and db["stage2"].shape == (16, k, 16)
