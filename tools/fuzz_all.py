@@ -242,6 +242,13 @@ def fuzz_encoder_ops(n=120):
         q, k, v = (t.reshape(B, T, H, hd).transpose(1, 2).double() for t in qkv.split(W, dim=1))
         want = Fn.scaled_dot_product_attention(q, k, v, is_causal=causal).transpose(1, 2).reshape(B * T, W)
         np.testing.assert_allclose(got.cpu().numpy(), want.float().cpu().numpy(), rtol=3e-5, atol=3e-5)
+        got3 = N.attention(qkv, B, T, H, hd, causal, bf16x3=True)  # split-bf16 x3 products (round 3)
+        sync()
+        np.testing.assert_allclose(got3.cpu().numpy(), want.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
+        sp = N.Split(B * T, W, DEV)
+        N.attention(qkv, B, T, H, hd, causal, out_split=sp, bf16x3=True)
+        sync()
+        np.testing.assert_allclose((sp.hi.float() + sp.lo.float()).cpu().numpy(), got3.cpu().numpy(), rtol=1e-4, atol=1e-5)
 
 
 FAMS = {"encoder": fuzz_encoder_ops, "preprocess": fuzz_preprocess, "template": fuzz_template, "collect": fuzz_collect, "reduce": fuzz_reduce, "tokens": fuzz_tokens, "gather": fuzz_gather, "similarity": fuzz_similarity, "scores": fuzz_scores}
