@@ -1174,8 +1174,10 @@ void launch_colreduce(ProfScope& prof, const T* x, int64_t B, int T_, int64_t F,
   // measured cold (tools/reduce_dtype_bench.py, SL_COLREDUCE_NW = 4 / 8 / 16): (256, 197, 768) fp32 5.52 / 5.63 / 5.46 TB/s,
   // (48, 729, 1152) fp32 5.46 / 5.73 / 5.45 and fp16 3.7 / 5.45 / 5.03, channels_last 14 x 14 fp16 5.74 / 5.94 / 4.0;
   // short reduced axes (7 x 7 = 49 rows, 50 tokens) lose with more than four waves
+  // In the pipeline (input just written, bench leg `tokens_collect`, seven runs) the 768-task shape reads 0.60-0.69 of spec with
+  // four waves against 0.55-0.65 with eight, so eight-wave workgroups are kept for grids below two tasks per CU.
   if (tasks * 2 < cus && rows >= 128) nw = 16;
-  else if (tasks * 4 < 24 * cus && rows >= 64) nw = 8;
+  else if (tasks < 2 * cus && rows >= 64) nw = 8;
   if (forced_nw == 4 || forced_nw == 8 || forced_nw == 16) nw = forced_nw;
   if (nw == 16)
     SL_LAUNCH(prof, (colreduce_kernel<T, OP, 16>), dim3((unsigned)blocks), dim3(1024), 0, st, x, B, T_, F, sb, st_, t0, t1, denom,
