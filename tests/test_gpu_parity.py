@@ -833,9 +833,9 @@ def test_fused_multi_layer_probe_equals_per_layer_similarity():
 
 
 def test_gemm_tile_variants_are_bit_identical(tmp_path):
-    """The 128x128 register-staged, the 256x128 LDS-DMA staged, the 256x256 ping-pong and the 256x256 8-phase split-bf16
-    kernels accumulate every output element in the same order: same bits (the variant is latched per process, hence
-    subprocesses).  Forcing a variant sends EVERY shape through it, ragged and tiny ones included."""
+    """The 128x128 register-staged, the 256x128 LDS-DMA staged, the 256x256 ping-pong, the 256x256 8-phase and the 160x256
+    three-stage (round 3) split-bf16 kernels accumulate every output element in the same order: same bits (the variant is
+    latched per process, hence subprocesses).  Forcing a variant sends EVERY shape through it, ragged and tiny ones included."""
     import os
     import subprocess
     import sys
@@ -859,11 +859,11 @@ torch.save(outs, sys.argv[1])
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for tile in ("128", "256", "512", "8"):
+    for tile in ("128", "256", "512", "8", "160"):
         out = tmp_path / f"g3_{tile}.pt"
         subprocess.run([sys.executable, "-c", code, str(out), root], check=True, env=dict(os.environ, SL_G3_TILE=tile))
         res[tile] = torch.load(out)
-    for other in ("256", "512", "8"):
+    for other in ("256", "512", "8", "160"):
         for a, b in zip(res["128"], res[other]):
             assert torch.equal(a, b), (other, tuple(a.shape))
     # the fp32-MFMA mode has two tile variants too (128 x 128 register-staged, 256 x 256 8-phase): same bits
