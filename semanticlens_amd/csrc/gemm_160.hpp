@@ -96,10 +96,11 @@ __global__ __launch_bounds__(512, 2) void gemm3_nt_160_kernel(const unsigned cha
   }
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
-  auto issue = [&](int stage, auto Ic) __attribute__((always_inline)) {
+  // `slot_off` = byte offset of the stage's slot (the caller keeps it as a counter: no division by three in the loop)
+  auto issue = [&](int stage, int slot_off, auto Ic) __attribute__((always_inline)) {
     constexpr int i = decltype(Ic)::value;
     const unsigned char* base = (from_a[i] ? A : B) + (int64_t)stage * 128;
-    unsigned char* l = dst[i] < 0 ? smem + NSLOT * STAGE_BYTES : smem + (stage % NSLOT) * STAGE_BYTES + dst[i];
+    unsigned char* l = dst[i] < 0 ? smem + NSLOT * STAGE_BYTES : smem + slot_off + dst[i];
     __builtin_amdgcn_global_load_lds((glb_void*)(base + src[i]), (lds_void*)l, 16, 0, 0);
   };
 
@@ -122,10 +123,11 @@ __global__ __launch_bounds__(512, 2) void gemm3_nt_160_kernel(const unsigned cha
     __builtin_amdgcn_sched_barrier(0);
   };
   // one phase = one k-half of a stage.  TAIL: one of the last two stages (the stage to fetch may not exist; waits are exact)
-  auto phase = [&](int stage, auto Kc, auto Tc) __attribute__((always_inline)) {
+  // cur_off / nxt_off: slot offsets of `stage` and of `stage + 2`
+  auto phase = [&](int stage, int cur_off, int nxt_off, auto Kc, auto Tc) __attribute__((always_inline)) {
     constexpr int kh = decltype(Kc)::value;
     constexpr bool TAIL = decltype(Tc)::value != 0;
-    const unsigned char* buf = smem + (stage % NSLOT) * STAGE_BYTES;
+    const unsigned char* buf = smem + cur_off;
     // ---- read slot: 10 A + 2 B fragments
     if (!(SL_G160_EXP & 2) || stage == 0)
 #pragma unroll
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_nt_160_kernel(const unsigned cha
 #define SL_G160_DMA(ii)                                  \
   do {                                                   \
     __builtin_amdgcn_sched_barrier(0);                   \
-    if (do_issue) issue(stage + 2, IntC<ii>());          \
+    if (do_issue) issue(stage + 2, nxt_off, IntC<ii>()); \
     __builtin_amdgcn_sched_barrier(0);                   \
   } while (0)
 #define SL_G160_MFMA(a, b, t) \
@@ -159,20 +161,20 @@ __global__ __launch_bounds__(512, 2) void gemm3_nt_160_kernel(const unsigned cha
     // per accumulator: lo*hi, hi*lo, hi*hi (small terms first), as in every kernel of gemm_bf16x3.hpp
     SL_G160_MFMA(fa[0][1], fb[0], 0);
     SL_G160_MFMA(fa[1][1], fb[0], 1);
-    SL_G160_DMA(kh == 0 ? 0 : 4);
     SL_G160_MFMA(fa[2][1], fb[0], 2);
+    SL_G160_DMA(kh == 0 ? 0 : 4);
     SL_G160_MFMA(fa[3][1], fb[0], 3);
-    SL_G160_DMA(kh == 0 ? 1 : 5);
     SL_G160_MFMA(fa[4][1], fb[0], 4);
     SL_G160_MFMA(fa[0][0], fb[1], 0);
-    SL_G160_DMA(kh == 0 ? 2 : 6);
+    SL_G160_DMA(kh == 0 ? 1 : 5);
     SL_G160_MFMA(fa[1][0], fb[1], 1);
     SL_G160_MFMA(fa[2][0], fb[1], 2);
-    if constexpr (kh == 0) SL_G160_DMA(3);
     SL_G160_MFMA(fa[3][0], fb[1], 3);
+    SL_G160_DMA(kh == 0 ? 2 : 6);
     SL_G160_MFMA(fa[4][0], fb[1], 4);
     SL_G160_MFMA(fa[0][0], fb[0], 0);
     SL_G160_MFMA(fa[1][0], fb[0], 1);
+    if constexpr (kh == 0) SL_G160_DMA(3);
     SL_G160_MFMA(fa[2][0], fb[0], 2);
     SL_G160_MFMA(fa[3][0], fb[0], 3);
     SL_G160_MFMA(fa[4][0], fb[0], 4);
@@ -184,11 +186,12 @@ __global__ __launch_bounds__(512, 2) void gemm3_nt_160_kernel(const unsigned cha
 
   if (ns > 0) {
     // prologue: stages 0 and 1 requested; stage 0 must have landed for every wave before anyone reads it
-    issue(0, IntC<0>()); issue(0, IntC<1>()); issue(0, IntC<2>()); issue(0, IntC<3>());
-    issue(0, IntC<4>()); issue(0, IntC<5>()); issue(0, IntC<6>());
+    issue(0, 0, IntC<0>()); issue(0, 0, IntC<1>()); issue(0, 0, IntC<2>()); issue(0, 0, IntC<3>());
+    issue(0, 0, IntC<4>()); issue(0, 0, IntC<5>()); issue(0, 0, IntC<6>());
     if (ns > 1) {
-      issue(1, IntC<0>()); issue(1, IntC<1>()); issue(1, IntC<2>()); issue(1, IntC<3>());
-      issue(1, IntC<4>()); issue(1, IntC<5>()); issue(1, IntC<6>());
+      issue(1, STAGE_BYTES, IntC<0>()); issue(1, STAGE_BYTES, IntC<1>()); issue(1, STAGE_BYTES, IntC<2>());
+      issue(1, STAGE_BYTES, IntC<3>()); issue(1, STAGE_BYTES, IntC<4>()); issue(1, STAGE_BYTES, IntC<5>());
+      issue(1, STAGE_BYTES, IntC<6>());
       asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -196,13 +199,20 @@ __global__ __launch_bounds__(512, 2) void gemm3_nt_160_kernel(const unsigned cha
     raw_barrier();
     if (grp == 1) raw_barrier();  // group 1 runs one barrier behind
     int s = 0;
+    int cur = 0, nxt = 2 * STAGE_BYTES;  // slot offsets of stage s and stage s + 2, advanced modulo three slots
+    auto advance = [&]() __attribute__((always_inline)) {
+      cur = cur + STAGE_BYTES == NSLOT * STAGE_BYTES ? 0 : cur + STAGE_BYTES;
+      nxt = nxt + STAGE_BYTES == NSLOT * STAGE_BYTES ? 0 : nxt + STAGE_BYTES;
+    };
     for (; s + 2 < ns; ++s) {  // stage s + 2 exists: constant waits
-      phase(s, IntC<0>(), IntC<0>());
-      phase(s, IntC<1>(), IntC<0>());
+      phase(s, cur, nxt, IntC<0>(), IntC<0>());
+      phase(s, cur, nxt, IntC<1>(), IntC<0>());
+      advance();
     }
     for (; s < ns; ++s) {
-      phase(s, IntC<0>(), IntC<1>());
-      phase(s, IntC<1>(), IntC<1>());
+      phase(s, cur, nxt, IntC<0>(), IntC<1>());
+      phase(s, cur, nxt, IntC<1>(), IntC<1>());
+      advance();
     }
     if (grp == 0) raw_barrier();
   }
