@@ -834,7 +834,7 @@ def test_fused_multi_layer_probe_equals_per_layer_similarity():
 
 def test_gemm_tile_variants_are_bit_identical(tmp_path):
     """The 128x128 register-staged, the 256x128 LDS-DMA staged, the 256x256 ping-pong, the 256x256 8-phase and the 160x256
-    three-stage (round 3) split-bf16 kernels accumulate every output element in the same order: same bits (the variant is
+    four-wave (round 3) split-bf16 kernels accumulate every output element in the same order: same bits (the variant is
     latched per process, hence subprocesses).  Forcing a variant sends EVERY shape through it, ragged and tiny ones included."""
     import os
     import subprocess
