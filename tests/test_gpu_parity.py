@@ -846,7 +846,7 @@ sys.path.insert(0, sys.argv[2])
 from semanticlens_amd import _native as N
 torch.manual_seed(0)
 outs = []
-for (q, c, d) in [(1000, 768, 1152), (130, 257, 64), (129, 128, 72), (1, 5, 4096), (300, 301, 104), (2048, 1024, 512), (513, 259, 200)]:
+for (q, c, d) in [(1000, 768, 1152), (130, 257, 64), (129, 128, 72), (1, 5, 4096), (300, 301, 104), (2048, 1024, 512), (513, 259, 200), (161, 257, 20), (320, 512, 32)]:  # the last two: a single k-tile
     x = torch.randn(q, d, device="cuda:0"); y = torch.randn(c, d, device="cuda:0")
     outs.append(N.similarity(x, y).cpu())
 # full-size probe (race screen for the LDS-DMA pipeline): three runs, order-sensitive checksums of the raw bits
