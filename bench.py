@@ -462,10 +462,21 @@ def probing_leg(dev):
     }
 
 
-def collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, cast=None, check_n=None):
+def collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, cast=None, check_n=None, overlap=None):
     """A short run of the same step on another probed model / aggregator / activation dtype, so that the reduce kernel that
     configuration selects gets its own driver-measured roofline object (algorithmic bytes / per-dispatch HIP-event time, as
-    for the headline) and its own oracle self-check."""
+    for the headline) and its own oracle self-check.  ``overlap``: embed on a second stream (None = as the headline)."""
+    global OVERLAP
+    saved = OVERLAP
+    if overlap is not None:
+        OVERLAP = bool(overlap)
+    try:
+        return _collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, cast, check_n)
+    finally:
+        OVERLAP = saved
+
+
+def _collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, cast, check_n):
     warm = [synth.synth_images_u8(torch.arange(10**7 + i * B, 10**7 + (i + 1) * B, device=dev)) for i in range(2)]
     cv_w = make_cv(model, 2 * B, args.k, args.tie_mode, layers, agg)
     finish_job(cv_w, run_steps(cv_w, fm, warm, 0, 2 * B, cast), 0, 2 * B, False)  # MIOpen / hipBLASLt pick their kernels
@@ -487,7 +498,8 @@ def collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, c
         "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": gbps / HBM_PEAK_GBPS if gbps else None, "traffic": None, "kernel": kernel, "launches": launches,
                      "avg_launch_us": ms / max(launches, 1) * 1e3, "algorithmic_bytes_per_launch": nbytes / max(launches, 1),
-                     "condition": "in-pipeline: inputs written by the model's last kernel microseconds earlier"},
+                     "condition": "in-pipeline: inputs written by the model's last kernel microseconds earlier, "
+                                  + ("embed on a second stream" if OVERLAP else "embed on the same stream")},
     }
     if not args.no_self_check:
         out["self_check"] = self_check(dev, model, fm, args, n=check_n or 2 * B, B=B, layers=layers, agg=agg, cast=cast)
@@ -740,8 +752,9 @@ def main():
             dev, fm, args, vit, [f"blocks.{i}" for i in range(12)], aggregators.aggregate_transformer_max,
             "colreduce (K2, (B, 197, 768) token activations, component axis contiguous)",
             "BASELINE configs[3] collect stage: ViT-B/16 (random init) probed model, all 12 encoder blocks (B,197,768) fp32, "
-            "aggregate_transformer_max, 7 262 208 B/image; embed = the headline's CLIP ViT-B/32", steps=min(n_batches, 12), B=Bt,
-            check_n=Bt)
+            "aggregate_transformer_max, 7 262 208 B/image; embed = the headline's CLIP ViT-B/32, on the SAME stream (beside a "
+            "GEMM-bound probed model a second stream loses 2-3 %: tools/k2_leg_probe.py)", steps=min(n_batches, 12), B=Bt,
+            check_n=Bt, overlap=False)
         del vit
     if single and not args.no_api_leg:
         line["api_path"] = api_path_leg(dev, model, fm_base, args)
