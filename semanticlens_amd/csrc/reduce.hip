@@ -596,7 +596,11 @@ constexpr int kDmaLdsPerCu = 160 * 1024;
 // T = float, _Float16 or uint16_t (bf16 bits): a 16-byte piece holds EPP = 4 or 8 elements; 2-byte rows start on any
 // 2-byte boundary, so the element masks of an unaligned row cover eight positions instead of four (round 3: fp16 / bf16
 // NCHW activations took rowreduce_h's VGPR loads, 3.5-3.7 TB/s at 14 x 14 and 7 x 7).
-template <typename T, int G, int U, int OP, bool ALIGNED>
+// MULTI (unaligned rows only): a row's window has more pieces than its G lanes — odd maps of 13 x 13 .. 15 x 15 (fp32, four
+// rows per task) or up to 30 x 30 (fp16 with S % 4 == 0, two rows per task): the lanes walk the window in steps of G pieces
+// and the element masks are recomputed per step (only a window's first and last piece are partial).
+// NI = 1-KiB LDS-DMA instructions per batch: 4, or 16 for MULTI tasks of 4-16 KiB (17 x 17 .. 31 x 31 maps), one per batch.
+template <typename T, int G, int U, int OP, bool ALIGNED, bool MULTI = false, int NI = kDmaMaxBatch / 1024>
 __global__ __launch_bounds__(256) void rowreduce_dma_kernel(const T* __restrict__ x, int64_t R, int S, float denom, int slot_bytes,
                                                              int64_t tail_from, uint16_t* __restrict__ cand,
                                                              float* __restrict__ outf) {
@@ -613,8 +617,9 @@ __global__ __launch_bounds__(256) void rowreduce_dma_kernel(const T* __restrict_
   const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int64_t wave0 = (int64_t)blockIdx.x * 4 + wave_in_block;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
+  static_assert(!(ALIGNED && MULTI), "aligned rows always walk in steps");
   const int npieces = ALIGNED ? S / EPP : (S + 2 * EPP - 2) / EPP;
-  const int nsteps = ALIGNED ? (npieces + G - 1) / G : 1;
+  const int nsteps = (ALIGNED || MULTI) ? (npieces + G - 1) / G : 1;
   const int h = ALIGNED ? 0 : ((g * S) & (EPP - 1));
   const uint32_t row_byte0 = (uint32_t)(((g * S) / EPP) * 16);
   const uint32_t task_bytes = (uint32_t)(RPT * S) * (uint32_t)sizeof(T);  // multiple of 16
@@ -631,7 +636,6 @@ __global__ __launch_bounds__(256) void rowreduce_dma_kernel(const T* __restrict_
   // batch tb of the tensor -> slot.  ALWAYS four instructions per batch, so the counted waits are compile-time
   // constants and the loop has no data-dependent branches: lanes past the batch's bytes are masked; an instruction that
   // would be empty (short batches; the tensor's last batch) keeps lane 0 alive on the batch's first 16 bytes.
-  constexpr int NI = kDmaMaxBatch / 1024;
   const int tail32 = tail_from > (int64_t)0x7fffffff ? 0x7fffffff : (int)tail_from;  // first task of the default-policy tail
   auto issue = [&](int task0, int nu, int slot) __attribute__((always_inline)) {
     const uint32_t nb = (uint32_t)nu * task_bytes;
@@ -728,6 +732,11 @@ __global__ __launch_bounds__(256) void rowreduce_dma_kernel(const T* __restrict_
       if constexpr (ALIGNED) {
         piece_ok = q < npieces;
         off = row_byte0 + (uint32_t)(piece_ok ? q : npieces - 1) * 16u;
+      } else if constexpr (MULTI) {
+        off = row_byte0 + (uint32_t)(q < npieces ? q : npieces - 1) * 16u;
+        const int pos = q * EPP - h;  // q >= npieces: pos >= S, every mask false
+#pragma unroll
+        for (int e = 0; e < EPP; ++e) km[e] = (unsigned)(pos + e) < (unsigned)S;
       } else {
         off = row_byte0 + (uint32_t)(li < npieces ? li : npieces - 1) * 16u;
       }
@@ -1073,7 +1082,7 @@ void launch_rowreduce_fast(ProfScope& prof, const float* x, int64_t R, int S, fl
   }
 }
 
-template <typename T, int G, int U, int OP, bool ALIGNED>
+template <typename T, int G, int U, int OP, bool ALIGNED, bool MULTI = false, int NI = kDmaMaxBatch / 1024>
 void launch_rowreduce_dma(ProfScope& prof, const T* x, int64_t R, int S, float denom, uint16_t* cand, float* outf, hipStream_t st) {
   constexpr int RPT = kWave / G;
   constexpr int ES = (int)sizeof(T);
@@ -1090,12 +1099,17 @@ void launch_rowreduce_dma(ProfScope& prof, const T* x, int64_t R, int S, float d
   const int64_t bytes = R * (int64_t)S * ES;
   int64_t tail_from = 0;  // tasks from here on use the default policy
   if (bytes >= nt_min_bytes) tail_from = tail_bytes > 0 ? (bytes > tail_bytes ? (bytes - tail_bytes) / ((int64_t)RPT * S * ES) : 0) : INT64_MAX;
-  SL_LAUNCH(prof, (rowreduce_dma_kernel<T, G, U, OP, ALIGNED>), dim3((unsigned)blocks), dim3(256), (size_t)lds, st, x, R, S, denom,
-            slot, tail_from, cand, outf);
+  if (lds > 64 * 1024) {  // dynamic LDS past 64 KiB has to be allowed per kernel
+    static const hipError_t allowed = hipFuncSetAttribute((const void*)rowreduce_dma_kernel<T, G, U, OP, ALIGNED, MULTI, NI>,
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLdsPerCu);
+    (void)allowed;
+  }
+  SL_LAUNCH(prof, (rowreduce_dma_kernel<T, G, U, OP, ALIGNED, MULTI, NI>), dim3((unsigned)blocks), dim3(256), (size_t)lds, st, x, R,
+            S, denom, slot, tail_from, cand, outf);
 }
 
 // U = tasks per batch (<= 4) so that a batch is at most 4 KiB; false when a task alone is larger
-template <int G, int OP, bool ALIGNED, typename T>
+template <int G, int OP, bool ALIGNED, typename T, bool MULTI = false>
 bool try_rowreduce_dma(ProfScope& prof, const T* x, int64_t R, int S, float denom, uint16_t* cand, float* outf, hipStream_t st) {
   static const bool enabled = [] {
     const char* e = getenv("SL_REDUCE_DMA");  // 0: always the VGPR-load kernels (A/B measurements)
@@ -1103,10 +1117,25 @@ bool try_rowreduce_dma(ProfScope& prof, const T* x, int64_t R, int S, float deno
   }();
   constexpr int RPT = kWave / G;
   const int64_t task_bytes = (int64_t)RPT * S * (int64_t)sizeof(T);
-  if (!enabled || task_bytes > kDmaMaxBatch || (task_bytes & 15) != 0 || R % RPT != 0 || R * (int64_t)S * (int64_t)sizeof(T) < (8ll << 20) ||
+  if (!enabled || task_bytes > (MULTI && sizeof(T) == 2 ? 16 * 1024 : kDmaMaxBatch) || (task_bytes & 15) != 0 || R % RPT != 0 || R * (int64_t)S * (int64_t)sizeof(T) < (8ll << 20) ||
       R > 0x7fffffffll)
     return false;  // small inputs: launch-bound either way; the kernel indexes tasks with 32 bits
   const int u = (int)(kDmaMaxBatch / task_bytes);
+  if constexpr (MULTI) {  // long windows: a task is 1-4 KiB, so one or two tasks per batch
+    if (task_bytes > kDmaMaxBatch) {
+      // 4-16 KiB: one task per batch of sixteen instructions, one workgroup per CU.  2-byte elements only: 17 x 17 fp16 maps
+      // 2.8 -> 4.1 TB/s against rowreduce_h, which leaves 27 of 64 lanes idle there; fp32 rows of this length lose
+      // (27 x 27: 5.7 -> 5.4 TB/s against launch_rowreduce<64, 4>) and stay on the VGPR-load kernel
+      if constexpr (sizeof(T) == 2) {
+        launch_rowreduce_dma<T, G, 1, OP, ALIGNED, true, 16>(prof, x, R, S, denom, cand, outf, st);
+        return true;
+      }
+      return false;
+    }
+    if (u >= 2) launch_rowreduce_dma<T, G, 2, OP, ALIGNED, true>(prof, x, R, S, denom, cand, outf, st);
+    else launch_rowreduce_dma<T, G, 1, OP, ALIGNED, true>(prof, x, R, S, denom, cand, outf, st);
+    return true;
+  }
   if (u >= 4) launch_rowreduce_dma<T, G, 4, OP, ALIGNED>(prof, x, R, S, denom, cand, outf, st);
   else if (u == 3) launch_rowreduce_dma<T, G, 3, OP, ALIGNED>(prof, x, R, S, denom, cand, outf, st);
   else if (u == 2) launch_rowreduce_dma<T, G, 2, OP, ALIGNED>(prof, x, R, S, denom, cand, outf, st);
@@ -1142,6 +1171,12 @@ void dispatch_rowreduce(ProfScope& prof, const float* x, int64_t R, int S, float
     if (need <= 8 && R % 8 == 0) SL_ROWREDUCE(8, 8, false);
     if (R % 4 == 0) SL_ROWREDUCE(16, 8, false);
 #undef SL_ROWREDUCE
+  }
+  // longer unaligned rows whose tasks still fit an LDS-DMA batch (<= 4 KiB): two rows per task when S is even (S <= 512),
+  // four otherwise (S <= 256: 13 x 13, 15 x 15 maps); the lanes walk a row's window in steps
+  if (S % 4 != 0 && need > 16) {
+    if (S % 2 == 0 && need > 32 && try_rowreduce_dma<32, OP, false, float, true>(prof, x, R, S, denom, cand, outf, st)) return;
+    if (try_rowreduce_dma<16, OP, false, float, true>(prof, x, R, S, denom, cand, outf, st)) return;
   }
   if (need <= 4) launch_rowreduce<4, 8, OP>(prof, x, R, S, denom, cand, outf, st);
   else if (need <= 8) launch_rowreduce<8, 8, OP>(prof, x, R, S, denom, cand, outf, st);
@@ -1223,6 +1258,11 @@ void dispatch_rowreduce_h(ProfScope& prof, const T* x, int64_t R, int S, float d
     if (np <= 8 && try_rowreduce_dma<8, OP, false>(prof, x, R, S, denom, cand, outf, st)) return;
     if (np <= 16 && try_rowreduce_dma<16, OP, false>(prof, x, R, S, denom, cand, outf, st)) return;
     if (np <= 32 && try_rowreduce_dma<32, OP, false>(prof, x, R, S, denom, cand, outf, st)) return;
+    // windows longer than a task's lanes, or rows whose short tasks are not whole pieces: walk the window in steps with the
+    // fewest rows per task that make it whole (2 rows when S % 4 == 0: S <= 1024; 4 when S is even: S <= 512; else 8: S <= 256)
+    if (S % 4 == 0 && try_rowreduce_dma<32, OP, false, T, true>(prof, x, R, S, denom, cand, outf, st)) return;
+    if (S % 2 == 0 && try_rowreduce_dma<16, OP, false, T, true>(prof, x, R, S, denom, cand, outf, st)) return;
+    if (try_rowreduce_dma<8, OP, false, T, true>(prof, x, R, S, denom, cand, outf, st)) return;
   }
 #define SL_ROWH(G, U, J)                                                                          \
   do {                                                                                            \

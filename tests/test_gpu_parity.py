@@ -298,7 +298,11 @@ def test_conv_reduce_half_precision_fast_paths(shape, dt):
 
 
 DMA_HALF_SHAPES = [(128, 1024, 7, 7), (64, 512, 14, 14), (16, 512, 28, 28), (256, 2048, 3, 3), (128, 512, 9, 10), (512, 1024, 4, 4),
-                   (256, 512, 8, 8), (16, 256, 32, 32), (131, 1001, 7, 7), (512, 1024, 2, 4)]
+                   (256, 512, 8, 8), (16, 256, 32, 32), (131, 1001, 7, 7), (512, 1024, 2, 4),
+                   # windows longer than a task's lanes (MULTI): 8 / 4 / 2 rows per task for odd S, even S, S % 4 == 0
+                   (128, 512, 13, 13), (64, 512, 15, 14), (32, 512, 18, 18), (16, 512, 30, 30), (128, 1024, 9, 9),
+                   # tasks of 4-16 KiB: one sixteen-instruction batch each
+                   (32, 512, 17, 17), (16, 512, 27, 27), (16, 512, 31, 33), (8, 512, 42, 42)]
 
 
 @pytest.mark.parametrize("shape", DMA_HALF_SHAPES)
@@ -363,6 +367,59 @@ def test_conv_reduce_half_precision_dma_ring_special_values(shape, dt):
             assert np.array_equal(np.isnan(got), np.isnan(want)), (shape, name)
             fin = np.isfinite(want)
             np.testing.assert_allclose(got[fin], want[fin], rtol=ulp, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(64, 512, 13, 13), (64, 256, 15, 15), (64, 512, 9, 14), (32, 256, 21, 22), (63, 511, 13, 13),
+                                   (32, 1024, 11, 11), (32, 256, 17, 17), (16, 256, 27, 27), (16, 256, 31, 33), (8, 256, 38, 39)])
+def test_conv_reduce_fp32_dma_ring_unaligned_long_windows(shape):
+    """fp32 rows that are not whole 16-byte pieces and longer than the 16 pieces of the single-step LDS-DMA path (odd maps of
+    11 x 11 .. 15 x 15: four rows per task; even S up to 512: two rows per task) walk their window in steps with per-step
+    element masks (`rowreduce_dma_kernel<..., MULTI>`); longer rows (17 x 17 .. 38 x 39) and 63 x 511 rows, which do not group
+    into tasks, take the VGPR-load kernel.
+    Special values at a row's first and last element, in the tensor's first and last rows; max exact, mean within 2e-6."""
+    rng = np.random.RandomState(sum(shape))
+    B, C, H, W = shape
+    assert B * C * H * W * 4 >= 8 << 20
+    x = torch.from_numpy(rng.randn(B * C, H * W).astype(np.float32))
+    R, S = x.shape
+    rows = np.unique(np.concatenate([rng.choice(R, size=200, replace=False), [0, 1, 2, 3, R - 4, R - 3, R - 2, R - 1]]))
+    for i, r in enumerate(rows):
+        kind, c = i % 7, rng.randint(S)
+        if kind == 0:
+            x[r, c] = float("nan")
+        elif kind == 1:
+            x[r, c] = float("inf")
+            x[r, (c + 1) % S] = -float("inf")
+        elif kind == 2:
+            x[r, :] = -float("inf")
+        elif kind == 3:
+            x[r, S - 1] = float("nan")
+        elif kind == 4:
+            x[r, 0] = float("inf")
+        elif kind == 5:
+            x[r, :] = -3.0
+            x[r, S - 1] = 5.0  # the maximum in the row's last element: shares a piece with the next row's first ones
+        else:
+            x[r, :] = -3.0
+            x[r, 0] = 7.0
+    xd = x.view(shape).to(DEV)
+    xf = x.numpy().reshape(shape)
+    for name, code in (("max", N.SL_CONV_MAX), ("mean", N.SL_CONV_MEAN), ("sum", N.SL_CONV_SUM)):
+        want = oracle.agg_conv(xf, "mean" if name == "sum" else name)
+        cand = torch.empty((B, C), dtype=torch.bfloat16, device=DEV)
+        out = torch.empty((B, C), dtype=torch.float32, device=DEV)
+        N.reduce_conv(xd, code, cand, out)
+        got = out.cpu().numpy()
+        if name == "max":
+            assert feq(got, want), shape
+            assert np.array_equal(bits(cand), oracle.f32_to_bf16(want)), shape
+        else:
+            if name == "sum":
+                want = want * np.float32(S)
+            assert np.array_equal(np.isnan(got), np.isnan(want)), (shape, name)
+            fin = np.isfinite(want)
+            np.testing.assert_allclose(got[fin], want[fin], rtol=2e-5 if name == "sum" else 2e-6, atol=1e-5 * (S if name == "sum" else 1))
+            assert np.array_equal(got[~fin & ~np.isnan(want)], want[~fin & ~np.isnan(want)]), (shape, name)
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
