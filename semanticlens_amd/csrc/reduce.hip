@@ -1178,6 +1178,9 @@ void dispatch_rowreduce(ProfScope& prof, const float* x, int64_t R, int S, float
     if (S % 2 == 0 && need > 32 && try_rowreduce_dma<32, OP, false, float, true>(prof, x, R, S, denom, cand, outf, st)) return;
     if (try_rowreduce_dma<16, OP, false, float, true>(prof, x, R, S, denom, cand, outf, st)) return;
   }
+  // Longer unaligned fp32 rows stay on the round-1 kernel (0.58-0.72 of spec cold).  Tried and dropped in round 3: reading
+  // each row from its own 4-byte-aligned start with unaligned 16-byte loads (legal on this part:
+  // tools/native/unaligned_probe.hip) — 17 x 17 4.7 -> 4.4 TB/s, 27 x 27 5.8 -> 5.4, 111 x 111 4.95 -> 5.26.
   if (need <= 4) launch_rowreduce<4, 8, OP>(prof, x, R, S, denom, cand, outf, st);
   else if (need <= 8) launch_rowreduce<8, 8, OP>(prof, x, R, S, denom, cand, outf, st);
   else if (need <= 16) launch_rowreduce<16, 8, OP>(prof, x, R, S, denom, cand, outf, st);
