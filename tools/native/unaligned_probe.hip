@@ -29,6 +29,24 @@ __global__ void stream(const float* __restrict__ x, size_t n4, int shift, float*
   if (acc == 123.456f) out[0] = acc;
 }
 
+// reference read stream: 32 waves per CU, four independent 16-byte streaming loads per lane and trip
+typedef float vf4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stream4(const vf4* __restrict__ x, size_t n4, float* out) {
+  float acc = 0.f;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const vf4 a = __builtin_nontemporal_load(x + i), b = __builtin_nontemporal_load(x + i + stride);
+    const vf4 c = __builtin_nontemporal_load(x + i + 2 * stride), d = __builtin_nontemporal_load(x + i + 3 * stride);
+    acc += (a.x + a.y + a.z + a.w) + (b.x + b.y + b.z + b.w) + (c.x + c.y + c.z + c.w) + (d.x + d.y + d.z + d.w);
+  }
+  for (; i < n4; i += stride) {
+    const vf4 a = __builtin_nontemporal_load(x + i);
+    acc += a.x + a.y + a.z + a.w;
+  }
+  if (acc == 123.456f) out[0] = acc;
+}
+
 int main() {
   float h[1024], *d, *o, ho[64 * 8];
   for (int i = 0; i < 1024; ++i) h[i] = (float)i;
@@ -64,6 +82,27 @@ int main() {
       if (r && ms < best) best = ms;
     }
     printf("1 GiB stream of 16-byte loads shifted by %d floats: %.0f GB/s\n", shift, n4 * 16.0 / best / 1e6);
+  }
+  // the same stream at the byte counts of K1's launches, cold (rotating through the 1 GiB allocation)
+  for (int variant : {0, 8, 16, 32})
+  for (size_t mb : {51, 103, 205, 411, 1024}) {
+    const size_t bytes = mb == 1024 ? n4 * 16 : mb * 1000 * 1000 / 16 * 16, n = bytes / 16;
+    const int nrot = (int)(n4 * 16 / bytes) > 0 ? (int)(n4 * 16 / bytes) : 1;
+    float tot = 0.f;
+    int cnt = 0;
+    for (int r = 0; r < 3 * nrot + 2; ++r) {
+      const vf4* src = reinterpret_cast<const vf4*>(big) + (size_t)(r % nrot) * n;
+      CHECK(hipEventRecord(a, 0));
+      if (variant == 0) hipLaunchKernelGGL(stream4, dim3(256 * 8), dim3(256), 0, 0, src, n, o);
+      else hipLaunchKernelGGL(stream, dim3(256 * variant), dim3(256), 0, 0, reinterpret_cast<const float*>(src), n, 0, o);
+      CHECK(hipEventRecord(b, 0));
+      CHECK(hipDeviceSynchronize());
+      float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+      if (r >= 2) { tot += ms; ++cnt; }
+    }
+    printf("%s x%-2d %4zu MB per launch (mean of %2d): %6.1f us  %.0f GB/s = %.3f of 8 TB/s\n",
+           variant ? "one load per lane and trip, blocks per CU" : "four loads 8 MB apart per lane and trip      ", variant ? variant : 8, mb, cnt,
+           tot / cnt * 1e3, bytes / (tot / cnt) / 1e6, bytes / (tot / cnt) / 8e9);
   }
   return 0;
 }
