@@ -26,6 +26,10 @@
 namespace sl {
 namespace {
 
+// The similarity matrices leave with streaming (nt) stores: 369 MB per text_probing call that nothing on the GPU re-reads
+// soon; with default stores the dirty lines are written back at the kernel boundary (the call 563 -> 547 us, the GEMM's own
+// HIP-event time 495 -> 498 us: tools/probing_ab.py, three alternating runs).  The encoder's epilogues keep default stores
+// (their consumer is the next kernel; nt there: 6.76 -> 6.79 ms per encode, tools/encoder_ab.py).
 // out[q][c] = acc * rinv_x[q] * rinv_y[c]
 struct CosineEpi {
   const float* ra;
@@ -33,14 +37,14 @@ struct CosineEpi {
   float* out;
   int64_t N;
   __device__ inline float column(int64_t col) const { return rb[col]; }
-  __device__ inline void store(int64_t row, int64_t col, float acc, float cv) const { out[row * N + col] = acc * ra[row] * cv; }
+  __device__ inline void store(int64_t row, int64_t col, float acc, float cv) const { __builtin_nontemporal_store(acc * ra[row] * cv, &out[row * N + col]); }
 };
 // operands were normalised before the bf16 split: the accumulator is the cosine
 struct PlainEpi {
   float* out;
   int64_t N;
   __device__ inline float column(int64_t) const { return 0.f; }
-  __device__ inline void store(int64_t row, int64_t col, float acc, float) const { out[row * N + col] = acc; }
+  __device__ inline void store(int64_t row, int64_t col, float acc, float) const { __builtin_nontemporal_store(acc, &out[row * N + col]); }
 };
 
 size_t align256_(size_t n) { return (n + 255) & ~(size_t)255; }
@@ -121,7 +125,7 @@ struct MultiEpi {
   }
   __device__ void store(int64_t row, int64_t col, float acc, float cv) const {
     const int l = __float_as_int(cv);
-    out[l][row * (start[l + 1] - start[l]) + (col - start[l])] = acc;
+    __builtin_nontemporal_store(acc, &out[l][row * (start[l + 1] - start[l]) + (col - start[l])]);
   }
 };
 
@@ -145,7 +149,7 @@ struct MultiCosineEpi {
   }
   __device__ void store(int64_t row, int64_t col, float acc, LayerCol cv) const {
     const int l = cv.layer;
-    out[l][row * (start[l + 1] - start[l]) + (col - start[l])] = acc * ra[row] * cv.rinv;
+    __builtin_nontemporal_store(acc * ra[row] * cv.rinv, &out[l][row * (start[l + 1] - start[l]) + (col - start[l])]);
   }
 };
 
