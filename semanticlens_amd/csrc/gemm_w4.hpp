@@ -32,7 +32,7 @@ constexpr int NSLOT = 3;
 #define SL_GW4_RD 0  // lab: 1 = all reads of a half in one burst behind its first MFMA, 2 = in pairs behind every second
 #endif
 #ifndef SL_GW4_EXP
-#define SL_GW4_EXP 0  // lab only (garbage results): 1 = no LDS-DMA in the k loop, 2 = no fragment reads, 3 = neither
+#define SL_GW4_EXP 0  // lab only (garbage results): 1 = no LDS-DMA in the k loop, 2 = no fragment reads, 3 = neither, 4 = no epilogue
 #endif
 
 template <int N_>
@@ -236,6 +236,17 @@ __global__ __launch_bounds__(256, 1) void gemm3_nt_w4_kernel(const unsigned char
     for (; s < ns; ++s) stage_body(s, IntC<1>());
   }
 
+  if (SL_GW4_EXP & 4) {  // lab: no epilogue (one impossible store keeps the accumulators alive)
+    float t = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < TM; ++tt)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) t += acc[tt][j][e];
+    if (t == 12345.678f) epi.store(m0, n0, t, epi.column(n0));
+    return;
+  }
   if (m0 + C::BM <= M && n0 + BN <= N) {
 #pragma unroll
     for (int t = 0; t < TM; ++t)
