@@ -71,6 +71,55 @@ def fuzz_reduce(n=300):
                 np.testing.assert_allclose(got[m], want[m], rtol=tol, atol=1e-5)
 
 
+def fuzz_reduce_big(n=80):
+    """Inputs of >= 8 MB (the LDS-DMA ring kernels and their step-walking variants take over there): random map sizes,
+    row counts that do and do not group into tasks, special values on row edges."""
+    for it in range(n):
+        H, W = int(rng.randint(1, 41)), int(rng.randint(1, 41))
+        dt = [torch.float32, torch.float16, torch.bfloat16][rng.randint(3)]
+        es = 4 if dt == torch.float32 else 2
+        rows = int((8 << 20) // (H * W * es)) + int(rng.randint(1, 4000))
+        C = int(rng.choice([rows // 7 + 1, 512, 509, 1024, 96]))
+        B = rows // C + 1
+        print("reduce_big", it, (B, C, H, W), dt, flush=True)
+        x = torch.from_numpy(rng.randn(B * C, H * W).astype(np.float32)).to(dt)
+        R, S = x.shape
+        for r in list(rng.choice(R, size=24, replace=False)) + [0, R - 1]:
+            kind = rng.randint(5)
+            c = rng.randint(S)
+            if kind == 0:
+                x[r, c] = float("nan")
+            elif kind == 1:
+                x[r, :] = -float("inf")
+            elif kind == 2:
+                x[r, :] = -2.0
+                x[r, S - 1] = 9.0
+            elif kind == 3:
+                x[r, :] = -2.0
+                x[r, 0] = 9.0
+            else:
+                x[r, c] = float("inf")
+        xd = x.view(B, C, H, W).to(DEV)
+        ref_in = x.float().numpy().reshape(B, C, H, W)
+        for name, code in (("max", N.SL_CONV_MAX), ("mean", N.SL_CONV_MEAN)):
+            out = torch.empty((B, C), dtype=torch.float32, device=DEV)
+            cand = torch.empty((B, C), dtype=torch.bfloat16, device=DEV)
+            N.reduce_conv(xd, code, cand, out)
+            sync()
+            want = oracle.agg_conv(ref_in, name)
+            got = out.cpu().numpy()
+            if name == "max":
+                assert feq(got, want), (name, np.argwhere(~((got == want) | (np.isnan(got) & np.isnan(want))))[:5])
+            else:
+                if dt != torch.float32:
+                    want = torch.from_numpy(want).to(dt).float().numpy()
+                assert np.array_equal(np.isnan(got), np.isnan(want))
+                tol = 2e-5 if dt == torch.float32 else (2.0 ** -9 if dt == torch.float16 else 2.0 ** -6)
+                m = np.isfinite(want)
+                np.testing.assert_allclose(got[m], want[m], rtol=tol, atol=1e-5)
+                assert np.array_equal(got[~m & ~np.isnan(want)], want[~m & ~np.isnan(want)])
+
+
 def fuzz_tokens(n=200):
     for it in range(n):
         B, T, F = int(rng.randint(1, 9)), int(rng.randint(1, 40)), int(rng.choice([1, 2, 3, 4, 5, 8, 12, 16, 31, 64, 260]))
@@ -251,7 +300,7 @@ def fuzz_encoder_ops(n=120):
         np.testing.assert_allclose((sp.hi.float() + sp.lo.float()).cpu().numpy(), got3.cpu().numpy(), rtol=1e-4, atol=1e-5)
 
 
-FAMS = {"encoder": fuzz_encoder_ops, "preprocess": fuzz_preprocess, "template": fuzz_template, "collect": fuzz_collect, "reduce": fuzz_reduce, "tokens": fuzz_tokens, "gather": fuzz_gather, "similarity": fuzz_similarity, "scores": fuzz_scores}
+FAMS = {"reduce_big": fuzz_reduce_big, "encoder": fuzz_encoder_ops, "preprocess": fuzz_preprocess, "template": fuzz_template, "collect": fuzz_collect, "reduce": fuzz_reduce, "tokens": fuzz_tokens, "gather": fuzz_gather, "similarity": fuzz_similarity, "scores": fuzz_scores}
 for name, fn in FAMS.items():
     if family in ("all", name):
         fn()
