@@ -27,7 +27,10 @@ def main(fetch_csv, write_csv, out_json):
     # (the template list continues with the cache-policy argument, hence prefix matches)
     # round 2: the LDS-DMA kernels rowreduce_dma_kernel<G, U, OP, ALIGNED>: layer2 <64, 1, ..>, layer3 <16, 1, ..>, layer4 <16, 4, .., false>
     # round 3: the element type leads the template list, rowreduce_dma_kernel<float, G, U, OP, ALIGNED>
-    algo = {"rowreduce_dma_kernel<float, 64, 1, 0, true>": 256 * 512 * 784 * 4, "rowreduce_dma_kernel<float, 16, 1, 0, true>": 256 * 1024 * 196 * 4,
+    # (later: further defaulted template arguments follow — MULTI, NI —, so the keys are prefixes without the closing bracket)
+    algo = {"rowreduce_dma_kernel<float, 64, 1, 0, true,": 256 * 512 * 784 * 4, "rowreduce_dma_kernel<float, 16, 1, 0, true,": 256 * 1024 * 196 * 4,
+            "rowreduce_dma_kernel<float, 16, 4, 0, false,": 256 * 2048 * 49 * 4,
+            "rowreduce_dma_kernel<float, 64, 1, 0, true>": 256 * 512 * 784 * 4, "rowreduce_dma_kernel<float, 16, 1, 0, true>": 256 * 1024 * 196 * 4,
             "rowreduce_dma_kernel<float, 16, 4, 0, false>": 256 * 2048 * 49 * 4,
             "rowreduce_dma_kernel<64, 1, 0, true>": 256 * 512 * 784 * 4, "rowreduce_dma_kernel<16, 1, 0, true>": 256 * 1024 * 196 * 4,
             "rowreduce_dma_kernel<16, 4, 0, false>": 256 * 2048 * 49 * 4}
