@@ -1,9 +1,10 @@
 // (32 TM) x 256 split-bf16 x3 NT GEMM, FOUR waves per workgroup — one per SIMD, software-pipelined (round 3).
 //
-// gemm_160.hpp showed what a 160-row tile is worth (one round instead of two on the 150-tile GEMMs of the encoder) and what
-// its eight-wave two-group schedule costs: four workgroup barriers per 30-MFMA stage and every A fragment read by all eight
-// waves.  Here each SIMD holds ONE wave that owns (32 TM) rows x 64 columns (2 TM accumulator tiles, 320 of its 512
-// registers at TM = 5) and overlaps its own LDS reads and LDS-DMA issues with its own MFMAs:
+// A first, eight-wave version of this tile (two wave groups one barrier apart; removed) showed what a 160-row tile is worth
+// (one round instead of two on the 150-tile GEMMs of the encoder) and what that schedule costs: four workgroup barriers per
+// 30-MFMA stage and every A fragment read by all eight waves.  Here each SIMD holds ONE wave that owns (32 TM) rows x 64
+// columns (2 TM accumulator tiles: 160 AGPRs + 156 VGPRs of its 512 registers at TM = 5) and overlaps its own LDS reads and
+// LDS-DMA issues with its own MFMAs:
 // * a stage (one 32-wide k-tile: A 32 TM lines + B 256 lines of 128 bytes) is two halves of 6 TM MFMAs (one 16-wide k-step:
 //   lo*hi, hi*lo, hi*hi per accumulator).  While the matrix pipe runs half h from fragment set h, the wave reads the
 //   2 TM + 4 fragments of the NEXT half into the other set — one `ds_read_b128` behind each of the first MFMAs — and
