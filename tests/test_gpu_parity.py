@@ -934,6 +934,48 @@ torch.save(outs, sys.argv[1])
         assert torch.equal(a, b), ("f32", tuple(a.shape))
 
 
+def test_linear_epilogues_are_bit_identical_across_tile_variants_on_ragged_shapes(tmp_path):
+    """The encoder's GEMM epilogues (bias, GELU -> split output, residual added in place, scattered rows + positional table)
+    through every split-bf16 tile variant, on shapes whose last row and column tiles are partial for each of them
+    (12 750 x 700: 80 tiles of 160 rows with 110 valid in the last, 50 of 256 with 206; 700 columns = 2.73 tiles): same bits,
+    and equal to the fp64 product within split-bf16 accuracy."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[2])
+from semanticlens_amd import _native as N
+torch.manual_seed(0)
+dev = "cuda:0"
+outs = []
+for (M, Nn, K) in [(12750, 700, 96), (321, 1030, 40), (12750, 768, 64)]:
+    x = torch.randn(M, K, device=dev); w = torch.randn(Nn, K, device=dev) * 0.1; b = torch.randn(Nn, device=dev)
+    sx, sw = N.Split.of(x), N.Split.of(w)
+    res = torch.randn(M, Nn, device=dev)
+    o1 = N.linear3(sx, sw, b)                                     # bias -> fp32
+    o2 = res.clone(); N.linear3(sx, sw, b, residual=o2, out=o2)   # bias + residual in place
+    sp = N.Split(M, Nn, dev); N.linear3(sx, sw, b, act=N.SL_ACT_GELU, out_split=sp)  # bias + GELU -> split
+    o3 = sp.hi.float() + sp.lo.float()
+    ref = (x.double() @ w.double().T + b.double())
+    outs += [o1.cpu(), o2.cpu(), o3.cpu(), (o1.double() - ref).abs().max().cpu(), ref.abs().max().cpu()]
+torch.save(outs, sys.argv[1])
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tile in ("128", "256", "8", "160"):
+        out = tmp_path / f"lin_{tile}.pt"
+        subprocess.run([sys.executable, "-c", code, str(out), root], check=True, env=dict(os.environ, SL_G3_TILE=tile))
+        res[tile] = torch.load(out)
+    for other in ("256", "8", "160"):
+        for i, (a, b) in enumerate(zip(res["128"], res[other])):
+            assert torch.equal(a, b), (other, i, tuple(a.shape))
+    for i in range(0, len(res["128"]), 5):
+        err, scale = float(res["128"][i + 3]), float(res["128"][i + 4])
+        assert err <= 2e-6 * max(scale, 1.0) * 4, (i, err, scale)
+
+
 def test_aggregator_goldens_half_precision(golden):
     """The reference's own outputs on fp16 / bf16 activations (tests/golden/aggregators_half.npz, CPU torch): result dtype =
     activation dtype; max / absmax exact; means within one ulp of that dtype (fp32 summation order differs)."""
