@@ -53,18 +53,36 @@ struct LinearEpi {
   int64_t rpg, gstride, roff;  // REMAP: out row = (r / rpg) * gstride + roff + r % rpg
   const float* rowadd;         // REMAP: (roff + r % rpg, col) of this (T, N) table is added (positional embedding)
   int64_t N;
+  uint32_t rpg_inv;            // REMAP: floor(2^32 / rpg) (2^32 - 1 for rpg = 1), for row / rpg without a division
+  // row -> (row / rpg, row % rpg), rows and rpg below 2^32: the high product underestimates the quotient by at most one
+  __device__ inline void divmod_rpg(int64_t row, uint32_t& q, uint32_t& rem) const {
+    const uint32_t r = (uint32_t)row, g = (uint32_t)rpg;
+    q = __umulhi(r, rpg_inv);
+    rem = r - q * g;
+    if (rem >= g) { q += 1; rem -= g; }
+    if (rem >= g) { q += 1; rem -= g; }
+  }
   __device__ inline float column(int64_t col) const { return bias ? bias[col] : 0.f; }
   // what `store` adds from memory, fetched ahead of the stores by kernels that batch their epilogue (gemm_8phase.hpp);
   // `store_fetched(..., fetch(row, col))` == `store(...)` bit for bit (same operands, same order of additions)
   static constexpr bool kFetches = RES || REMAP;
   __device__ inline int64_t out_row(int64_t row) const {
-    if constexpr (REMAP) return (row / rpg) * gstride + roff + row % rpg;
+    if constexpr (REMAP) {
+      // (two 64-bit divisions per element cost the patch-embedding GEMM 10 us of 176)
+      uint32_t q, rem;
+      divmod_rpg(row, q, rem);
+      return (int64_t)q * gstride + roff + (int64_t)rem;
+    }
     return row;
   }
   __device__ inline float2 fetch(int64_t row, int64_t col) const {  // (positional-table value, residual value)
     float2 f = make_float2(0.f, 0.f);
     if constexpr (REMAP) {
-      if (rowadd) f.x = rowadd[(roff + row % rpg) * N + col];
+      if (rowadd) {
+        uint32_t q, rem;
+        divmod_rpg(row, q, rem);
+        f.x = rowadd[(roff + (int64_t)rem) * N + col];
+      }
     }
     if constexpr (RES) f.y = res[out_row(row) * ldo + col];
     return f;
@@ -97,7 +115,8 @@ template <int ACT, bool RES, bool REMAP>
 int run_linear(ProfScope& prof, const float* x, int64_t M, int64_t K, const float* w, int64_t N, const float* bias,
                const float* res, float* out, int64_t ldo, int64_t rpg, int64_t gstride, int64_t roff,
                const float* rowadd, hipStream_t st) {
-  LinearEpi<ACT, RES, REMAP> epi{bias, res, out, nullptr, 0, ldo, rpg, gstride, roff, rowadd, N};
+  LinearEpi<ACT, RES, REMAP> epi{bias, res, out, nullptr, 0, ldo, rpg, gstride, roff, rowadd, N,
+                                 rpg > 1 ? (uint32_t)((1ull << 32) / (uint64_t)rpg) : 0xFFFFFFFFu};
   return gemm::launch_gemm_nt(prof, x, M, w, N, K, epi, st);
 }
 
@@ -105,7 +124,8 @@ template <int ACT, bool RES, bool REMAP, bool SPLIT>
 int run_linear3(ProfScope& prof, const uint16_t* xs, int64_t M, int64_t K, const uint16_t* ws, int64_t N, const float* bias,
                 const float* res, float* out, uint16_t* osp, int64_t ldo, int64_t rpg, int64_t gstride, int64_t roff,
                 const float* rowadd, hipStream_t st) {
-  LinearEpi<ACT, RES, REMAP, SPLIT> epi{bias, res, out, osp, split_kp(N), ldo, rpg, gstride, roff, rowadd, N};
+  LinearEpi<ACT, RES, REMAP, SPLIT> epi{bias, res, out, osp, split_kp(N), ldo, rpg, gstride, roff, rowadd, N,
+                                        rpg > 1 ? (uint32_t)((1ull << 32) / (uint64_t)rpg) : 0xFFFFFFFFu};
   return gemm3::launch_gemm3_nt(prof, xs, M, ws, N, K, epi, st);
 }
 
@@ -818,6 +838,7 @@ SL_API int sl_linear(const float* d_x, int64_t M, int64_t K, const float* d_w, i
   SL_REQUIRE(d_x && d_w && d_out, "sl_linear: null pointer");
   const bool remap = rows_per_group > 0;
   SL_REQUIRE(!(remap && (act != SL_ACT_NONE || d_residual)), "sl_linear: row scatter supports neither activation nor residual");
+  SL_REQUIRE(!remap || (M < (1ll << 32) && rows_per_group < (1ll << 32)), "sl_linear: row scatter indexes rows with 32 bits");
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof(SL_PROF_GEMM, st, 2.0 * (double)M * (double)N * (double)K);
 #define SL_RUN(A_, R_, P_) \
@@ -1025,6 +1046,7 @@ SL_API int sl_linear_bf16x3(const uint16_t* d_x_split, int64_t M, int64_t K, con
              "sl_linear_bf16x3: split matrices must be 128-byte aligned");
   const bool remap = rows_per_group > 0;
   SL_REQUIRE(!(remap && (act != SL_ACT_NONE || d_residual || split)), "sl_linear_bf16x3: row scatter is plain fp32 only");
+  SL_REQUIRE(!remap || (M < (1ll << 32) && rows_per_group < (1ll << 32)), "sl_linear_bf16x3: row scatter indexes rows with 32 bits");
   SL_REQUIRE(!(split && d_residual), "sl_linear_bf16x3: split output takes no residual");
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof(SL_PROF_GEMM, st, 2.0 * (double)M * (double)N * (double)K);

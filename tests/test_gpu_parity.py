@@ -976,6 +976,31 @@ torch.save(outs, sys.argv[1])
         assert err <= 2e-6 * max(scale, 1.0) * 4, (i, err, scale)
 
 
+@pytest.mark.parametrize("rpg,gs,ro", [(1, 3, 1), (2, 2, 0), (7, 9, 2), (49, 50, 1), (197, 200, 3), (1000, 1001, 1)])
+def test_linear_row_scatter_maps_rows_exactly(rpg, gs, ro):
+    """The scattering epilogue (patch embeddings land behind the class token of their image and take their row of the positional
+    table) computes row / rpg and row % rpg with a multiply-high + correction instead of divisions: every output row is the one
+    the formula names, every other row of the buffer stays untouched; both arithmetic modes."""
+    torch.manual_seed(rpg)
+    Ms = 3000
+    xs, ws = torch.randn(Ms, 64, device=DEV), torch.randn(96, 64, device=DEV) * 0.1
+    groups = -(-Ms // rpg)
+    tab = torch.randn(ro + rpg, 96, device=DEV)
+    r = torch.arange(Ms, device=DEV)
+    rows = (r // rpg) * gs + ro + r % rpg
+    want = xs.double() @ ws.double().T + tab[ro + r % rpg].double()
+    untouched = torch.ones(groups * gs + ro + rpg, dtype=torch.bool, device=DEV)
+    untouched[rows] = False
+    for mode in ("bf16x3", "f32"):
+        o = torch.full((groups * gs + ro + rpg, 96), 7.0, device=DEV)
+        if mode == "bf16x3":
+            N.linear3(N.Split.of(xs), N.Split.of(ws), None, out=o, scatter=(rpg, gs, ro), rowadd=tab)
+        else:
+            N.linear(xs, ws, None, out=o, scatter=(rpg, gs, ro), rowadd=tab)
+        assert float((o[rows].double() - want).abs().max()) < 1e-4, (mode, rpg)
+        assert bool((o[untouched] == 7.0).all()), (mode, rpg)
+
+
 def test_aggregator_goldens_half_precision(golden):
     """The reference's own outputs on fp16 / bf16 activations (tests/golden/aggregators_half.npz, CPU torch): result dtype =
     activation dtype; max / absmax exact; means within one ulp of that dtype (fp32 summation order differs)."""
