@@ -24,6 +24,7 @@
 #include "common.hpp"
 #include "gemm_8phase.hpp"
 #include "gemm_w4.hpp"
+#include "gemm_skinny.hpp"
 #include <cstdlib>
 
 namespace sl {
@@ -538,7 +539,7 @@ int launch_gemm3_nt(ProfScope& prof, const uint16_t* A, int64_t M, const uint16_
   const int64_t Kp = split_kp(K);
   static const int forced = [] {
     // 128: register-staged 128 x 128 tiles (kernel 1), 256: LDS-DMA staged 256 x 128 tiles (kernel 2),
-    // 512: ping-pong 256 x 256 (kernel 3), 8: 8-phase 256 x 256 (kernel 4), 160: 160 x 256 four-wave three-slot (gemm_w4.hpp);
+    // 512: ping-pong 256 x 256 (kernel 3), 8: 8-phase 256 x 256 (kernel 4), 160: 160 x 256 four-wave three-slot (gemm_w4.hpp), 64: 64 x 64 eight-slot ring for small grids (gemm_skinny.hpp);
     // unset: by grid size
     const char* e = getenv("SL_G3_TILE");
     return e ? atoi(e) : 0;
@@ -550,6 +551,9 @@ int launch_gemm3_nt(ProfScope& prof, const uint16_t* A, int64_t M, const uint16_
     SL_CHECK_HIP(hipGetLastError());
     return 0;
   }
+  // gemm_skinny.hpp: 64 x 64 tiles behind an eight-stage LDS-DMA ring for small grids with long k loops
+  if (gemm8::fits(M, N, 4 * Kp) && (forced ? forced == 64 : gemmsk::prefer(M, N, Kp / 32)))
+    return gemmsk::launch(prof, A, M, B, N, 4 * Kp, Kp / 32, epi, st);
   // gemm_w4.hpp: 160 x 256 tiles where they shorten the makespan (150-tile GEMMs of the encoder: 240 items in one round)
   if (gemm8::fits(M, N, 4 * Kp) && (forced ? forced == 160 : gemmw4::prefer(M, N)))
     return gemmw4::launch<5>(prof, A, M, B, N, 4 * Kp, Kp / 32, epi, st);
