@@ -539,7 +539,7 @@ int launch_gemm3_nt(ProfScope& prof, const uint16_t* A, int64_t M, const uint16_
   const int64_t Kp = split_kp(K);
   static const int forced = [] {
     // 128: register-staged 128 x 128 tiles (kernel 1), 256: LDS-DMA staged 256 x 128 tiles (kernel 2),
-    // 512: ping-pong 256 x 256 (kernel 3), 8: 8-phase 256 x 256 (kernel 4), 160: 160 x 256 four-wave three-slot (gemm_w4.hpp), 64: 64 x 64 eight-slot ring for small grids (gemm_skinny.hpp);
+    // 512: ping-pong 256 x 256 (kernel 3), 8: 8-phase 256 x 256 (kernel 4), 160: 160 x 256 four-wave three-slot (gemm_w4.hpp), 64 / 1280: 64 x 64 eight-slot / 128 x 128 four-slot ring for small grids (gemm_skinny.hpp);
     // unset: by grid size
     const char* e = getenv("SL_G3_TILE");
     return e ? atoi(e) : 0;
@@ -553,7 +553,8 @@ int launch_gemm3_nt(ProfScope& prof, const uint16_t* A, int64_t M, const uint16_
   }
   // gemm_skinny.hpp: 64 x 64 tiles behind an eight-stage LDS-DMA ring for small grids with long k loops
   if (gemm8::fits(M, N, 4 * Kp) && (forced ? forced == 64 : gemmsk::prefer(M, N, Kp / 32)))
-    return gemmsk::launch(prof, A, M, B, N, 4 * Kp, Kp / 32, epi, st);
+    return gemmsk::launch<1>(prof, A, M, B, N, 4 * Kp, Kp / 32, epi, st);
+  if (forced == 1280 && gemm8::fits(M, N, 4 * Kp)) return gemmsk::launch<2>(prof, A, M, B, N, 4 * Kp, Kp / 32, epi, st);
   // gemm_w4.hpp: 160 x 256 tiles where they shorten the makespan (150-tile GEMMs of the encoder: 240 items in one round)
   if (gemm8::fits(M, N, 4 * Kp) && (forced ? forced == 160 : gemmw4::prefer(M, N)))
     return gemmw4::launch<5>(prof, A, M, B, N, 4 * Kp, Kp / 32, epi, st);
@@ -563,6 +564,10 @@ int launch_gemm3_nt(ProfScope& prof, const uint16_t* A, int64_t M, const uint16_
     return gemm8::launch<gemm8::MODE_BF16X3>(prof, A, M, B, N, 4 * Kp, Kp / 32, epi, st);
   else if (k2)
     SL_LAUNCH(prof, (gemm3_nt_dma256_kernel<Epi>), dim3((unsigned)(tm3 * tn)), dim3(256), 0, st, A, B, M, N, Kp, (int)tn, epi);
+  else if (!forced && gemm8::fits(M, N, 4 * Kp) && Kp / 32 >= 8)
+    // mid-size grids: the same 128 x 128 tiles behind the four-stage LDS-DMA ring of gemm_skinny.hpp (5-30 % under the
+    // register-staged kernel from 450 to 2 400 tiles, equal at 4 800; tools/enc_gemm_lab.py <M> with SL_G3_TILE = 128 / 1280)
+    return gemmsk::launch<2>(prof, A, M, B, N, 4 * Kp, Kp / 32, epi, st);
   else
     SL_LAUNCH(prof, (gemm3_nt_kernel<Epi>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, A, B, M, N, Kp, (int)tn, epi);
   SL_CHECK_HIP(hipGetLastError());

@@ -1,4 +1,4 @@
-// 64 x 64 split-bf16 x3 NT GEMM for SMALL GRIDS (round 3): few output tiles, long k loops.
+// 64 x 64 (and 128 x 128) split-bf16 x3 NT GEMM for SMALL AND MID-SIZE GRIDS (round 3): few output tiles, long k loops.
 //
 // A GEMM with a handful of rows — one image (50 tokens), the class-token rows of the last transformer block (M = batch),
 // interactive probing — is a few tiles of any size, and each workgroup walks the whole K alone.  What matters then is the time
@@ -10,6 +10,8 @@
 //   instructions per wave): seven stages (~112 KB) in flight per workgroup, a step costs its six dependent MFMAs (~0.15 us);
 // * one workgroup barrier per stage; stage s + 7 is requested right behind the barrier of stage s into the slot stage s - 1
 //   left; a wave waits for its own share of stage s with a counted `vmcnt(24)`.
+// * the same schedule with 128 x 128 tiles (each wave 64 x 64, four 32-KB slots) serves the grids between this regime and
+//   the 256 x 256 kernels' (where the register-staged 128 x 128 kernel of round 1 used to run).
 // Same operands, LDS image, swizzle, fragment layout and per-element accumulation order (k ascending; lo*hi, hi*lo, hi*hi per
 // 16-wide k-step) as every kernel of gemm_bf16x3.hpp: bit-identical results, so an embedding does not depend on the batch it
 // was computed in (tests/test_gpu_parity.py::test_gemm_tile_variants_are_bit_identical, test_gpu_native_clip.py).
@@ -24,17 +26,24 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 64, BN = 64;
-constexpr int A_BYTES = BM * 128;
-constexpr int STAGE_BYTES = (BM + BN) * 128;  // 16 384
-constexpr int NSLOT = 8;
-constexpr int NI = (BM + BN) / 32;            // LDS-DMA instructions (8 lines each) per wave and stage: 4
-constexpr int LEAD = NSLOT - 1;               // stages requested ahead of the one being computed
+// WT = accumulator tiles per wave and side: 1 -> 64 x 64 tiles, eight 16-KB slots; 2 -> 128 x 128 tiles (each wave 64 x 64),
+// four 32-KB slots, for the mid-size grids above (the same ring in front of four times the MFMAs per step)
+template <int WT>
+struct Cfg {
+  static constexpr int BM = 64 * WT, BN = 64 * WT;
+  static constexpr int A_BYTES = BM * 128;
+  static constexpr int STAGE_BYTES = (BM + BN) * 128;  // 16 / 32 KB
+  static constexpr int NSLOT = 8 / WT;
+  static constexpr int NI = (BM + BN) / 32;            // LDS-DMA instructions (8 lines each) per wave and stage: 4 / 8
+  static constexpr int LEAD = NSLOT - 1;               // stages requested ahead of the one being computed
+};
 
-template <class Epi>
+template <int WT, class Epi>
 __global__ __launch_bounds__(256, 1) void gemm3_nt_skinny_kernel(const unsigned char* __restrict__ A, const unsigned char* __restrict__ B,
                                                                  int64_t M, int64_t N, int64_t row_bytes, int ns, int tiles_n,
                                                                  Epi epi) {
+  typedef Cfg<WT> C;
+  constexpr int BM = C::BM, BN = C::BN, A_BYTES = C::A_BYTES, STAGE_BYTES = C::STAGE_BYTES, NSLOT = C::NSLOT, NI = C::NI, LEAD = C::LEAD;
   __shared__ __align__(1024) unsigned char smem[NSLOT * STAGE_BYTES];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -44,11 +53,15 @@ __global__ __launch_bounds__(256, 1) void gemm3_nt_skinny_kernel(const unsigned 
   const int64_t m0 = (int64_t)(blockIdx.x / tiles_n) * BM;
   const int64_t n0 = (int64_t)(blockIdx.x % tiles_n) * BN;
 
-  floatx16 acc;
+  floatx16 acc[WT][WT];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int t = 0; t < WT; ++t)
+#pragma unroll
+    for (int j = 0; j < WT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][j][e] = 0.f;
 
-  // LDS-DMA plan: row group g = w + 4 i of the stage: groups 0-7 are A rows 8 g .., 8-15 B rows 8 (g - 8) ..
+  // LDS-DMA plan: row group g = w + 4 i of the stage: the first BM / 8 groups are A rows 8 g .., the rest B rows
   uint32_t src[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
@@ -72,8 +85,9 @@ __global__ __launch_bounds__(256, 1) void gemm3_nt_skinny_kernel(const unsigned 
     }
   };
   // fragment addresses inside a stage slot (k-half 0, hi halves; k-half -> ^32, lo -> ^64)
-  const int a_addr = (wm * 32 + li) * 128 + ((lh ^ ((li >> 1) & 7)) << 4);
-  const int b_addr = A_BYTES + (wn * 32 + li) * 128 + ((lh ^ ((li >> 1) & 7)) << 4);
+  // (accumulator tile t / j of the wave: + 4096 t / + 4096 j — 32 lines; the swizzle repeats every 16 lines)
+  const int a_addr = (wm * 32 * WT + li) * 128 + ((lh ^ ((li >> 1) & 7)) << 4);
+  const int b_addr = A_BYTES + (wn * 32 * WT + li) * 128 + ((lh ^ ((li >> 1) & 7)) << 4);
 
   auto wait_landed = [&](int ahead) __attribute__((always_inline)) {  // at most `ahead` younger stages still in flight
     switch (ahead) {
@@ -88,23 +102,29 @@ __global__ __launch_bounds__(256, 1) void gemm3_nt_skinny_kernel(const unsigned 
     __builtin_amdgcn_s_barrier();  // stage s is visible to everyone; everyone is done with the slot of stage s - 1
     __builtin_amdgcn_sched_barrier(0);
     const unsigned char* buf = smem + (s & (NSLOT - 1)) * STAGE_BYTES;
-    u32x4 fa[2][2], fb[2][2];  // [k-half][hi, lo]
+    u32x4 fa[2][WT][2], fb[2][WT][2];  // [k-half][tile][hi, lo]
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-      for (int lo = 0; lo < 2; ++lo) {
-        fa[kh][lo] = *reinterpret_cast<const u32x4*>(buf + (a_addr ^ (kh * 32) ^ (lo * 64)));
-        fb[kh][lo] = *reinterpret_cast<const u32x4*>(buf + (b_addr ^ (kh * 32) ^ (lo * 64)));
-      }
+      for (int t = 0; t < WT; ++t)
+#pragma unroll
+        for (int lo = 0; lo < 2; ++lo) {
+          fa[kh][t][lo] = *reinterpret_cast<const u32x4*>(buf + ((a_addr ^ (kh * 32) ^ (lo * 64)) + t * 4096));
+          fb[kh][t][lo] = *reinterpret_cast<const u32x4*>(buf + ((b_addr ^ (kh * 32) ^ (lo * 64)) + t * 4096));
+        }
     __builtin_amdgcn_sched_barrier(0);
     if (fetch) issue(s + LEAD);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {  // per accumulator: lo*hi, hi*lo, hi*hi (small terms first), as in every other kernel
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[kh][1]), __builtin_bit_cast(bf16x8, fb[kh][0]), acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[kh][0]), __builtin_bit_cast(bf16x8, fb[kh][1]), acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[kh][0]), __builtin_bit_cast(bf16x8, fb[kh][0]), acc, 0, 0, 0);
-    }
+    for (int kh = 0; kh < 2; ++kh)  // per accumulator: lo*hi, hi*lo, hi*hi (small terms first), as in every other kernel
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int t = 0; t < WT; ++t)
+#pragma unroll
+          for (int j = 0; j < WT; ++j)
+            acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[kh][t][p == 0 ? 1 : 0]),
+                                                                __builtin_bit_cast(bf16x8, fb[kh][j][p == 1 ? 1 : 0]), acc[t][j], 0, 0, 0);
     // the reads of this slot have returned (the MFMAs consumed them) before this wave reaches the next barrier
   };
 
@@ -122,19 +142,26 @@ __global__ __launch_bounds__(256, 1) void gemm3_nt_skinny_kernel(const unsigned 
     }
   }
 
-  const int64_t row0 = m0 + wm * 32 + 4 * lh, col = n0 + wn * 32 + li;
-  if (m0 + BM <= M && n0 + BN <= N) store_mfma_tile<false>(epi, row0, col, acc, M, N);
-  else store_mfma_tile<true>(epi, row0, col, acc, M, N);
+  const bool inside = m0 + BM <= M && n0 + BN <= N;
+#pragma unroll
+  for (int t = 0; t < WT; ++t)
+#pragma unroll
+    for (int j = 0; j < WT; ++j) {
+      const int64_t row0 = m0 + (wm * WT + t) * 32 + 4 * lh, col = n0 + (wn * WT + j) * 32 + li;
+      if (inside) store_mfma_tile<false>(epi, row0, col, acc[t][j], M, N);
+      else store_mfma_tile<true>(epi, row0, col, acc[t][j], M, N);
+    }
 }
 
-template <class Epi>
+template <int WT, class Epi>
 int launch(ProfScope& prof, const void* A, int64_t M, const void* B, int64_t N, int64_t row_bytes, int64_t ns, const Epi& epi,
            hipStream_t st) {
+  constexpr int BM = Cfg<WT>::BM, BN = Cfg<WT>::BN;
   const int64_t tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
   SL_REQUIRE(tm * tn < (1ll << 31) && ns < (1ll << 29), "GEMM: too many tiles");
   SL_REQUIRE((M > N ? M : N) * row_bytes < (1ll << 32), "GEMM: operand larger than 4 GB (use another kernel)");
   if (tm * tn == 0) return 0;
-  SL_LAUNCH(prof, (gemm3_nt_skinny_kernel<Epi>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, (const unsigned char*)A,
+  SL_LAUNCH(prof, (gemm3_nt_skinny_kernel<WT, Epi>), dim3((unsigned)(tm * tn)), dim3(256), 0, st, (const unsigned char*)A,
             (const unsigned char*)B, M, N, row_bytes, (int)ns, (int)tn, epi);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
@@ -145,7 +172,7 @@ int launch(ProfScope& prof, const void* A, int64_t M, const void* B, int64_t N, 
 // fc1 9 / 35; M = 1600: 18 / 32, 49 / 90, 35 / 35, 45 / 54; M = 3200: 28 / 37, 73 / 94 (600 tiles) but qkv 67 / 52 and
 // fc1 89 / 74 (1 800 / 2 400 tiles).
 inline bool prefer(int64_t M, int64_t N, int64_t ns) {
-  const int64_t t64 = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  const int64_t t64 = ((M + 63) / 64) * ((N + 63) / 64);
   return t64 <= 5 * (int64_t)num_cus() && ns >= 8;
 }
 

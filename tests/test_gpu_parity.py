@@ -916,11 +916,11 @@ torch.save(outs, sys.argv[1])
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for tile in ("128", "256", "512", "8", "160", "64"):
+    for tile in ("128", "256", "512", "8", "160", "64", "1280"):
         out = tmp_path / f"g3_{tile}.pt"
         subprocess.run([sys.executable, "-c", code, str(out), root], check=True, env=dict(os.environ, SL_G3_TILE=tile))
         res[tile] = torch.load(out)
-    for other in ("256", "512", "8", "160", "64"):
+    for other in ("256", "512", "8", "160", "64", "1280"):
         for a, b in zip(res["128"], res[other]):
             assert torch.equal(a, b), (other, tuple(a.shape))
     # the fp32-MFMA mode has two tile variants too (128 x 128 register-staged, 256 x 256 8-phase): same bits
@@ -964,11 +964,11 @@ torch.save(outs, sys.argv[1])
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for tile in ("128", "256", "8", "160", "64"):
+    for tile in ("128", "256", "8", "160", "64", "1280"):
         out = tmp_path / f"lin_{tile}.pt"
         subprocess.run([sys.executable, "-c", code, str(out), root], check=True, env=dict(os.environ, SL_G3_TILE=tile))
         res[tile] = torch.load(out)
-    for other in ("256", "8", "160", "64"):
+    for other in ("256", "8", "160", "64", "1280"):
         for i, (a, b) in enumerate(zip(res["128"], res[other])):
             assert torch.equal(a, b), (other, i, tuple(a.shape))
     for i in range(0, len(res["128"]), 5):
