@@ -167,13 +167,15 @@ int launch(ProfScope& prof, const void* A, int64_t M, const void* B, int64_t N, 
   return 0;
 }
 
-// Up to five 64 x 64 tiles per CU, k loops long enough for the ring to matter.  Measured against the 128 x 128 kernel on the
-// ViT-B/32 block shapes (tools/enc_gemm_lab.py <M>, SL_G3_TILE = 64 / 128), us: M = 256: o-proj 8 / 30, fc2 22 / 90, qkv 9 / 30,
-// fc1 9 / 35; M = 1600: 18 / 32, 49 / 90, 35 / 35, 45 / 54; M = 3200: 28 / 37, 73 / 94 (600 tiles) but qkv 67 / 52 and
-// fc1 89 / 74 (1 800 / 2 400 tiles).
+// Up to two 64 x 64 tiles per CU, k loops long enough for the ring to matter; beyond that the 128 x 128 instance (the caller's
+// fallback for mid-size grids) is as fast or faster.  Measured on the ViT-B/32 block shapes (tools/enc_gemm_lab.py <M>,
+// SL_G3_TILE = 64 / 1280 / 128 = this kernel / its 128 x 128 instance / the register-staged 128 x 128 kernel), us:
+//   M =   256: o-proj  8 /  - / 30, fc2 22 /  - / 90, qkv  9 /  - / 30, fc1  9 /  - / 35
+//   M = 1 600: o-proj 19 / 29 / 32, fc2 48 / 68 / 89 (300 tiles); qkv 34 / 29 / 33 (900), fc1 47 / 50 / 53 (1 200)
+//   M = 3 200: o-proj 28 / 24 / 36, fc2 74 / 67 / 95 (600 tiles); qkv 67 / 45 / 50, fc1 88 / 69 / 73
 inline bool prefer(int64_t M, int64_t N, int64_t ns) {
   const int64_t t64 = ((M + 63) / 64) * ((N + 63) / 64);
-  return t64 <= 5 * (int64_t)num_cus() && ns >= 8;
+  return t64 <= 2 * (int64_t)num_cus() && ns >= 8;
 }
 
 }  // namespace gemmsk
