@@ -890,8 +890,9 @@ def test_fused_multi_layer_probe_equals_per_layer_similarity():
 
 
 def test_gemm_tile_variants_are_bit_identical(tmp_path):
-    """The 128x128 register-staged, the 256x128 LDS-DMA staged, the 256x256 ping-pong, the 256x256 8-phase and the 160x256
-    four-wave (round 3) split-bf16 kernels accumulate every output element in the same order: same bits (the variant is
+    """The 128x128 register-staged, the 256x128 LDS-DMA staged, the 256x256 ping-pong, the 256x256 8-phase, the 160x256
+    four-wave and the 64x64 / 128x128 ring (round 3: "160", "64", "1280") split-bf16 kernels accumulate every output element in
+    the same order: same bits (the variant is
     latched per process, hence subprocesses).  Forcing a variant sends EVERY shape through it, ragged and tiny ones included."""
     import os
     import subprocess
