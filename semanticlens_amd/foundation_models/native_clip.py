@@ -188,6 +188,17 @@ def _read_timm_block(blk: nn.Module, device) -> _BlockWeights:
     return w.scale_branches(_layer_scale(getattr(blk, "ls1", None), device), _layer_scale(getattr(blk, "ls2", None), device))
 
 
+def _project(pooled: torch.Tensor, w: torch.Tensor | None, b: torch.Tensor | None, s_w) -> torch.Tensor:
+    """The tower's output projection of the pooled rows.  With ``s_w`` (the weight as a split matrix: split mode) it runs in the
+    arithmetic of the blocks (``linear3``: a (B, W) x (D, W) product is a few tiles, which the small-grid kernel walks in
+    ~6 us; the fp32-MFMA kernel took 65)."""
+    if w is None:
+        return pooled
+    if s_w is None:
+        return N.linear(pooled, w, b)
+    return N.linear3(N.Split.of(pooled), s_w, b)
+
+
 class _Tower:
     """L residual blocks over a (B*T, W) fp32 token matrix (the residual stream stays fp32 in both modes)."""
 
@@ -312,6 +323,7 @@ class NativeVisionTower:
         if proj is None:
             proj = getattr(visual, "proj_v", None)
         self.w_proj = _f32(proj.t(), device) if proj is not None else None  # features = x @ proj -> Linear weight (D, W)
+        self.s_proj = N.Split.of(self.w_proj) if split and self.w_proj is not None else None
         self.split = split
         if split:
             self.s_patch = N.Split.of(self.w_patch)
@@ -361,7 +373,7 @@ class NativeVisionTower:
             N.reduce_tokens(h.view(B, T, W)[:, 1:], N.SL_TOK_MEAN, 0, None, pooled)
             if self.ln_after_pool:
                 pooled = N.layernorm(pooled, *self.ln_post)
-        return N.linear(pooled, self.w_proj) if self.w_proj is not None else pooled
+        return _project(pooled, self.w_proj, None, self.s_proj)
 
 
 class NativeTextTower:
@@ -386,6 +398,7 @@ class NativeTextTower:
             self.w_proj, self.b_proj = _f32(proj.weight, device), (_f32(proj.bias, device) if proj.bias is not None else None)
         else:
             self.w_proj = _f32(proj.t(), device) if proj is not None else None
+        self.s_proj = N.Split.of(self.w_proj) if split and self.w_proj is not None else None
         self.tower = _Tower([_read_mha_block(b, device) for b in blocks], split)
         self.pool, self.causal = pool, bool(causal)
         self.truncate = True  # skip the positions after the batch's last end-of-text token (see __call__)
@@ -417,7 +430,7 @@ class NativeTextTower:
         else:
             picked = N.gather_rows(self.tower.forward(x, B, T, causal=self.causal), rows, check=False)
         pooled = N.layernorm(picked, *self.ln_final)
-        return N.linear(pooled, self.w_proj, self.b_proj) if self.w_proj is not None else pooled
+        return _project(pooled, self.w_proj, self.b_proj, self.s_proj)
 
 
 def _require_clip_layout(model):
@@ -574,10 +587,12 @@ class NativeSigLipVision:
         self.tower = _Tower(blocks, split)
         self.ln_post = ln_post
         self.head = head
-        if split:
-            self.s_kv = N.Split.of(head.w_kv)
         self.w_final = _f32(final_proj.weight, device) if final_proj is not None else None
         self.b_final = _f32(final_proj.bias, device) if final_proj is not None and final_proj.bias is not None else None
+        if split:  # the head's GEMMs in the arithmetic of the blocks: its (B, W) products are small grids (gemm_skinny.hpp)
+            self.s_kv = N.Split.of(head.w_kv)
+            self.s_o, self.s_1, self.s_2 = N.Split.of(head.w_o), N.Split.of(head.w1), N.Split.of(head.w2)
+            self.s_final = N.Split.of(self.w_final) if self.w_final is not None else None
 
     @classmethod
     def from_transformers(cls, vm: nn.Module, cfg, device, split: bool):
@@ -642,6 +657,13 @@ class NativeSigLipVision:
         else:
             kv = N.linear(N.layernorm(x, *self.ln_post), hd.w_kv, hd.b_kv)
         pooled = N.attention_pool(hd.q_probe, kv, B, T, hd.heads, hd.head_dim)  # (B, W)
+        if self.split:
+            dev = img.device
+            res = N.linear3(N.Split.of(pooled), self.s_o, hd.b_o)
+            hid = N.linear3(N.layernorm(res, *hd.ln, out_split=N.Split(B, W, dev)), self.s_1, hd.b1, act=hd.act,
+                            out_split=N.Split(B, hd.w1.shape[0], dev))
+            out = N.linear3(hid, self.s_2, hd.b2, residual=res, out=res)
+            return N.linear3(N.Split.of(out), self.s_final, self.b_final) if self.w_final is not None else out
         res = N.linear(pooled, hd.w_o, hd.b_o)
         hid = N.linear(N.layernorm(res, *hd.ln), hd.w1, hd.b1, act=hd.act)
         out = N.linear(hid, hd.w2, hd.b2, residual=res, out=res)
@@ -659,6 +681,7 @@ class NativeSigLipText:
         self.tower = _Tower([_read_hf_siglip_block(b, cfg.num_attention_heads, act, device) for b in tm.encoder.layers], split)
         self.ln_final = _ln(tm.final_layer_norm, device)
         self.w_head, self.b_head = _f32(tm.head.weight, device), _f32(tm.head.bias, device)
+        self.s_head = N.Split.of(self.w_head) if split else None
 
     @torch.no_grad()
     def __call__(self, tokens: torch.Tensor) -> torch.Tensor:
@@ -669,7 +692,7 @@ class NativeSigLipText:
         x = N.embed_tokens(self.table, tokens, self.pos[:T].contiguous())
         rows = torch.arange(B, device=tokens.device, dtype=torch.int64) * T + (T - 1)
         picked = self.tower.forward(x, B, T, causal=False, pool_rows=rows)
-        return N.linear(N.layernorm(picked, *self.ln_final), self.w_head, self.b_head)
+        return _project(N.layernorm(picked, *self.ln_final), self.w_head, self.b_head, self.s_head)
 
 
 class NativeSigLip(AbstractVLM):
