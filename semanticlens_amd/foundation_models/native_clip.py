@@ -451,6 +451,10 @@ def _require_clip_layout(model):
 class NativeClip(AbstractVLM):
     """``AbstractVLM`` running ``base``'s CLIP towers on HIP kernels; ``base`` keeps tokenizer + preprocessing."""
 
+    # The embed stage of the concept-DB build may hold preprocessed batches back until this many images are there: the
+    # towers' GEMMs reach their rate from a few thousand rows, and an embedding does not depend on its batch (bit for bit).
+    embed_accumulate = 256
+
     def __init__(self, base, device=None, gemm: str = "bf16x3", preprocess=None):
         """``preprocess``: ``None`` keeps ``base.preprocess`` (host transform, as upstream); a
         ``DevicePreprocess`` (or ``"device"`` to derive one from ``base.preprocessor``) runs resize / crop /
@@ -703,6 +707,8 @@ class NativeSigLip(AbstractVLM):
     ``TextTransformer``, non-causal, pooled at the last position, projection with bias) or transformers' ``SiglipModel``
     (``vision_model`` / ``text_model``; the geometry of SigLIP-so400m — width 1152, head_dim 72 — is what BASELINE
     configs[3] names).  Tokenizer and host preprocessing stay ``base``'s; ``preprocess`` as for :class:`NativeClip`."""
+
+    embed_accumulate = 64  # see NativeClip; 64 images of a so400m-sized tower are 46 656 token rows already
 
     def __init__(self, base, device=None, gemm: str = "bf16x3", preprocess=None):
         if gemm not in ("bf16x3", "f32"):

@@ -100,3 +100,45 @@ def test_configs1_native_embeddings_within_tolerance_of_the_torch_module(world):
     for gemm in ("bf16x3", "f32"):
         got = NativeClip(base, gemm=gemm).encode_image(x)
         assert (got - want).abs().max().item() < 1e-4 * scale, gemm
+
+
+def test_small_loader_batches_are_embedded_in_large_ones_with_the_same_bits(world):
+    """With a native foundation model the embed stage holds preprocessed loader batches back until ``fm.embed_accumulate``
+    (256) images are there — the reference's default ``batch_size=32`` would otherwise run the encoder at an eighth of its
+    batch.  An embedding does not depend on the batch it is computed in, so the table is bit-identical to the walk that
+    encodes batch by batch (accumulation off) and to the 256-image walk; loader batches of 40 divide neither 256 nor the
+    768 images (the last encoder call is a partial one).  The single-pass build gathers from that same table.  (The
+    probed model's activations are PyTorch's and DO depend on the batch size — MIOpen picks its algorithms per shape —,
+    so the comparison is on the embed stage, not on the top-k of two batch sizes.)"""
+    model, base, DS = world
+    fm = NativeClip(base)
+    cv = ActivationComponentVisualizer(model, DS("model"), DS("fm"), LAYERS, num_samples=K, aggregate_fn=aggregators.aggregate_conv_max,
+                                       tie_mode="total")
+    calls = []
+    orig = fm.encode_image
+    fm.encode_image = lambda x: (calls.append(int(x.shape[0])), orig(x))[1]
+    try:
+        fm.embed_accumulate = 0
+        ref = cv._embed_vision_dataset(fm, 256)
+        assert calls == [256, 256, 256]
+        calls.clear()
+        one = cv._embed_vision_dataset(fm, 40)
+        assert calls == [40] * (N_IMAGES // 40) + [N_IMAGES % 40]
+        calls.clear()
+        fm.embed_accumulate = 256
+        acc = cv._embed_vision_dataset(fm, 40)
+        assert calls == [280, 280, 208]  # seven loader batches of 40 reach 256
+        subset = list(range(5, 700, 3))
+        calls.clear()
+        sub = cv._embed_vision_dataset(fm, 40, subset=subset)
+        assert calls == [len(subset)]  # 232 images: below the threshold, one call at the end
+        assert torch.equal(ref, one) and torch.equal(ref, acc) and torch.equal(ref[subset], sub)
+        calls.clear()
+        db = Lens(fm, device=DEV).compute_concept_db(cv, batch_size=40, single_pass=True)
+        assert calls == [280, 280, 208]
+        for name in LAYERS:
+            ids = cv.get_max_reference(name)
+            assert torch.equal(db[name], ref.cpu()[ids]), name
+    finally:
+        del fm.encode_image
+        fm.embed_accumulate = type(fm).embed_accumulate
