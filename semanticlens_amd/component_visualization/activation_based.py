@@ -62,6 +62,7 @@ class _EmbedStage:
     def add(self, items, preprocessed=None):
         pre = self.fm.preprocess(items) if preprocessed is None else preprocessed
         if not self.target or not torch.is_tensor(pre):
+            self.flush()  # held tensor batches come first: rows are written in dataset order
             return self._encode(pre)
         self._held.append(N.to_device(pre))
         self._held_n += pre.shape[0]

@@ -18,8 +18,8 @@ only gradient x activation:
   rule       modified passes                                                 used for
   =========  ==============================================================  ==================================
   epsilon    ``(a, w, b)``; ``stabilise(z) = z + eps * sign(z)``, eps 1e-6   ``nn.Linear``
-  z+         ``(a+, w+)`` and ``(a-, w-)``, no bias                          ``nn.Conv*``
-  flat       ``(1, 1)``: ``R_out`` spread evenly over the receptive field    the first linear module
+  z+         ``(a+, w+, b+)`` and ``(a-, w-, 0)``                            ``nn.Conv*``
+  flat       ``(1, 1)``: ``R_out`` spread evenly over the receptive field    the first linear module (module order)
   norm       ``(a,)`` through the module itself                              average pooling
   pass       ``R_in = R_out``                                                activations, batch norm, dropout
   =========  ==============================================================  ==================================
@@ -52,6 +52,14 @@ def _stabilise(z: torch.Tensor, eps: float) -> torch.Tensor:
     return z + eps * torch.where(z >= 0, torch.ones_like(z), -torch.ones_like(z))
 
 
+def _alias(out: torch.Tensor) -> torch.Tensor:
+    """What a rule's forward returns: the module's own output, as a NON-view alias.  ``out.view_as(out)`` made inside a custom
+    Function is a view autograd refuses to see modified in place, and torchvision-style residual blocks do exactly that
+    (``out = bn2(conv2(x)); out += identity``, functional in-place ReLUs).  ``detach()`` shares storage and version counter
+    with ``out`` — so an in-place edit of a tensor another node saved is still caught — without being a view."""
+    return out.detach()
+
+
 def _functional(module: nn.Module):
     """``f(a, w, b)`` computing the module's linear map with other weights."""
     if isinstance(module, nn.Linear):
@@ -69,7 +77,7 @@ class _LinearRule(torch.autograd.Function):
     def forward(ctx, a, out, module, rule, eps):
         ctx.module, ctx.rule, ctx.eps = module, rule, eps
         ctx.save_for_backward(a)
-        return out.view_as(out)
+        return _alias(out)
 
     @staticmethod
     def backward(ctx, r_out):
@@ -81,7 +89,9 @@ class _LinearRule(torch.autograd.Function):
         if rule == "epsilon":
             passes = [(a.detach(), w, b)]
         elif rule == "zplus":
-            passes = [(a.detach().clamp(min=0), w.clamp(min=0), None), (a.detach().clamp(max=0), w.clamp(max=0), None)]
+            # zennit's ZPlus: ClampMod(min=0) on weight AND bias in the (a+, w+) pass, the bias zeroed in the (a-, w-) pass
+            bp = b.clamp(min=0) if b is not None else None
+            passes = [(a.detach().clamp(min=0), w.clamp(min=0), bp), (a.detach().clamp(max=0), w.clamp(max=0), None)]
         elif rule == "flat":
             passes = [(torch.ones_like(a), torch.ones_like(w), None)]
         else:
@@ -102,7 +112,7 @@ class _NormRule(torch.autograd.Function):
     def forward(ctx, a, out, module, eps):
         ctx.module, ctx.eps = module, eps
         ctx.save_for_backward(a)
-        return out.view_as(out)
+        return _alias(out)
 
     @staticmethod
     def backward(ctx, r_out):
@@ -124,7 +134,7 @@ class _PassRule(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, out):
-        return out.view_as(out)
+        return _alias(out)
 
     @staticmethod
     def backward(ctx, r_out):
@@ -138,7 +148,9 @@ def epsilon_plus_flat(model: nn.Module, epsilon: float = 1e-6, first_layer_flat:
     Rules attach to leaf modules by type (table in the module docstring).  In-place activations are switched to
     out-of-place for the duration (their input is needed by the rule of the module in front of them)."""
     handles, restored = [], []
-    first = [True]
+    # zennit's SpecialFirstLayerMapComposite picks the first linear module in MODULE order (registration order of
+    # `model.modules()`), not the first one the forward pass happens to call
+    first_linear = next((m for m in model.modules() if not len(list(m.children())) and isinstance(m, (nn.Linear,) + _CONVS)), None)
 
     def hook_for(kind):
         def hook(module, inputs, output):
@@ -150,9 +162,8 @@ def epsilon_plus_flat(model: nn.Module, epsilon: float = 1e-6, first_layer_flat:
                 if not a.requires_grad:  # the model's input: keep the graph connected so that the flat rule can run
                     a = a.detach().requires_grad_(True)
                 rule = "epsilon" if isinstance(module, nn.Linear) else "zplus"
-                if first[0] and first_layer_flat:
+                if module is first_linear and first_layer_flat:
                     rule = "flat"
-                first[0] = False
                 return _LinearRule.apply(a, output, module, rule, epsilon)
             if not a.requires_grad:
                 return None

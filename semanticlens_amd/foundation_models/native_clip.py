@@ -62,7 +62,7 @@ def _first(obj, *names):
     raise AttributeError(f"none of {names} found on {type(obj).__name__}")
 
 
-_HEAD_DIMS = tuple(range(32, 129, 8))  # what csrc/encoder.hip instantiates sl_attention for
+_HEAD_DIMS = (32, 64, 72, 80, 88, 96, 104, 128)  # exactly what csrc/encoder.hip instantiates sl_attention / sl_attention_bf16x3 for
 
 
 def _ln(mod: nn.Module, device):
@@ -112,7 +112,7 @@ class _BlockWeights:
         self.width, self.heads, self.act = int(width), int(heads), act
         self.head_dim = self.width // self.heads
         if self.head_dim not in _HEAD_DIMS or self.head_dim * self.heads != self.width:
-            raise ValueError(f"head_dim {self.head_dim} is not supported (32 to 128 in steps of 8)")
+            raise ValueError(f"head_dim {self.head_dim} is not supported (built: {_HEAD_DIMS})")
 
     def scale_branches(self, g_attn, g_mlp):
         """Fold LayerScale into the projection it follows: gamma * (W x + b) = (gamma W) x + gamma b."""
@@ -477,6 +477,11 @@ class NativeClip(AbstractVLM):
             self.vision = NativeVisionTower(visual, visual.transformer.resblocks, dev, split, pool=getattr(visual, "pool_type", "tok"),
                                             ln_after_pool=getattr(visual, "final_ln_after_pool", False))
             text = model.text if hasattr(model, "text") and hasattr(model.text, "transformer") else model
+            if not hasattr(getattr(text, "transformer", None), "resblocks"):
+                # e.g. open_clip's CustomTextCLIP around a Hugging Face text encoder: `.text.transformer` is an HF model
+                raise TypeError(f"NativeClip reads open_clip's TextTransformer layout (`transformer.resblocks`); the text tower is "
+                                f"{type(text).__name__} around {type(getattr(text, 'transformer', None)).__name__} — run this model "
+                                "through its own torch modules (OpenClip without .native())")
             pool = getattr(text, "pool_type", None) or getattr(model, "text_pool_type", "argmax")
             self.text = NativeTextTower(text, text.transformer.resblocks, dev, split, pool=pool,
                                         causal=getattr(text, "attn_mask", None) is not None)
@@ -540,7 +545,7 @@ class _MapHead:
         W = probe.numel()
         self.heads, self.head_dim, self.act = int(heads), W // int(heads), act
         if self.head_dim not in _HEAD_DIMS or self.head_dim * self.heads != W:
-            raise ValueError(f"MAP head: head_dim {self.head_dim} is not supported (32 to 128 in steps of 8)")
+            raise ValueError(f"MAP head: head_dim {self.head_dim} is not supported (built: {_HEAD_DIMS})")
         # the probe is the same for every image: its query projection is a constant of the model
         self.q_probe = N.linear(probe.reshape(1, W).contiguous(), wq, bq).reshape(W).contiguous()
         self.w_kv, self.b_kv = wkv, bkv  # (2W, W): rows [k | v]

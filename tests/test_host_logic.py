@@ -647,3 +647,46 @@ def test_pinned_stack_falls_back_to_default_collate_without_a_device():
     ragged = [(torch.zeros(2), 0), (torch.zeros(3), 1)]
     with pytest.raises(RuntimeError):
         stack(ragged)  # default_collate's own error, as in the reference
+
+
+def test_native_block_refuses_head_dims_the_attention_kernels_are_not_built_for():
+    """`_HEAD_DIMS` listed every multiple of 8 while encoder.hip instantiates eight of them; a head_dim-48 model
+    constructed, split all its weights and died on the first encode.  Now refused at construction."""
+    import re
+
+    from semanticlens_amd.foundation_models import native_clip as nc
+
+    src = (ROOT / "semanticlens_amd" / "csrc" / "encoder.hip").read_text()
+    for fn in ("launch_attention_mfma", "launch_attention_bf16x3"):
+        built = sorted({int(m) for m in re.findall(r"case (\d+): return %s<\1>" % fn, src)})
+        assert tuple(built) == nc._HEAD_DIMS, (fn, built)
+    for width, heads in ((192, 4), (320, 8), (448, 8), (896, 8), (960, 8)):  # head_dim 48, 40, 56, 112, 120
+        with pytest.raises(ValueError, match="head_dim"):
+            nc._BlockWeights(width, heads, 0)
+    assert nc._BlockWeights(1152, 16, 0).head_dim == 72
+
+
+def test_embed_stage_writes_rows_in_dataset_order_when_preprocess_output_types_mix(monkeypatch):
+    """a non-tensor `preprocess` result was encoded at once while earlier tensor batches were still held back,
+    so its rows landed in front of theirs."""
+    from semanticlens_amd.component_visualization import activation_based as ab
+
+    monkeypatch.setattr(ab.N, "to_device", lambda t, device=None: t)
+
+    class FM:
+        embed_accumulate = 8
+
+        def preprocess(self, items):
+            return items
+
+        def encode_image(self, pre):
+            x = pre if torch.is_tensor(pre) else torch.stack(list(pre))
+            return x.reshape(x.shape[0], -1)[:, :1].float() * torch.ones(1, 3)
+
+    stage = ab._EmbedStage(FM(), 7, batch_hint=2)
+    stage.add(None, torch.tensor([[0.0], [1.0]]))
+    stage.add(None, torch.tensor([[2.0], [3.0]]))
+    stage.add(None, [torch.tensor([4.0]), torch.tensor([5.0])])  # a list: cannot be held back
+    stage.add(None, torch.tensor([[6.0]]))
+    out = stage.finish()
+    assert out[:, 0].tolist() == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0]

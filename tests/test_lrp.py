@@ -134,3 +134,82 @@ def test_unsupported_padding_mode_is_reported():
     m = nn.Sequential(nn.Conv2d(3, 2, 3, padding=1, padding_mode="reflect"), nn.ReLU(), nn.Flatten(), nn.Linear(2 * 16, 2)).eval()
     with pytest.raises(NotImplementedError, match="padding_mode"):
         lrp_epsilon_plus_flat(m, {"1": m[1]}, torch.rand(1, 3, 4, 4), None)
+
+
+class _BasicBlock(nn.Module):
+    """torchvision's BasicBlock pattern: in-place ReLU modules and an in-place residual add on a hooked leaf's output."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.conv1 = nn.Conv2d(c, c, 3, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(c)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(c, c, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(c)
+
+    def forward(self, x):
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        out += identity  # in-place on the output of a rule's autograd node
+        return nn.functional.relu(out, inplace=True)  # functional in-place activation: not a module, no rule
+
+
+def test_residual_block_with_in_place_add_and_in_place_relu():
+    """rule outputs were views made inside a custom Function; `out += identity` raised
+    'Output 0 of _PassRuleBackward is a view and is being modified inplace' on every ResNet-family model."""
+    torch.manual_seed(0)
+    m = nn.Sequential(nn.Conv2d(3, 6, 3, padding=1, bias=False), nn.ReLU(inplace=True), _BasicBlock(6), _BasicBlock(6),
+                      nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(6, 4, bias=False)).eval()
+    x = torch.rand(2, 3, 8, 8)
+    layers = {"2": m[2], "3": m[3], "6": m[6]}
+    out = lrp_epsilon_plus_flat(m, layers, x, None)
+    with torch.no_grad():
+        y = m(x)
+    t = y.argmax(1)
+    assert torch.allclose(out["6"][1].sum(1), y[torch.arange(2), t])
+    for name in ("2", "3"):
+        act, rel = out[name]
+        assert act.shape == rel.shape == (2, 6, 8, 8) and torch.isfinite(rel).all() and rel.abs().sum() > 0
+    assert torch.allclose(out["3"][0], m[:4](x))  # the hooked activations are the model's own
+    assert m[1].inplace and m[2].relu.inplace  # and the in-place flags are back
+
+
+def test_zplus_keeps_the_positive_part_of_the_bias_in_its_first_pass():
+    """zennit's ZPlus clamps weight AND bias at zero from below in the (a+, w+) pass and zeroes the bias in the (a-, w-)
+    pass: z = conv(a+, w+) + b+ + conv(a-, w-)."""
+    torch.manual_seed(2)
+    m = nn.Sequential(nn.Conv2d(2, 3, 3, bias=True), nn.ReLU(), nn.Conv2d(3, 4, 3, bias=True), nn.ReLU(), nn.AdaptiveAvgPool2d(1),
+                      nn.Flatten(), nn.Linear(4, 2, bias=False)).eval()
+    with torch.no_grad():
+        m[2].bias.copy_(torch.tensor([0.5, -0.7, 0.25, -0.1]))
+    x = torch.rand(2, 2, 7, 7)
+    out = lrp_epsilon_plus_flat(m, {"1": m[1], "3": m[3]}, x, None)
+    a1, r_a2 = out["1"][0], out["3"][1]
+    wp, bp = m[2].weight.detach().clamp(min=0), m[2].bias.detach().clamp(min=0)
+    z = nn.functional.conv2d(a1, wp, bp)  # a1 >= 0 after the ReLU: the (a-, w-) pass is zero
+    want = a1 * nn.functional.conv_transpose2d(r_a2 / (z + 1e-6 * torch.where(z >= 0, 1.0, -1.0)), wp)
+    assert torch.allclose(out["1"][1], want, rtol=1e-5, atol=1e-8)
+
+
+def test_first_layer_is_the_first_linear_module_in_module_order():
+    """zennit's SpecialFirstLayerMapComposite: module order, not call order."""
+
+    class Swapped(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.late = nn.Linear(5, 3, bias=False)  # registered first, called second
+            self.early = nn.Linear(4, 5, bias=False)
+
+        def forward(self, x):
+            return self.late(torch.relu(self.early(x)))
+
+    torch.manual_seed(3)
+    m = Swapped().eval()
+    x = torch.rand(2, 4) + 0.1
+    with epsilon_plus_flat(m):
+        xx = x.clone().requires_grad_(True)
+        y = m(xx)
+        (r_x,) = torch.autograd.grad(y, xx, grad_outputs=y.detach())
+    # `early` runs the epsilon rule (relevance depends on x), it is not the flat one
+    assert not torch.allclose(r_x[:, 0], r_x[:, 1])
