@@ -1,6 +1,7 @@
 """bench.py — concept-DB build throughput (BASELINE.json configs[1]) + text_probing, on N MI355X.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8 --steps 20 --warmup 3        # launches its own 8 ranks (one per GPU, RCCL), prints ONE line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -49,7 +50,13 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--k", type=int, default=20)  # num_samples; the reference tutorial's value
-    ap.add_argument("--tie-mode", default="total", choices=["total", "aten"])
+    ap.add_argument("--tie-mode", default=None, choices=["total", "aten"],
+                    help="default: 'aten' on one GPU (top-k ids in torch.topk's CPU tie order = bit-identical to the reference, "
+                         "activation_caching.py:133-141), 'total' on several (value desc, id asc: shard- and batch-invariant)")
+    ap.add_argument("--strong-images", type=int, default=1281167,
+                    help="after the weak-scaling job, build the concept DB of this many images in TOTAL, sharded over the ranks "
+                         "(north_star: 1.28 M-image set, >= 6x from 1 to 8 GPUs) and report it as `strong_scaling`; 0 = skip")
+    ap.add_argument("--strong-pool-batches", type=int, default=200, help="distinct resident batches the strong-scaling job cycles through")
     ap.add_argument("--cpu-images", type=int, default=192, help="bounded sample for the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probing", action="store_true")
@@ -509,8 +516,35 @@ def _collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, 
     return out
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves — one process per GPU, backend
+    nccl (= RCCL) — by re-executing this file under torch.distributed.run on a free local port.  Rank 0 prints the ONE JSON
+    line.  A box with fewer than N GPUs is refused loudly (SL_BENCH_SHARE_GPU=1: N ranks on GPU 0 over gloo — a debugging /
+    test aid for the N > 1 code path, never a measurement)."""
+    import socket
+
+    have = torch.cuda.device_count()
+    env = dict(os.environ)
+    if have < args.gpus:
+        if env.get("SL_BENCH_SHARE_GPU") != "1":
+            raise SystemExit(f"bench.py --gpus {args.gpus}: this box has {have} HIP device(s) (one rank per GPU; "
+                             "SL_BENCH_SHARE_GPU=1 runs the ranks on GPU 0 over gloo for testing)")
+        env.setdefault("SL_BENCH_BACKEND", "gloo")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execvpe(sys.executable, cmd, env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)  # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -531,6 +565,25 @@ def main():
         else:
             dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.tie_mode is None:
+        # one GPU: the reference's own tie order, so that "top-k indices bit-exact vs the reference" and the throughput figure
+        # describe the same run; several GPUs: the total order (shard-invariant; the reference's order depends on batch AND shard cuts)
+        args.tie_mode = "total" if (world > 1 or sharded) else "aten"
+    if sharded and args.tie_mode != "total":
+        raise SystemExit("a sharded build needs --tie-mode total (distributed.run_sharded)")
+    comm = sld.native_comm(None, dev) if sharded else None  # the library's own RCCL communicator (None under gloo / SL_COLLECTIVES=torch)
+
+    def all_max(x: float) -> float:
+        """max over ranks of one host double (timing, warm-up decision)"""
+        if not sharded:
+            return x
+        if comm is not None:
+            t = torch.tensor([x], dtype=torch.float64, device=dev)
+            comm.allreduce(t, "max")
+            return float(t.item())
+        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
     global OVERLAP
     OVERLAP = bool(args.overlap)
@@ -586,10 +639,7 @@ def main():
             # first ten seconds of a process 10 % slow: 5 250 vs 5 850 images/s); give up waiting after ten times --min-warmup-seconds (15 s)
             settled = len(job_times) >= 3 and max(job_times[-2:]) <= 1.03 * min(job_times[1:])
             more = 1.0 if spent < args.min_warmup_seconds or (not settled and spent < 10.0 * args.min_warmup_seconds) else 0.0
-            if sharded:
-                t = torch.tensor([more], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                more = float(t.item())
+            more = all_max(more)
             if not more:
                 break
         del warm, emb_w, warm_cv
@@ -607,16 +657,18 @@ def main():
 
     assert n_local > 0, "every rank needs at least one sample (--images >= --gpus)"
 
-    def timed_job(fm_used, batches, n_total, n_local, model_=None):
-        cv_ = make_cv(model_ or model, n_total, args.k, args.tie_mode)
-        N.prof_enable(True)
+    def timed_job(fm_used, batches, n_total, n_local, model_=None, id_start_=None, tie_mode=None, prof=True):
+        """One complete job between barriers: collect + embed over `batches`, flush / cross-rank merge, concept_db gather."""
+        cv_ = make_cv(model_ or model, n_total, args.k, tie_mode or args.tie_mode)
+        ids0 = id_start if id_start_ is None else id_start_
+        N.prof_enable(prof)
         N.prof_reset()
         torch.cuda.synchronize()
         if sharded:
             dist.barrier()
         t0_ = time.perf_counter()
-        embeds_ = run_steps(cv_, fm_used, batches, id_start, n_local)
-        db_ = finish_job(cv_, embeds_, id_start, n_total, sharded)
+        embeds_ = run_steps(cv_, fm_used, batches, ids0, n_local)
+        db_ = finish_job(cv_, embeds_, ids0, n_total, sharded)
         torch.cuda.synchronize()
         if sharded:
             dist.barrier()
@@ -627,15 +679,33 @@ def main():
     mrg_ms, mrg_n, _ = N.prof_read(N.SL_PROF_MERGE)
     gat_ms, gat_n, _ = N.prof_read(N.SL_PROF_GATHER)
     N.prof_enable(False)
-    if sharded:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = all_max(elapsed)
     assert all(v.shape == (c, args.k, 512) for v, c in zip(concept_db.values(), (512, 1024, 2048)))
     del concept_db
 
+    # ---- strong scaling: the north star's 1.28 M-image set in TOTAL, sharded over the ranks (every rank takes part) ----
+    strong = None
+    if args.strong_images > 0 and args.scaling == "weak" and not args.quick:
+        s_total = args.strong_images
+        s_start, s_stop = sld.shard_range(s_total, rank, world)
+        s_local = s_stop - s_start
+        assert s_local > 0, "--strong-images must be at least --gpus"
+        s_nb = -(-s_local // B)
+        s_pool = max(1, min(args.strong_pool_batches, s_nb, len(distinct)))
+        # the resident pool is cycled (1.28 M images are 193 GB of uint8 pixels); ids stay unique and global
+        s_batches = [distinct[i % s_pool][: min(B, s_local - i * B)] for i in range(s_nb)]
+        s_elapsed, s_db = timed_job(fm, s_batches, s_total, s_local, id_start_=s_start, prof=False)
+        s_elapsed = all_max(s_elapsed)
+        assert all(v.shape == (c, args.k, 512) for v, c in zip(s_db.values(), (512, 1024, 2048)))
+        del s_db, s_batches
+        strong = {"images": s_total, "n_gpus": world, "seconds": s_elapsed, "images_per_s": s_total / s_elapsed,
+                  "images_per_gpu": -(-s_total // world), "distinct_resident_batches": s_pool, "tie_mode": args.tie_mode,
+                  "workload": "the same job (collect + embed + merge + concept_db gather) over --strong-images samples in total, "
+                              "contiguous shards of ceil(N / ranks) samples (distributed.shard_range), global sample ids"}
+
     if rank != 0:
         if sharded:
+            sld.destroy_native_comms()
             dist.destroy_process_group()
         return
 
@@ -676,8 +746,13 @@ def main():
             "distinct_resident_batches": pool,
             "tie_mode": args.tie_mode,
             "streams": 2 if args.overlap else 1, "layers": LAYERS, "parallelism": f"shard{world}" if world > 1 else "single",
-            "collectives": "torch.distributed (RCCL): one all_gather_into_tensor of the packed top-k states + one "
-                           "all_reduce per layer of the sharded gather" if sharded else "none",
+            "collectives": ("none" if not sharded else
+                            "libsemanticlens_hip.so (RCCL behind the C ABI): sl_actmax_allgather_merge = pack + ONE ncclAllGather of all "
+                            "layers' top-k states + K4, and one sl_comm_allreduce per layer of the sharded gather" if comm is not None else
+                            f"torch.distributed ({backend}): one all_gather_into_tensor of the packed top-k states + one all_reduce per "
+                            "layer of the sharded gather"),
+            "rccl_world_size": (comm.info()[0] if comm is not None else (dist.get_world_size() if sharded and backend == "nccl" else None)),
+            "process_group": {"backend": backend, "world_size": dist.get_world_size()} if sharded else None,
             "clip_encoder": {"native": "NativeClip (HIP kernels, split-bf16 x3 GEMMs, fp32-class accuracy)",
                              "native-f32": "NativeClip (HIP kernels, fp32-input MFMA GEMMs)",
                              "torch": "torch module (hipBLASLt fp32)"}[args.fm],
@@ -702,8 +777,43 @@ def main():
         },
     }
     single = world == 1
+    if strong is not None:
+        # the N = 1 figure the speed-up is taken against: measured by THIS command at --gpus 1 (its own `strong_scaling`
+        # object; committed copy of the round's run: profiles/strong_scaling_n1.json)
+        ref_path = ROOT / "profiles" / "strong_scaling_n1.json"
+        ref = None
+        if ref_path.exists():
+            try:
+                ref = json.loads(ref_path.read_text())
+            except Exception:
+                ref = None
+        if world == 1 and not sharded:
+            strong["speedup_vs_n1"] = 1.0
+            strong["n1_reference"] = "this run"
+        elif ref and ref.get("images_per_s"):
+            strong["n1_reference"] = {"images_per_s": ref["images_per_s"], "images": ref.get("images"), "tie_mode": ref.get("tie_mode"),
+                                      "source": "profiles/strong_scaling_n1.json (`strong_scaling` of `python bench.py --gpus 1` on one MI355X)"}
+            strong["speedup_vs_n1"] = strong["images_per_s"] / ref["images_per_s"]
+        else:
+            strong["n1_reference"] = None
+            strong["speedup_vs_n1"] = None
+        strong["weak_scaling_images_per_s_same_run"] = n_total / elapsed
+        line["strong_scaling"] = strong
     if single and not args.no_self_check:
         line["self_check"] = self_check(dev, model, fm, args)
+    if single and not args.quick and not sharded:
+        # both tie orders on the same 24 batches: 'aten' = torch.topk's CPU order on cat([state, batch]) per batch (one K3 launch per
+        # layer and batch, ids bit-identical to the reference); 'total' = value desc / id asc, merged every 8 batches (the sharded mode)
+        few = batches[: min(n_batches, 24)]
+        n_few = sum(b.shape[0] for b in few)
+        rates = {}
+        for mode in ("total", "aten"):
+            timed_job(fm, few[:2], 2 * B, 2 * B, tie_mode=mode, prof=False)
+            dt_m, _ = timed_job(fm, few, n_few, n_few, tie_mode=mode, prof=False)
+            rates[mode] = n_few / dt_m
+        line["tie_modes"] = {"headline": args.tie_mode, "images_per_s": rates, "batches": len(few),
+                             "note": "aten: top-k ids bit-identical to the reference CPU path (activation_caching.py:133-141) at the "
+                                     "same batch size; total: batch- and shard-invariant order used for N > 1"}
     if single and not args.quick:
         line["roofline"]["cold_inputs"] = reduce_cold_leg(dev, B)
     if single and args.fm == "native" and not args.quick:
@@ -769,6 +879,7 @@ def main():
         line["cpu_baseline"] = cpu_baseline(args, synth.resnet50(), synth.SyntheticClip(device="cpu"))
     print(json.dumps(line), flush=True)
     if sharded:
+        sld.destroy_native_comms()
         dist.destroy_process_group()
 
 

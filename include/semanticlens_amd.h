@@ -17,7 +17,8 @@
  *    sl_prof_read().
  *  - Return value: 0 (or a non-negative code where documented) on success,
  *    negative SL_E_* on failure; sl_last_error() returns a thread-local message.
- *  - No entry point allocates device memory; scratch is passed in by the caller.
+ *  - No entry point allocates device memory; scratch is passed in by the caller.  The only object that
+ *    outlives a call is the RCCL communicator of sl_comm_init_from_unique_id / sl_comm_destroy.
  *  - Strides are in ELEMENTS.
  */
 #ifndef SEMANTICLENS_AMD_H
@@ -124,6 +125,46 @@ size_t sl_actmax_aten_ws_bytes(int64_t C, int64_t k, int64_t B);
  * top-k of the union.  d_other_vals/ids are (R,C,k). */
 int sl_actmax_merge_states(uint16_t* d_vals, int64_t* d_ids, int64_t C, int64_t k, const uint16_t* d_other_vals,
                            const int64_t* d_other_ids, int64_t R, void* stream);
+
+/* ---- K4 with its exchange step: RCCL behind this ABI --------------
+ * No reference counterpart: the reference is single-process (no torch.distributed / NCCL call anywhere).  One
+ * process per GPU; rank r collects the sample range [r*ceil(N/R), ...) with global ids into its own (C,k) states.
+ * The communicator is the ONE object of this library that outlives a call: rank 0 obtains an id
+ * (sl_comm_unique_id, 128 bytes, host), hands it to the other processes by any means (the Python host uses the
+ * torch.distributed store it was launched with), and every rank calls sl_comm_init_from_unique_id on its current HIP
+ * device (ncclCommInitRank: collective).  The library links librccl. */
+#define SL_COMM_ID_BYTES 128
+int sl_comm_unique_id(uint8_t* h_id);
+int sl_comm_init_from_unique_id(const uint8_t* h_id, int world, int rank, void** comm);
+int sl_comm_destroy(void* comm);
+int sl_comm_info(void* comm, int* world, int* rank, int* device);
+/* ncclAllGather of nbytes per rank: d_recv (world * nbytes) receives rank r's block at r * nbytes. */
+int sl_comm_allgather(void* comm, const void* d_send, void* d_recv, int64_t nbytes, void* stream);
+/* in-place ncclAllReduce of n elements (the sharded K5 gather is assembled by a SUM of zero-filled blocks; the
+ * bench's max-over-ranks time is a MAX of one double). */
+#define SL_COMM_F32 0
+#define SL_COMM_F64 1
+#define SL_COMM_I64 2
+#define SL_COMM_SUM 0
+#define SL_COMM_MAX 1
+#define SL_COMM_MIN 2
+int sl_comm_allreduce(void* comm, void* d_buf, int64_t n, int dtype, int op, void* stream);
+/* The cross-rank merge in one call: pack the (C_l,k) states of n_layers layers (h_vals[l] bf16 bits, h_ids[l] int64:
+ * host arrays of DEVICE pointers) into d_ws -> ONE ncclAllGather over xGMI -> K4 (SL_TIES_TOTAL top-k of the union) of
+ * every layer against the other ranks' blocks, read in place from the gathered buffer.  Afterwards every rank holds the
+ * same global states.  d_ws: sl_actmax_allgather_merge_ws_bytes(...) bytes, 16-byte aligned, owned by the caller. */
+/* The two local halves on their own (what a caller that brings its own transport uses; the gloo test path does):
+ * sl_actmax_pack writes one rank's block — [ids of layer 0..L-1 | values of layer 0..L-1 | zero pad to 16 bytes],
+ * sl_actmax_packed_bytes(...) bytes — and sl_actmax_merge_packed folds R such blocks (d_gathered, block r at
+ * r * packed_bytes, 8-byte aligned) into the states, leaving block skip_rank (-1: none) out. */
+size_t sl_actmax_packed_bytes(int n_layers, const int64_t* h_C, int64_t k);
+int sl_actmax_pack(int n_layers, uint16_t* const* h_vals, int64_t* const* h_ids, const int64_t* h_C, int64_t k, void* d_out,
+                   void* stream);
+int sl_actmax_merge_packed(int n_layers, uint16_t* const* h_vals, int64_t* const* h_ids, const int64_t* h_C, int64_t k,
+                           const void* d_gathered, int64_t R, int64_t skip_rank, void* stream);
+size_t sl_actmax_allgather_merge_ws_bytes(int n_layers, const int64_t* h_C, int64_t k, int world);
+int sl_actmax_allgather_merge(void* comm, int n_layers, uint16_t* const* h_vals, int64_t* const* h_ids, const int64_t* h_C,
+                              int64_t k, void* d_ws, size_t ws_bytes, void* stream);
 
 /* ---- K5: concept_db[layer] = embeds[sample_ids] (activation_based.py:387-390) ------------
  * d_emb (N,D) f32, d_ids (n_ids) int64; negative ids wrap (id -1 -> row N-1).  An id

@@ -48,6 +48,17 @@ SIGNATURES = {
     "sl_actmax_update": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _int, _vp, _sz, _vp]),
     "sl_actmax_aten_ws_bytes": (_sz, [_i64, _i64, _i64]),
     "sl_actmax_merge_states": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),
+    "sl_comm_unique_id": (_int, [_vp]),
+    "sl_comm_init_from_unique_id": (_int, [_vp, _int, _int, ctypes.POINTER(_vp)]),
+    "sl_comm_destroy": (_int, [_vp]),
+    "sl_comm_info": (_int, [_vp, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)]),
+    "sl_comm_allgather": (_int, [_vp, _vp, _vp, _i64, _vp]),
+    "sl_comm_allreduce": (_int, [_vp, _vp, _i64, _int, _int, _vp]),
+    "sl_actmax_packed_bytes": (_sz, [_int, _vp, _i64]),
+    "sl_actmax_pack": (_int, [_int, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "sl_actmax_merge_packed": (_int, [_int, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp]),
+    "sl_actmax_allgather_merge_ws_bytes": (_sz, [_int, _vp, _i64, _int]),
+    "sl_actmax_allgather_merge": (_int, [_vp, _int, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "sl_gather_rows": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp]),
     "sl_gather_rows_shard": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "sl_similarity": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
@@ -271,6 +282,125 @@ def actmax_merge_states(vals, ids, other_vals: torch.Tensor, other_ids: torch.Te
     with _on(vals.device):
         rc = lib().sl_actmax_merge_states(_ptr(vals), _ptr(ids), C, k, _ptr(other_vals), _ptr(other_ids), R, _stream(vals))
     _check(rc, "sl_actmax_merge_states")
+
+
+# ------------------------------------------------------------------------------------------------
+# K4 with its exchange step: RCCL behind the C ABI (csrc/comm.hip)
+# ------------------------------------------------------------------------------------------------
+SL_COMM_ID_BYTES = 128
+_COMM_DTYPES = {torch.float32: 0, torch.float64: 1, torch.int64: 2}
+_COMM_OPS = {"sum": 0, "max": 1, "min": 2}
+
+
+def _state_tables(states):
+    """ctypes tables (C[], vals*[], ids*[]) + k of live device states [(vals (C,k) bf16, ids (C,k) int64)]."""
+    k = int(states[0][0].shape[1])
+    dev = states[0][0].device
+    for vals, ids in states:
+        if not (vals.is_cuda and ids.is_cuda and vals.device == dev and ids.device == dev and vals.is_contiguous() and ids.is_contiguous()):
+            raise ValueError("states are contiguous tensors on one HIP device")
+        if vals.dtype != torch.bfloat16 or ids.dtype != torch.int64 or vals.shape != ids.shape or vals.ndim != 2 or vals.shape[1] != k:
+            raise ValueError("states are (C, k) bf16 values + (C, k) int64 ids with one k")
+    n = len(states)
+    C = (_i64 * n)(*[int(v.shape[0]) for v, _ in states])
+    pv = (_vp * n)(*[v.data_ptr() for v, _ in states])
+    pi = (_vp * n)(*[i.data_ptr() for _, i in states])
+    return n, C, pv, pi, k
+
+
+def actmax_pack(states) -> torch.Tensor:
+    """One rank's packed block of all layers' states (uint8, ``sl_actmax_packed_bytes`` long; layout of ``sl_actmax_pack``)."""
+    n, C, pv, pi, k = _state_tables(states)
+    dev = states[0][0].device
+    out = torch.empty(int(lib().sl_actmax_packed_bytes(n, C, k)), dtype=torch.uint8, device=dev)
+    with _on(dev):
+        rc = lib().sl_actmax_pack(n, pv, pi, C, k, _ptr(out), _stream(out))
+    _check(rc, "sl_actmax_pack")
+    return out
+
+
+def actmax_merge_packed(states, gathered: torch.Tensor, skip_rank: int = -1):
+    """K4 of every layer against ``gathered`` = ``(R, packed_bytes)`` uint8 blocks (e.g. all-gathered), in place."""
+    n, C, pv, pi, k = _state_tables(states)
+    dev = states[0][0].device
+    P = int(lib().sl_actmax_packed_bytes(n, C, k))
+    if not (gathered.is_cuda and gathered.device == dev and gathered.dtype == torch.uint8 and gathered.is_contiguous()
+            and gathered.ndim == 2 and gathered.shape[1] == P):
+        raise ValueError(f"gathered states are a contiguous (R, {P}) uint8 tensor on {dev}")
+    with _on(dev):
+        rc = lib().sl_actmax_merge_packed(n, pv, pi, C, k, _ptr(gathered), gathered.shape[0], int(skip_rank), _stream(gathered))
+    _check(rc, "sl_actmax_merge_packed")
+
+
+class Comm:
+    """One RCCL communicator of the native library (``sl_comm_*``): one process per GPU, created collectively.
+
+    ``Comm.unique_id()`` on rank 0 -> hand the 128 bytes to every process -> ``Comm(id, world, rank, device)`` on all of
+    them.  Collectives are enqueued on torch's current stream of ``device``."""
+
+    def __init__(self, unique_id: bytes, world: int, rank: int, device=None):
+        if len(unique_id) != SL_COMM_ID_BYTES:
+            raise ValueError(f"an RCCL unique id is {SL_COMM_ID_BYTES} bytes, got {len(unique_id)}")
+        self.device = torch.device(device) if device is not None else default_device()
+        self.world, self.rank = int(world), int(rank)
+        handle = _vp()
+        buf = ctypes.create_string_buffer(bytes(unique_id), SL_COMM_ID_BYTES)
+        with _on(self.device):
+            rc = lib().sl_comm_init_from_unique_id(ctypes.cast(buf, _vp), self.world, self.rank, ctypes.byref(handle))
+        _check(rc, "sl_comm_init_from_unique_id")
+        self._h = handle
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(SL_COMM_ID_BYTES)
+        _check(lib().sl_comm_unique_id(ctypes.cast(buf, _vp)), "sl_comm_unique_id")
+        return buf.raw
+
+    def info(self):
+        w, r, d = _int(), _int(), _int()
+        _check(lib().sl_comm_info(self._h, ctypes.byref(w), ctypes.byref(r), ctypes.byref(d)), "sl_comm_info")
+        return w.value, r.value, d.value
+
+    def destroy(self):
+        if self._h is not None:
+            h, self._h = self._h, None
+            _check(lib().sl_comm_destroy(h), "sl_comm_destroy")
+
+    def _dev(self, t: torch.Tensor):
+        if not (t.is_cuda and t.device == self.device and t.is_contiguous()):
+            raise ValueError(f"collectives take contiguous tensors on {self.device}")
+        return t
+
+    def allgather(self, send: torch.Tensor) -> torch.Tensor:
+        """``(world,) + send.shape``: block r is rank r's ``send`` (equal sizes on every rank)."""
+        send = self._dev(send)
+        recv = torch.empty((self.world,) + tuple(send.shape), dtype=send.dtype, device=self.device)
+        with _on(self.device):
+            rc = lib().sl_comm_allgather(self._h, _ptr(send), _ptr(recv), send.numel() * send.element_size(), _stream(send))
+        _check(rc, "sl_comm_allgather")
+        return recv
+
+    def allreduce(self, t: torch.Tensor, op: str = "sum") -> torch.Tensor:
+        """In place; fp32 / fp64 / int64, ``op`` "sum", "max" or "min"."""
+        t = self._dev(t)
+        with _on(self.device):
+            rc = lib().sl_comm_allreduce(self._h, _ptr(t), t.numel(), _COMM_DTYPES[t.dtype], _COMM_OPS[op], _stream(t))
+        _check(rc, "sl_comm_allreduce")
+        return t
+
+    def actmax_allgather_merge(self, states):
+        """``states``: [(vals (C_l,k) bf16, ids (C_l,k) int64)] live device tensors, updated in place to the global top-k:
+        pack -> ONE all-gather -> K4 per layer against the other ranks' blocks (``sl_actmax_allgather_merge``)."""
+        if not states:
+            return
+        n, C, pv, pi, k = _state_tables(states)
+        self._dev(states[0][0])
+        need = lib().sl_actmax_allgather_merge_ws_bytes(n, C, k, self.world)
+        ws = torch.empty(max(int(need), 16), dtype=torch.uint8, device=self.device)
+        with _on(self.device):
+            rc = lib().sl_actmax_allgather_merge(self._h, n, pv, pi, C, k, _ptr(ws), ws.numel(), _stream(ws))
+        _check(rc, "sl_actmax_allgather_merge")
+        ws.record_stream(torch.cuda.current_stream(self.device))
 
 
 # ------------------------------------------------------------------------------------------------

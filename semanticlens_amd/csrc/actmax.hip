@@ -159,11 +159,14 @@ __global__ __launch_bounds__(256) void actmax_merge_kernel(uint16_t* __restrict_
   row.store(vals, ids, c, lane);
 }
 
-// candidates: R other states (R,C,k) with explicit ids
+// candidates: R other states with explicit ids; state r's row c starts at ovals + r * stride_v + c * k (ids likewise with
+// stride_i) — (R,C,k) tensors have stride C*k, the all-gathered packed buffer of sl_actmax_allgather_merge one rank's block.
+// State `skip` (this rank's own block in an all-gathered buffer; -1: none) is not read.
 __global__ __launch_bounds__(256) void actmax_merge_states_kernel(uint16_t* __restrict__ vals,
                                                                    int64_t* __restrict__ ids, int64_t C, int k,
                                                                    const uint16_t* __restrict__ ovals,
-                                                                   const int64_t* __restrict__ oids, int64_t R) {
+                                                                   const int64_t* __restrict__ oids, int64_t R,
+                                                                   int64_t stride_v, int64_t stride_i, int64_t skip) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;
@@ -172,12 +175,14 @@ __global__ __launch_bounds__(256) void actmax_merge_states_kernel(uint16_t* __re
   Row row = make_row(smem, k, w);
   row.load(vals, ids, c, lane);
   for (int64_t r = 0; r < R; ++r) {
-    const int64_t off = (r * C + c) * k;
+    if (r == skip) continue;
+    const uint16_t* ov = ovals + r * stride_v + c * k;
+    const int64_t* oi = oids + r * stride_i + c * k;
     for (int j0 = 0; j0 < k; j0 += kWave) {
       const int j = j0 + lane;
       const bool valid = j < k;
-      const uint32_t bits = valid ? ovals[off + j] : 0u;
-      const int64_t cid = valid ? oids[off + j] : 0;
+      const uint32_t bits = valid ? ov[j] : 0u;
+      const int64_t cid = valid ? oi[j] : 0;
       row.offer(bf16_order_key((uint16_t)bits), bits, cid, valid, lane);
     }
   }
@@ -274,18 +279,27 @@ SL_API int sl_actmax_update(uint16_t* d_vals, int64_t* d_ids, int64_t C, int64_t
   return 0;
 }
 
-SL_API int sl_actmax_merge_states(uint16_t* d_vals, int64_t* d_ids, int64_t C, int64_t k,
-                                  const uint16_t* d_other_vals, const int64_t* d_other_ids, int64_t R, void* stream) {
-  if (int rc = check_state("sl_actmax_merge_states", d_vals, d_ids, C, k)) return rc;
-  SL_REQUIRE(R >= 0, "sl_actmax_merge_states: negative R");
-  if (C * k == 0 || R == 0) return 0;
-  SL_REQUIRE(d_other_vals && d_other_ids, "sl_actmax_merge_states: null inputs");
-  hipStream_t st = (hipStream_t)stream;
-  ProfScope prof(SL_PROF_MERGE, st, (double)(R + 1) * C * k * 10);
+namespace sl {
+// shared with comm.hip (sl_actmax_allgather_merge): strides in ELEMENTS of the respective array
+int merge_states_strided(const char* fn, uint16_t* d_vals, int64_t* d_ids, int64_t C, int64_t k, const uint16_t* d_other_vals,
+                         const int64_t* d_other_ids, int64_t R, int64_t stride_v, int64_t stride_i, int64_t skip,
+                         hipStream_t st) {
+  if (int rc = check_state(fn, d_vals, d_ids, C, k)) return rc;
+  SL_REQUIRE(R >= 0, "%s: negative R", fn);
+  if (C * k == 0 || R == 0 || (R == 1 && skip == 0)) return 0;
+  SL_REQUIRE(d_other_vals && d_other_ids, "%s: null inputs", fn);
+  ProfScope prof(SL_PROF_MERGE, st, (double)(R + 1 - (skip >= 0 && skip < R ? 1 : 0)) * C * k * 10);
   const unsigned blocks = (unsigned)((C + kWavesPerBlock - 1) / kWavesPerBlock);
   if (int rc = allow_smem(actmax_merge_states_kernel, row_smem_bytes(k))) return rc;
   SL_LAUNCH(prof, actmax_merge_states_kernel, dim3(blocks), dim3(256), row_smem_bytes(k), st, d_vals, d_ids, C, (int)k,
-            d_other_vals, d_other_ids, R);
+            d_other_vals, d_other_ids, R, stride_v, stride_i, skip);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
+}
+}  // namespace sl
+
+SL_API int sl_actmax_merge_states(uint16_t* d_vals, int64_t* d_ids, int64_t C, int64_t k,
+                                  const uint16_t* d_other_vals, const int64_t* d_other_ids, int64_t R, void* stream) {
+  return merge_states_strided("sl_actmax_merge_states", d_vals, d_ids, C, k, d_other_vals, d_other_ids, R, C * k, C * k, -1,
+                              (hipStream_t)stream);
 }

@@ -6,8 +6,17 @@ sample range ``shard_range(N, r, R)`` with *global* sample ids, so every rank en
 ``(C, k)`` state per layer over its shard.  Top-k under the total order (value desc, id asc) is
 associative and commutative, so the global state is the merge of the per-rank states:
 
-    pack all layers' (values, ids) -> ONE ``all_gather_into_tensor`` (RCCL over xGMI, a few MB
-    at most, latency-bound) -> K4 merge kernel on every rank -> identical state everywhere.
+    pack all layers' (values, ids) -> ONE all-gather (RCCL over xGMI, a few MB at most,
+    latency-bound) -> K4 merge kernel on every rank -> identical state everywhere.
+
+Who issues the collective (``COLLECTIVES`` / environment ``SL_COLLECTIVES``):
+
+* ``"native"`` (default) — the C-ABI library itself: ``sl_actmax_allgather_merge`` (pack + ``ncclAllGather`` + K4 in one
+  call) and ``sl_comm_allreduce`` on a communicator the library owns (``csrc/comm.hip``, linked against librccl).  Used
+  whenever the process group's backend is ``nccl``; ``torch.distributed`` then only launches the processes and carries
+  the 128-byte RCCL id from rank 0 to the others.
+* ``"torch"`` — ``torch.distributed`` collectives (``all_gather_into_tensor`` / ``all_reduce``) + ``sl_actmax_merge_states``.
+  The only choice under ``gloo`` (CPU tests, several ranks sharing one GPU).
 
 No other collective is on the data path.  With ``tie_mode="total"`` the 1/2/4/8-GPU results are
 bit-identical to each other.
@@ -21,7 +30,35 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
+import os
+
 from semanticlens_amd import _native as N
+
+COLLECTIVES = os.environ.get("SL_COLLECTIVES", "native")  # "native": RCCL through the C ABI; "torch": torch.distributed
+_COMMS: dict = {}
+
+
+def native_comm(group=None, device=None):
+    """The library's own RCCL communicator for ``group`` (created collectively on first use, then cached), or None when
+    the collectives go through torch.distributed (``COLLECTIVES == "torch"``, or a backend other than nccl)."""
+    if COLLECTIVES != "native" or dist.get_backend(group) != "nccl":
+        return None
+    key = id(group) if group is not None else None
+    comm = _COMMS.get(key)
+    if comm is None:
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        box = [N.Comm.unique_id() if rank == 0 else None]
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast_object_list(box, src=src, group=group, device=dev)
+        comm = _COMMS[key] = N.Comm(box[0], world, rank, dev)
+    return comm
+
+
+def destroy_native_comms():
+    """Tear down the cached communicators (before ``dist.destroy_process_group``)."""
+    while _COMMS:
+        _COMMS.popitem()[1].destroy()
 
 
 def shard_range(n_samples: int, rank: int, world_size: int) -> tuple[int, int]:
@@ -88,6 +125,11 @@ def all_gather_states(states, group=None):
 
 def _all_reduce_host_ints(values: list[int], op, group, device) -> list[int]:
     """All-reduce a few Python ints (layer widths, cache-hit flags); device tensor under RCCL, host tensor under gloo."""
+    comm = native_comm(group, device)
+    if comm is not None:
+        t = torch.tensor(values, dtype=torch.int64).to(comm.device)
+        comm.allreduce(t, {dist.ReduceOp.MAX: "max", dist.ReduceOp.MIN: "min", dist.ReduceOp.SUM: "sum"}[op])
+        return [int(v) for v in t.cpu().tolist()]
     t = torch.tensor(values, dtype=torch.int64)
     if not _host_staged(group):
         t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
@@ -118,12 +160,33 @@ def merge_actmax_cache(actmax_cache, group=None, device=None):
             raise RuntimeError(f"layer {name!r}: this rank has {am.n_latents} components, another rank {width}")
         layers.append(name)
     states = [actmax_cache.cache[name].device_state(device) for name in layers]
-    gathered = all_gather_states(states, group)
+    comm = native_comm(group, device)
+    if comm is not None:  # pack + ncclAllGather + K4 inside the library, states updated in place
+        comm.actmax_allgather_merge(states)
+        for name in layers:
+            actmax_cache.cache[name]._dev_newer = True
+        return
     world = dist.get_world_size(group)
-    others = [r for r in range(world) if r != rank]
-    for name, (vals, ids) in zip(layers, gathered):
-        if others:
-            actmax_cache.cache[name].merge_states(vals[others], ids[others])
+    if states and not states[0][0].is_cuda:
+        # host tensors never come out of ActMax.device_state: this branch serves tests/test_distributed_gloo.py, which
+        # replaces ActMax's two device touch-points by oracle stand-ins to exercise the plumbing around them on the CPU
+        gathered = all_gather_states(states, group)
+        others = [r for r in range(world) if r != rank]
+        for name, (vals, ids) in zip(layers, gathered):
+            if others:
+                actmax_cache.cache[name].merge_states(vals[others], ids[others])
+        return
+    mine = N.actmax_pack(states)  # the layout of pack_states; K4 reads the gathered blocks in place
+    if _host_staged(group):
+        host = torch.empty((world, mine.numel()), dtype=torch.uint8)
+        dist.all_gather_into_tensor(host.reshape(-1), mine.cpu(), group=group)
+        gathered = host.to(mine.device)
+    else:
+        gathered = torch.empty((world, mine.numel()), dtype=torch.uint8, device=mine.device)
+        dist.all_gather_into_tensor(gathered.reshape(-1), mine, group=group)
+    N.actmax_merge_packed(states, gathered, skip_rank=rank)
+    for name in layers:
+        actmax_cache.cache[name]._dev_newer = True
 
 
 def run_sharded(cv, batch_size: int = 64, num_workers: int = 0, group=None):
@@ -163,6 +226,9 @@ def gather_concept_db_sharded(embeds_local: torch.Tensor, shard_start: int, n_to
     owns (zeros elsewhere, K5 sharded form) and one all-reduce sums the disjoint pieces.  Exchanges
     ``C*k*D*4`` bytes per layer instead of the whole ``(N, D)`` table."""
     part = N.gather_rows_shard(embeds_local, ids, shard_start, n_total)
+    comm = native_comm(group, part.device)
+    if comm is not None:
+        return comm.allreduce(part, "sum")
     if _host_staged(group) and part.is_cuda:
         host = part.cpu()
         dist.all_reduce(host, group=group)
@@ -204,7 +270,10 @@ def compute_concept_db_sharded(cv, fm, batch_size: int = 64, num_workers: int = 
         dim = torch.zeros(1, dtype=torch.int64, device=cv.device)
     else:
         dim = torch.tensor([embeds.shape[1]], dtype=torch.int64, device=embeds.device)
-    if _host_staged(group) and dim.is_cuda:
+    comm = native_comm(group, cv.device)
+    if comm is not None:
+        comm.allreduce(dim, "max")
+    elif _host_staged(group) and dim.is_cuda:
         host = dim.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
         dim = host
@@ -233,6 +302,9 @@ def all_gather_rows(part: torch.Tensor, n_total: int, group=None) -> torch.Tenso
         block = part.new_zeros((per,) + tail)
         block[: part.shape[0]] = part
     block = block.contiguous()
+    comm = native_comm(group, block.device) if block.is_cuda else None
+    if comm is not None:
+        return comm.allgather(block).reshape((world * per,) + tail)[:n_total]
     if _host_staged(group) and block.is_cuda:
         host = torch.empty((world * per,) + tail, dtype=block.dtype)
         dist.all_gather_into_tensor(host, block.cpu(), group=group)

@@ -309,5 +309,174 @@ def test_bench_distributed_path_over_rccl_on_one_gpu():
     K4 merge, sharded K5 + all-reduce, max-over-ranks timing) runs over RCCL on the 1-GPU box."""
     line = _bench_line({"SL_BENCH_FORCE_DIST": "1"}, ["--steps", "2", "--batches-per-step", "2", "--warmup", "1", "--batch", "64",
                                                         "--min-warmup-seconds", "0.3", "--quick"], 1)
-    assert line["n_gpus"] == 1 and line["config"]["collectives"].startswith("torch.distributed (RCCL)")
+    assert line["n_gpus"] == 1 and line["config"]["collectives"].startswith("libsemanticlens_hip.so (RCCL behind the C ABI)")
+    assert line["config"]["rccl_world_size"] == 1 and line["config"]["tie_mode"] == "total"
     assert line["config"]["images_total"] == 2 * 2 * 64 and line["value"] > 0 and line["self_check"] == "ok"
+    line = _bench_line({"SL_BENCH_FORCE_DIST": "1", "SL_COLLECTIVES": "torch"}, ["--steps", "1", "--batches-per-step", "2", "--warmup", "1",
+                                                                                 "--batch", "64", "--min-warmup-seconds", "0", "--quick"], 1)
+    assert line["config"]["collectives"].startswith("torch.distributed (nccl)") and line["config"]["rccl_world_size"] == 1
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment starts N ranks itself (torch.distributed.run
+    on a free local port) and prints ONE line — here two ranks on the one GPU of the box (SL_BENCH_SHARE_GPU=1 -> gloo), with the
+    strong-scaling job behind the weak-scaling one."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SL_BENCH_SHARE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--batches-per-step", "2", "--warmup", "1",
+           "--batch", "64", "--min-warmup-seconds", "0.2", "--strong-images", "333", "--strong-pool-batches", "2"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["images_total"] == 2 * 2 * 2 * 64
+    assert line["config"]["tie_mode"] == "total" and line["config"]["process_group"] == {"backend": "gloo", "world_size": 2}
+    st = line["strong_scaling"]
+    assert st["images"] == 333 and st["n_gpus"] == 2 and st["images_per_gpu"] == 167 and st["seconds"] > 0
+    # without the test switch a box with fewer GPUs than ranks is refused, loudly
+    env.pop("SL_BENCH_SHARE_GPU")
+    if torch.cuda.device_count() < 2:
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=root)
+        assert res.returncode != 0 and "one rank per GPU" in (res.stderr + res.stdout)
+
+
+# ---- RCCL behind the C ABI (csrc/comm.hip): sl_comm_*, sl_actmax_pack / _merge_packed / _allgather_merge -----------------
+def _random_states(R, shapes, k, seed):
+    """Per-rank total-order states of `shapes` layers over disjoint id ranges (oracle-built), tie-heavy values."""
+    import oracle
+
+    rng = np.random.RandomState(seed)
+    per_rank, n = [], 70
+    acts = [(rng.randint(-4, 40, size=(R * n, C)) / 8.0).astype(np.float32) for C in shapes]
+    for r in range(R):
+        states = []
+        for a in acts:
+            o = oracle.ActMaxOracle(k, a.shape[1], oracle.MODE_TOTAL)
+            if r != 1:  # rank 1 of every test saw nothing: it contributes the initial state
+                o.update(a[r * n:(r + 1) * n], np.arange(r * n, (r + 1) * n))
+            states.append((o.vals.copy(), o.ids.copy()))
+        per_rank.append(states)
+    want = []
+    for a in acts:
+        o = oracle.ActMaxOracle(k, a.shape[1], oracle.MODE_TOTAL)
+        keep = np.concatenate([np.arange(r * n, (r + 1) * n) for r in range(R) if r != 1])
+        o.update(a[keep], keep)
+        want.append((o.vals, o.ids))
+    return per_rank, want
+
+
+def _to_dev(states):
+    return [(torch.from_numpy(v.view(np.int16)).view(torch.bfloat16).cuda(), torch.from_numpy(i).cuda()) for v, i in states]
+
+
+@pytest.mark.parametrize("R,k", [(2, 6), (4, 20), (8, 100), (3, 1)])
+def test_packed_merge_of_gathered_states_equals_the_oracle(R, k):
+    """`sl_actmax_pack` + `sl_actmax_merge_packed` — the two local halves of `sl_actmax_allgather_merge` — on a gathered buffer
+    assembled by hand: every rank ends with the oracle's global top-k, whichever block it leaves out as its own."""
+    from semanticlens_amd import _native as N
+    from semanticlens_amd import distributed as sld
+
+    shapes = (37, 5, 130)  # odd sizes: the blocks' value sections are only 2-byte aligned
+    per_rank, want = _random_states(R, shapes, k, seed=R * 100 + k)
+    blocks = [N.actmax_pack(_to_dev(s)) for s in per_rank]
+    for r in range(R):  # the packed layout is distributed.pack_states' (what the torch transport has always sent)
+        ref = sld.pack_states([(torch.from_numpy(v.view(np.int16)).view(torch.bfloat16), torch.from_numpy(i)) for v, i in per_rank[r]])
+        assert torch.equal(blocks[r].cpu(), ref), r
+    gathered = torch.stack(blocks)
+    for r in range(R):
+        mine = _to_dev(per_rank[r])
+        N.actmax_merge_packed(mine, gathered, skip_rank=r)
+        for (v, i), (wv, wi) in zip(mine, want):
+            assert np.array_equal(v.view(torch.int16).cpu().numpy().view(np.uint16), wv), (R, k, r)
+            assert np.array_equal(i.cpu().numpy(), wi), (R, k, r)
+    # skip_rank = -1: every block is foreign (a fresh state takes all of them)
+    fresh = _to_dev([(np.full_like(v, 0x8000), np.full_like(i, -1)) for v, i in per_rank[0]])
+    N.actmax_merge_packed(fresh, gathered, skip_rank=-1)
+    for (v, i), (wv, wi) in zip(fresh, want):
+        assert np.array_equal(i.cpu().numpy(), wi) and np.array_equal(v.view(torch.int16).cpu().numpy().view(np.uint16), wv)
+
+
+def _native_comm_worker(rank, world, port, out_dir):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(__file__))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(__file__)))
+    from semanticlens_amd import _native as N
+    from semanticlens_amd import distributed as sld
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        assert sld.COLLECTIVES == "native"
+        comm = sld.native_comm()
+        assert isinstance(comm, N.Comm) and comm.info() == (world, rank, rank) and sld.native_comm() is comm
+        # raw collectives
+        x = torch.arange(6, dtype=torch.float32, device=dev) + 10 * rank
+        got = comm.allgather(x)
+        assert got.shape == (world, 6) and all(torch.equal(got[r], torch.arange(6, dtype=torch.float32, device=dev) + 10 * r) for r in range(world))
+        for dt in (torch.float32, torch.float64, torch.int64):
+            t = torch.full((5,), rank + 1, dtype=dt, device=dev)
+            assert comm.allreduce(t.clone(), "sum").tolist() == [world * (world + 1) // 2] * 5
+            assert comm.allreduce(t.clone(), "max").tolist() == [world] * 5 and comm.allreduce(t.clone(), "min").tolist() == [1] * 5
+        # the fused cross-rank merge
+        per_rank, want = _random_states(world, (37, 5, 130), 20, seed=7)
+        mine = [(v.to(dev), i.to(dev)) for v, i in _to_dev(per_rank[rank])]
+        comm.actmax_allgather_merge(mine)
+        ref = want if world > 1 else per_rank[0]  # one rank: nothing to merge, the state keeps its bits
+        for (v, i), (wv, wi) in zip(mine, ref):
+                assert np.array_equal(v.view(torch.int16).cpu().numpy().view(np.uint16), wv), rank
+                assert np.array_equal(i.cpu().numpy(), wi), rank
+        # the whole sharded build and the analysis stage through the library's communicator
+        cv, fm = _build(device=dev)
+        db = sld.compute_concept_db_sharded(cv, fm, batch_size=8)
+        rows = torch.arange(35, dtype=torch.float32, device=dev).reshape(7, 5)
+        s, e = sld.shard_range(7, rank, world)
+        assert torch.equal(sld.all_gather_rows(rows[s:e].contiguous(), 7), rows)
+        np.savez(os.path.join(out_dir, f"nc_w{world}_r{rank}.npz"), **{f"db_{k}": v.cpu().numpy() for k, v in db.items()},
+                 **{f"ids_{k}": cv.get_max_reference(k).numpy() for k in db})
+        sld.destroy_native_comms()
+        assert not sld._COMMS
+    finally:
+        dist.destroy_process_group()
+
+
+def _check_native_comm_run(world, tmp_path):
+    cv, fm = _build()
+    want = cv._compute_concept_db(fm, batch_size=8)
+    mp.spawn(_native_comm_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        got = np.load(tmp_path / f"nc_w{world}_r{r}.npz")
+        for k in ("0", "2"):
+            assert np.array_equal(got[f"ids_{k}"], cv.get_max_reference(k).numpy()), (r, k)
+            assert np.array_equal(got[f"db_{k}"], want[k].numpy()), (r, k)
+
+
+def test_library_owned_rccl_communicator_with_one_rank(tmp_path):
+    """RCCL inside the C-ABI library.  A one-rank communicator created from a unique id through ctypes runs
+    ncclAllGather / ncclAllReduce and `sl_actmax_allgather_merge` on the 1-GPU box; `distributed.py` picks it up for every
+    collective of the sharded build when the process group's backend is nccl."""
+    _check_native_comm_run(1, tmp_path)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: data movement between GPUs through the library's communicator")
+def test_library_owned_rccl_communicator_across_gpus(tmp_path):
+    _check_native_comm_run(min(torch.cuda.device_count(), 8), tmp_path)
+
+
+def test_torch_collectives_remain_selectable(tmp_path, monkeypatch):
+    """`SL_COLLECTIVES=torch`: the same build over torch.distributed's all_gather_into_tensor / all_reduce (one-rank nccl group)."""
+    monkeypatch.setenv("SL_COLLECTIVES", "torch")
+    cv, fm = _build()
+    want = cv._compute_concept_db(fm, batch_size=8)
+    mp.spawn(_nccl_single_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    got = np.load(tmp_path / "nccl1.npz")
+    for k in ("0", "2"):
+        assert np.array_equal(got[f"db_{k}"], want[k].numpy()), k
