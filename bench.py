@@ -75,7 +75,8 @@ def parse():
                          "batch distinct.  For dataset sizes whose uint8 pixels exceed HBM (1.28 M images = 193 GB)")
     ap.add_argument("--no-self-check", action="store_true")
     ap.add_argument("--quick", action="store_true", help="headline + self-check only: none of the extra legs (tests)")
-    ap.add_argument("--no-tokens-leg", action="store_true")
+    ap.add_argument("--no-tokens-leg", action="store_true", help="skip the configs[3] leg (ViT-B/16 collect + so400m embed + 10k-prompt probing)")
+    ap.add_argument("--no-config4-leg", action="store_true", help="skip the configs[4] leg (ConvNeXt-L collect + relevance visualizer + scores)")
     ap.add_argument("--no-half-leg", action="store_true")
     ap.add_argument("--no-api-leg", action="store_true")
     ap.add_argument("--no-channels-last", action="store_true")
@@ -317,20 +318,29 @@ def cpu_baseline(args, model_cpu, fm_cpu):
     import oracle  # checker / baseline only — never on the product path
 
     B = 64
-    # pick the torch thread count that is fastest on this box (containers often expose more logical CPUs
-    # than their quota sustains: on the MI355X boxes 32 threads beat 128 by 3x)
-    probe = synth.normalize_u8(synth.synth_images_u8(torch.arange(16)), synth.IMAGENET_MEAN, synth.IMAGENET_STD)
+    # pick the torch thread count that is fastest on this box (containers often expose more logical CPUs than their quota
+    # sustains: on the MI355X boxes 16-32 threads beat 256 by 3x): ResNet-50 forward of 64 images, best of 2 after a warm-up
+    # call, per candidate; the all-cores figure is reported beside the best one
+    probe = synth.normalize_u8(synth.synth_images_u8(torch.arange(64)), synth.IMAGENET_MEAN, synth.IMAGENET_STD)
+    try:
+        all_cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        all_cores = os.cpu_count() or torch.get_num_threads()
     best_t, best_dt = torch.get_num_threads(), float("inf")
-    cands = sorted({t for t in (8, 16, 32, 64, torch.get_num_threads()) if t <= torch.get_num_threads()})
+    cands = sorted({t for t in (8, 16, 32, 64, 128, all_cores) if t <= all_cores})
+    thread_probe = {}
     with torch.no_grad():
         for t in cands:
             torch.set_num_threads(t)
-            model_cpu(probe)
-            t0 = time.perf_counter()
-            model_cpu(probe)
-            dt = time.perf_counter() - t0
-            if dt < best_dt:
-                best_t, best_dt = t, dt
+            model_cpu(probe[:16])
+            dts = []
+            for _ in range(2):
+                t0 = time.perf_counter()
+                model_cpu(probe)
+                dts.append(time.perf_counter() - t0)
+            thread_probe[t] = 64 / min(dts)
+            if min(dts) < best_dt:
+                best_t, best_dt = t, min(dts)
     torch.set_num_threads(best_t)
     threads = best_t
     oracle.set_threads(threads)
@@ -389,6 +399,10 @@ def cpu_baseline(args, model_cpu, fm_cpu):
                   f"(ATen tie order) + CPU CLIP encode + gather; {dt:.1f} s",
         "collect_only_GBps": n * bytes_per_img / agg_s[0] / 1e9,
         "collect_only_seconds": agg_s[0],
+        # ResNet-50 forward alone, images/s per thread count tried (64 images, best of 2): how `cores` was chosen, and what
+        # every core of the box gives (`all_cores`)
+        "thread_probe_forward_images_per_s": {str(k_): v for k_, v in thread_probe.items()},
+        "all_cores": {"threads": all_cores, "forward_images_per_s": thread_probe.get(all_cores)},
     }
 
 
@@ -472,7 +486,7 @@ def probing_leg(dev):
     }
 
 
-def collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, cast=None, check_n=None, overlap=None):
+def collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, cast=None, check_n=None, overlap=None, keep_db=None):
     """A short run of the same step on another probed model / aggregator / activation dtype, so that the reduce kernel that
     configuration selects gets its own driver-measured roofline object (algorithmic bytes / per-dispatch HIP-event time, as
     for the headline) and its own oracle self-check.  ``overlap``: embed on a second stream (None = as the headline)."""
@@ -481,12 +495,12 @@ def collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, c
     if overlap is not None:
         OVERLAP = bool(overlap)
     try:
-        return _collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, cast, check_n)
+        return _collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, cast, check_n, keep_db)
     finally:
         OVERLAP = saved
 
 
-def _collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, cast, check_n):
+def _collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, cast, check_n, keep_db=None):
     warm = [synth.synth_images_u8(torch.arange(10**7 + i * B, 10**7 + (i + 1) * B, device=dev)) for i in range(2)]
     cv_w = make_cv(model, 2 * B, args.k, args.tie_mode, layers, agg)
     finish_job(cv_w, run_steps(cv_w, fm, warm, 0, 2 * B, cast), 0, 2 * B, False)  # MIOpen / hipBLASLt pick their kernels
@@ -497,11 +511,15 @@ def _collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, 
     N.prof_reset()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    finish_job(cv, run_steps(cv, fm, batches, 0, n, cast), 0, n, False)
+    db = finish_job(cv, run_steps(cv, fm, batches, 0, n, cast), 0, n, False)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ms, launches, nbytes = N.prof_read(N.SL_PROF_REDUCE)
+    g_ms, g_n, g_bytes = N.prof_read(N.SL_PROF_GATHER)
     N.prof_enable(False)
+    if keep_db is not None:
+        keep_db.update(db)
+    del db
     gbps = nbytes / ms / 1e6 if ms else None
     out = {
         "workload": workload, "images_per_s": n / dt, "steps": steps, "batch": B,
@@ -510,9 +528,236 @@ def _collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, 
                      "avg_launch_us": ms / max(launches, 1) * 1e3, "algorithmic_bytes_per_launch": nbytes / max(launches, 1),
                      "condition": "in-pipeline: inputs written by the model's last kernel microseconds earlier, "
                                   + ("embed on a second stream" if OVERLAP else "embed on the same stream")},
+        # K5 (embeds[sample_ids], activation_based.py:387-390): C*k*D*4 bytes read + written per layer
+        "gather_k5": {"bound": "hbm", "achieved": g_bytes / g_ms / 1e6 if g_ms else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                      "frac": g_bytes / g_ms / 1e6 / HBM_PEAK_GBPS if g_ms else None, "launches": g_n,
+                      "algorithmic_bytes_per_launch": g_bytes / max(g_n, 1)},
     }
     if not args.no_self_check:
         out["self_check"] = self_check(dev, model, fm, args, n=check_n or 2 * B, B=B, layers=layers, agg=agg, cast=cast)
+    return out
+
+
+def _prompts(n):
+    words = ["zebra", "stripe", "wheel", "sky", "grass", "dog", "cat", "red", "round", "metal", "wood", "water", "face", "text"]
+    return [f"a photo of a {words[i % 14]} {words[(i // 14) % 14]} {i}" for i in range(n)]
+
+
+@torch.no_grad()
+def config3_leg(dev, args):
+    """BASELINE configs[3] at its full geometry on one GPU: ViT-B/16 probed model (random init), ALL 12 encoder blocks
+    (B,197,768) under aggregate_transformer_max (K2 + K3), SigLIP-so400m embed (27 x 1152, MLP 4304, patch 14, 256 tokens;
+    `NativeSigLip` on the package's kernels) into concept_db (768, k, 1152) per block, then `Lens.text_probing` of 10,000
+    prompts through the so400m TEXT tower (27 x 1152, ctx 64) against the 12 aggregated layers (K6: 92.16 M similarities)."""
+    import numpy as np
+
+    import oracle  # checker only
+    from semanticlens_amd.foundation_models import NativeSigLip
+
+    base = synth.SyntheticSigLip(device=dev)  # so400m geometry (synth.SIGLIP_SO400M)
+    fm = NativeSigLip(base)
+    vit = synth.vit_b16().to(dev)
+    layers = [f"blocks.{i}" for i in range(12)]
+    B = args.batch
+    db = {}
+    out = collect_leg(
+        dev, fm, args, vit, layers, aggregators.aggregate_transformer_max,
+        "colreduce (K2, (B, 197, 768) token activations, component axis contiguous)",
+        "BASELINE configs[3], full geometry: ViT-B/16 (random init) probed model, all 12 encoder blocks (B,197,768) fp32, "
+        "aggregate_transformer_max, 7 262 208 B/image; embed = NativeSigLip at the SigLIP-so400m geometry (27 x 1152, 16 heads "
+        "of 72, MLP 4304, patch 14 -> 256 tokens, D = 1152), on the same stream", steps=4, B=B, check_n=B, overlap=False, keep_db=db)
+    assert all(v.shape == (768, args.k, 1152) for v in db.values()) and len(db) == 12
+    agg_db = {name: v.mean(1) for name, v in db.items()}  # what a user hands text_probing (README: `concept_db[layer].mean(1)`)
+    lens = Lens(fm, device=dev)
+    prompts = _prompts(10000)
+    lens.text_probing(prompts[:1024], agg_db, batch_size=1024)  # warm-up
+    torch.cuda.synchronize()
+    N.prof_enable(True)
+    N.prof_reset()
+    t0 = time.perf_counter()
+    sims = lens.text_probing(prompts, agg_db, batch_size=1024)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    N.prof_enable(False)
+    assert all(v.shape == (10000, 768) for v in sims.values())
+    n_sims = 10000 * 768 * 12
+    # the probe against the oracle on a sample of the queries: the same device text embeddings, fp64 cosine on the host
+    q = fm.encode_text(fm.tokenize(prompts[:64]).to(dev)).float().cpu().numpy()
+    worst = 0.0
+    for name in (layers[0], layers[-1]):
+        want = oracle.similarity(q, agg_db[name].cpu().numpy())
+        worst = max(worst, float(np.abs(sims[name][:64].cpu().numpy() - want).max()))
+    if not worst < 1e-4:
+        raise AssertionError(f"config3: text_probing differs from the oracle by {worst}")
+    out["text_probing_from_prompts"] = {
+        "queries_per_s": 10000 / wall, "Msim_per_s": n_sims / wall / 1e6, "wall_ms": wall * 1e3,
+        "workload": "Lens.text_probing: 10,000 prompts -> tokenizer -> so400m text tower (27 x 1152, ctx 64, batches of 1024) -> "
+                    "cosine GEMM vs 12 layers x 768 components x D=1152 (the leg's own concept_db, mean over k)",
+        "max_abs_diff_vs_oracle_64_queries": worst}
+    out["embed_model"] = fm.name
+    del db, agg_db, sims
+    return out
+
+
+def config4_leg(dev, fm, args):
+    """BASELINE configs[4] on one GPU: ConvNeXt-L (random init, 198 M parameters), the four stage outputs
+    (192 x 56^2, 384 x 28^2, 768 x 14^2, 1536 x 7^2: 4 515 840 B/image) through (i) the activation collect (K1 + K3, roofline),
+    (ii) the relevance-maximisation visualizer (EpsilonPlusFlat LRP backward in PyTorch, K1 sum + abs-norm + K3) and
+    (iii) eval_clarity / eval_redundancy / eval_polysemanticity over the WHOLE concept_db (2 880 components x k x 512)."""
+    import numpy as np
+
+    import oracle  # checker only
+    from semanticlens_amd import scores
+    from semanticlens_amd.component_visualization import RelevanceComponentVisualizer
+
+    model = synth.convnext_l().to(dev)
+    layers = [f"stages.{i}" for i in range(4)]
+    B = args.batch
+    db = {}
+    out = collect_leg(
+        dev, fm, args, model, layers, aggregators.aggregate_conv_max,
+        "rowreduce (K1, NCHW fp32 stage outputs, S = 3136 / 784 / 196 / 49)",
+        "BASELINE configs[4] collect stage: ConvNeXt-L (random init) probed model, stages.0-3 outputs fp32 NCHW, aggregate_conv_max, "
+        "4 515 840 B/image; embed = the headline's CLIP ViT-B/32", steps=4, B=B, check_n=B, keep_db=db)
+    widths = (192, 384, 768, 1536)
+    assert all(db[n].shape == (c, args.k, 512) for n, c in zip(layers, widths))
+
+    # ---- (ii) relevance visualizer: forward + LRP backward per batch, both top-k states ----
+    n_rel, b_rel = 128, 32
+    u8 = synth.synth_images_u8(torch.arange(n_rel, device=dev))
+    ds_model = _Rows(synth.normalize_u8(u8, synth.IMAGENET_MEAN, synth.IMAGENET_STD).cpu(), f"cfg4-{n_rel}", True)
+    ds_fm = _Rows(u8.cpu(), "cfg4-fm", False)
+    first = {}
+
+    def tapped(model_, modules, images, targets):
+        from semanticlens_amd.component_visualization.lrp import lrp_epsilon_plus_flat
+
+        res = lrp_epsilon_plus_flat(model_, modules, images, targets)
+        if not first:
+            first.update({k_: (a.detach().clone(), r.detach().clone()) for k_, (a, r) in res.items()})
+        return res
+
+    with torch.enable_grad():
+        cvr = RelevanceComponentVisualizer(model, ds_model, ds_fm, layers, num_samples=args.k, attribution=tapped, device=dev)
+        cvr._run(batch_size=b_rel)  # warm-up (MIOpen backward kernels)
+        first.clear()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cvr._run(batch_size=b_rel)
+        torch.cuda.synchronize()
+        dt_rel = time.perf_counter() - t0
+    worst_rel = 0.0
+    for name, c in zip(layers, widths):
+        ids = cvr.get_max_reference(name)
+        assert ids.shape == (c, args.k) and int(ids.max()) < n_rel and int(ids.min()) >= 0
+        act, rel = first[name]
+        got = cvr._summed(rel).cpu().numpy()
+        want = oracle.agg_conv(rel.float().cpu().numpy(), "sum")
+        scale = max(float(np.abs(want).max()), 1e-30)
+        worst_rel = max(worst_rel, float(np.abs(got - want).max()) / scale)
+    if not worst_rel < 1e-5:
+        raise AssertionError(f"config4: summed relevance differs from the oracle by {worst_rel} of its scale")
+    out["relevance_visualizer"] = {
+        "images_per_s": n_rel / dt_rel, "images": n_rel, "batch": b_rel, "composite": cvr.composite,
+        "workload": "RelevanceComponentVisualizer._run: ConvNeXt-L forward + EpsilonPlusFlat LRP backward (PyTorch autograd), "
+                    "relevance and activation of 4 stages -> K1 sum -> abs-norm -> K3 (two top-k states per layer)",
+        "summed_relevance_max_rel_diff_vs_oracle": worst_rel}
+    del cvr, first
+
+    # ---- (iii) the scores over the whole concept_db ----
+    lens = Lens(fm, device=dev)
+    agg_db = {n: v.mean(1) for n, v in db.items()}
+
+    def timed(fn, family):
+        fn()  # warm-up
+        torch.cuda.synchronize()
+        N.prof_enable(True)
+        N.prof_reset()
+        t = time.perf_counter()
+        res = fn()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t
+        ms, launches, work = N.prof_read(family)
+        N.prof_enable(False)
+        return res, wall, ms, launches, work
+
+    comps = sum(widths)
+    in_bytes = comps * args.k * 512 * 4
+    cl, w_cl, ms_cl, n_cl, by_cl = timed(lambda: lens.eval_clarity(db), N.SL_PROF_SCORES)
+    po, w_po, ms_po, n_po, by_po = timed(lambda: lens.eval_polysemanticity(db), N.SL_PROF_SCORES)
+    rd, w_rd, ms_rd, n_rd, fl_rd = timed(lambda: lens.eval_redundancy(agg_db), N.SL_PROF_GEMM)
+    # against the oracle: clarity of every component, polysemanticity of 48 components through scikit-learn, redundancy per layer
+    worst = {"clarity": 0.0, "polysemanticity": 0.0, "redundancy": 0.0}
+    for name in layers:
+        V = db[name].cpu().numpy()
+        worst["clarity"] = max(worst["clarity"], float(np.abs(cl[name].cpu().numpy() - oracle.clarity(V)).max()))
+        worst["redundancy"] = max(worst["redundancy"], abs(float(rd[name]) - float(oracle.redundancy(agg_db[name].cpu().numpy()))))
+        sub = np.arange(0, V.shape[0], max(1, V.shape[0] // 12))[:12]
+        worst["polysemanticity"] = max(worst["polysemanticity"],
+                                       float(np.abs(po[name].cpu().numpy()[sub] - oracle.polysemanticity(V[sub])).max()))
+    if not all(v < 1e-4 for v in worst.values()):
+        raise AssertionError(f"config4: scores differ from the oracle: {worst}")
+    out["scores_full_db"] = {
+        "components": comps, "k": args.k, "D": 512, "input_bytes": in_bytes,
+        "clarity_k7": {"bound": "hbm", "achieved": by_cl / ms_cl / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                       "frac": by_cl / ms_cl / 1e6 / HBM_PEAK_GBPS, "kernel_ms": ms_cl, "launches": n_cl, "wall_ms": w_cl * 1e3,
+                       "note": "C*n*D*4 bytes read once; the 4 layers are 2.4-19 MB each: launch-latency-sized"},
+        "polysemanticity_k9": {"bound": "valu/lds", "components_per_s": comps / w_po, "kernel_ms": ms_po, "launches": n_po, "wall_ms": w_po * 1e3,
+                               "input_GBps": by_po / ms_po / 1e6,
+                               "note": "Gram matrix of each component from C*n*D*4 input bytes (read once), then sklearn's k-means++ / "
+                                       "Lloyd / best-of-10 replayed in Gram space in fp64 in LDS: no HBM traffic per Lloyd iteration"},
+        "redundancy_k8": {"bound": "mfma", "achieved_TFLOPs": fl_rd / ms_rd / 1e9 if ms_rd else None, "kernel_ms": ms_rd, "launches": n_rd,
+                          "wall_ms": w_rd * 1e3, "note": "K6 on (C,D)x(C,D) per layer + row max; C <= 1536: a few tiles, latency-bound"},
+        "max_abs_diff_vs_oracle": worst}
+    del db, agg_db, model
+    return out
+
+
+def cpu_baseline_scores(threads_best: int):
+    """Same-box CPU figures for the OTHER metric and the scores (BASELINE.md §2 holds container numbers): the reference's
+    arithmetic on the host — `similarity_score` (scores.py:119-128: F.normalize + matmul = torch-CPU sgemm), `clarity_score`
+    (scores.py:45-46), `polysemanticity_score` (scores.py:167-185: scikit-learn KMeans per component) — at SURVEY §6's shapes,
+    with the thread count the images/s baseline picked AND with every core the process may use."""
+    import numpy as np
+
+    import oracle  # checker / baseline only
+
+    try:
+        all_cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        all_cores = os.cpu_count()
+    g = torch.Generator().manual_seed(6)
+    x, y = torch.randn(10000, 1152, generator=g), torch.randn(768, 1152, generator=g)
+    V = torch.randn(2048, 20, 512, generator=g)
+    Vp = np.random.RandomState(4).randn(64, 20, 512).astype(np.float32)
+
+    def best_of(fn, reps=3):
+        fn()
+        ts = []
+        for _ in range(reps):
+            t = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t)
+        return min(ts)
+
+    out = {"kind": "port", "threads_best": threads_best, "host_cores_affinity": all_cores,
+           "sample": "similarity (10000,1152)x(768,1152)^T = one configs[3] layer (7.68 M similarities); clarity (2048,20,512); "
+                     "polysemanticity 64 x (20,512) through scikit-learn; best of 3 after one warm-up call"}
+    before = torch.get_num_threads()
+    try:
+        for tag, t in (("best_threads", threads_best), ("all_cores", all_cores)):
+            torch.set_num_threads(t)
+            oracle.set_threads(t)
+            dt_sim = best_of(lambda: oracle.similarity_torch(x, y))
+            dt_cl = best_of(lambda: oracle.clarity_torch(V))
+            dt_cl_c = best_of(lambda: oracle.clarity(V.numpy()))
+            out[tag] = {"threads": t, "similarity_Msim_per_s": 10000 * 768 / dt_sim / 1e6, "similarity_GFLOPs": 2 * 10000 * 768 * 1152 / dt_sim / 1e9,
+                        "clarity_ms_2048x20x512": dt_cl * 1e3, "clarity_ms_oracle_c_openmp": dt_cl_c * 1e3}
+        t = time.perf_counter()
+        oracle.polysemanticity(Vp)
+        out["polysemanticity_ms_per_component"] = (time.perf_counter() - t) / 64 * 1e3
+    finally:
+        torch.set_num_threads(before)
     return out
 
 
@@ -589,7 +834,7 @@ def main():
     OVERLAP = bool(args.overlap)
     if args.quick:
         args.no_api_leg = args.no_channels_last = args.no_probing = args.no_cpu_baseline = True
-        args.no_tokens_leg = args.no_half_leg = True
+        args.no_tokens_leg = args.no_half_leg = args.no_config4_leg = True
 
     B, K, W, bps = args.batch, args.steps, args.warmup, max(1, args.batches_per_step)
     if args.scaling == "strong":  # fixed TOTAL work, contiguous shards (distributed.shard_range), ids global
@@ -858,17 +1103,13 @@ def main():
             "1 404 928 B/image", steps=min(n_batches, 16), B=B, cast=torch.float16)
         del model_h
     if single and not args.no_tokens_leg:
-        # BASELINE configs[3]'s collect stage: ViT-B/16 probed model, all 12 encoder blocks, token-max aggregator -> K2 (colreduce)
-        vit = synth.vit_b16().to(dev)
-        Bt = B
-        line["tokens_collect"] = collect_leg(
-            dev, fm, args, vit, [f"blocks.{i}" for i in range(12)], aggregators.aggregate_transformer_max,
-            "colreduce (K2, (B, 197, 768) token activations, component axis contiguous)",
-            "BASELINE configs[3] collect stage: ViT-B/16 (random init) probed model, all 12 encoder blocks (B,197,768) fp32, "
-            "aggregate_transformer_max, 7 262 208 B/image; embed = the headline's CLIP ViT-B/32, on the SAME stream (beside a "
-            "GEMM-bound probed model a second stream loses 2-3 %: tools/k2_leg_probe.py)", steps=min(n_batches, 12), B=Bt,
-            check_n=Bt, overlap=False)
-        del vit
+        # BASELINE configs[3] at full geometry (ViT-B/16 x 12 blocks -> K2; so400m embed; 10k-prompt text_probing at D = 1152)
+        line["config3_full"] = config3_leg(dev, args)
+        torch.cuda.empty_cache()
+    if single and not args.no_config4_leg:
+        # BASELINE configs[4]: ConvNeXt-L 4-stage collect (K1), relevance visualizer, scores over the whole concept_db
+        line["config4_full"] = config4_leg(dev, fm, args)
+        torch.cuda.empty_cache()
     if single and not args.no_api_leg:
         line["api_path"] = api_path_leg(dev, model, fm_base, args)
     if single and not args.no_probing:
@@ -877,6 +1118,7 @@ def main():
     if single and not args.no_cpu_baseline:
         torch.manual_seed(0)
         line["cpu_baseline"] = cpu_baseline(args, synth.resnet50(), synth.SyntheticClip(device="cpu"))
+        line["cpu_baseline"]["scores_and_probing"] = cpu_baseline_scores(line["cpu_baseline"]["threads"])
     print(json.dumps(line), flush=True)
     if sharded:
         sld.destroy_native_comms()

@@ -163,6 +163,35 @@ def similarity(x, y) -> np.ndarray:
     return out
 
 
+def similarity_torch(x, y):
+    """`similarity_score` as the reference runs it on the host — `F.normalize` + `matmul` / `cosine_similarity` on torch-CPU
+    tensors (scores.py:119-128) — for the cpu_baseline TIMING of `text_probing` (torch's sgemm, not this file's fp64 loops,
+    is what the reference's CPU path costs).  Pinned to `similarity` / the golden vectors in tests/test_oracle_golden.py."""
+    import torch
+    import torch.nn.functional as F
+
+    x, y = torch.as_tensor(x), torch.as_tensor(y)
+    if x.shape == y.shape:
+        return F.cosine_similarity(x, y, dim=-1)
+    xn, yn = F.normalize(x, dim=-1), F.normalize(y, dim=-1)
+    if x.shape[1] == y.shape[0]:
+        return xn @ yn
+    if x.shape[1] == y.shape[1]:
+        return xn @ yn.T
+    raise ValueError("x and y must have the same shape")
+
+
+def clarity_torch(V):
+    """`clarity_score` as the reference computes it on torch-CPU tensors (scores.py:45-46), for cpu_baseline timing."""
+    import torch
+    import torch.nn.functional as F
+
+    V = torch.as_tensor(V)
+    n = V.shape[-2]
+    m = F.normalize(V, dim=-1).mean(-2)
+    return ((m**2).sum(-1) - 1 / n) / (n - 1) * n
+
+
 def clarity(V) -> np.ndarray:
     V = _f32(V)
     C, n, D = V.shape

@@ -392,3 +392,64 @@ def vit_b16(seed: int = 0, **arch) -> nn.Module:
     m = VisionTransformer(**arch).eval()
     m.name = "vit-b16-random"
     return m
+
+
+# ------------------------------------------------------------------------------------------------
+# probed model of BASELINE configs[4]: ConvNeXt-L (random init), stages named ``stages.<i>``
+# ------------------------------------------------------------------------------------------------
+class _LayerNorm2d(nn.LayerNorm):
+    """LayerNorm over the channel axis of an NCHW map (ConvNeXt's channels_first norm)."""
+
+    def forward(self, x):
+        return super().forward(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+
+
+class ConvNeXtBlock(nn.Module):
+    """Liu et al. 2022: 7x7 depthwise conv -> LayerNorm -> 1x1 (4x) -> GELU -> 1x1 -> layer scale -> residual."""
+
+    def __init__(self, dim, layer_scale=1e-6):
+        super().__init__()
+        self.dwconv = nn.Conv2d(dim, dim, 7, padding=3, groups=dim)
+        self.norm = nn.LayerNorm(dim, eps=1e-6)
+        self.pwconv1 = nn.Linear(dim, 4 * dim)
+        self.act = nn.GELU()
+        self.pwconv2 = nn.Linear(4 * dim, dim)
+        self.gamma = nn.Parameter(layer_scale * torch.ones(dim))
+
+    def forward(self, x):
+        h = self.dwconv(x).permute(0, 2, 3, 1)
+        h = self.pwconv2(self.act(self.pwconv1(self.norm(h)))) * self.gamma
+        return x + h.permute(0, 3, 1, 2)
+
+
+class ConvNeXt(nn.Module):
+    """ConvNeXt classifier: 4x4/4 stem, four stages of ``depths`` blocks at ``dims`` channels with 2x2/2 downsampling in
+    front of stages 1-3, global average pool, LayerNorm, linear head.  ``stages.<i>`` outputs ``(B, dims[i], 56 >> i, 56 >> i)``
+    at 224 x 224: ConvNeXt-L = depths (3, 3, 27, 3), dims (192, 384, 768, 1536) -> S = 3136 / 784 / 196 / 49."""
+
+    def __init__(self, depths=(3, 3, 27, 3), dims=(192, 384, 768, 1536), num_classes=1000, layer_scale=1e-6):
+        super().__init__()
+        self.downsample_layers = nn.ModuleList([nn.Sequential(nn.Conv2d(3, dims[0], 4, 4), _LayerNorm2d(dims[0], eps=1e-6))])
+        for i in range(3):
+            self.downsample_layers.append(nn.Sequential(_LayerNorm2d(dims[i], eps=1e-6), nn.Conv2d(dims[i], dims[i + 1], 2, 2)))
+        self.stages = nn.ModuleList([nn.Sequential(*[ConvNeXtBlock(d, layer_scale) for _ in range(n)]) for n, d in zip(depths, dims)])
+        self.norm = nn.LayerNorm(dims[-1], eps=1e-6)
+        self.head = nn.Linear(dims[-1], num_classes)
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                nn.init.zeros_(m.bias)
+
+    def forward(self, x):
+        for down, stage in zip(self.downsample_layers, self.stages):
+            x = stage(down(x))
+        return self.head(self.norm(x.mean((-2, -1))))
+
+
+def convnext_l(seed: int = 0, layer_scale: float = 1.0, **arch) -> nn.Module:
+    """ConvNeXt-L, random init.  ``layer_scale`` defaults to 1.0 instead of the training-time initial value 1e-6: with
+    random weights and gamma = 1e-6 every block would be the identity and all blocks of a stage would emit the same map."""
+    torch.manual_seed(seed)
+    m = ConvNeXt(layer_scale=layer_scale, **arch).eval()
+    m.name = "convnext-l-random"
+    return m
