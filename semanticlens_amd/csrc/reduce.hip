@@ -887,121 +887,152 @@ __global__ __launch_bounds__(64 * NW) void colreduce_kernel(const E* __restrict_
   }
 }
 
-// ---- colreduce_dma: the same reduction fed through wave-private LDS-DMA rings (round 4) ----------------------------------
-// colreduce_kernel issues eight VGPR loads per lane, reduces them, and only then issues the next eight: the bytes a wave
-// has in flight swing between 8 KB and nothing once per round, and a (256, 197, 768) launch is only six such rounds long.
-// Here the global side is K1's (rowreduce_dma_kernel): a wave owns a 64-piece column chunk (a piece = 16 bytes = 4 fp32 or 8
-// half-precision components) and walks its rows in *batches* of kColRows rows; a batch is kColRows 1-KiB LDS-DMA
-// instructions (`global_load_lds_dwordx4`: lane l fetches its own 16 bytes of one row) into a slot of a wave-private
-// ring of DEPTH slots, DEPTH - 1 batches in flight while one is reduced, counted `s_waitcnt vmcnt`, no barrier until the
-// waves of the workgroup (which split the reduced axis) combine.  The per-row work needs no cross-lane step: a lane reads
-// its own piece of each row back with one ds_read_b128 (conflict-free: lane * 16 within a 1-KiB row).
-// Always kColRows instructions per batch so that the waits are compile-time constants; a row past the end keeps lane 0
-// alive on the tensor's first piece and lands in the workgroup's spare KiB (K1's rule).
-// Needs: x 16-byte aligned, row and sample strides multiples of 16 bytes, F a multiple of the piece.
-constexpr int kColRows = 4;
-constexpr int kColDepthDefault = 3;  // ring slots per wave unless SL_COLREDUCE_DEPTH says otherwise (tools/k2_lab.py)
-
-template <typename E, int OP, int NW, int DEPTH>
-__global__ __launch_bounds__(64 * NW) void colreduce_dma_kernel(const E* __restrict__ x, int64_t B, int T, int64_t F, int64_t sb,
-                                                                 int64_t st, int t_begin, int t_end, float denom,
-                                                                 int64_t tail_from, uint16_t* __restrict__ cand,
-                                                                 float* __restrict__ outf) {
-  constexpr int EPP = 16 / (int)sizeof(E);  // components per piece
-  constexpr int CW = 64 * EPP;              // components per chunk
+// ---- colreduce2 (round 4): 16-byte pieces for every dtype, LPR lanes per row, loads never drain ------------------------------
+// What the round-4 lab (tools/k2_lab.py, profiles/r04_k2_lab.txt) found wrong with colreduce_kernel on (256, 197, 768):
+//  * its row tail ran ONE load per lane and iteration: 197 = 6 x 32 + 5 rows left two serialised memory round trips (~2 us
+//    each) at the end of a 26-us launch; (256, 196, 1024) — one tail trip, 16 waves per CU — ran 6.3 TB/s, this shape 5.9;
+//  * a round of eight loads was reduced before the next eight were issued: the bytes in flight swung between 8 KB per wave and
+//    nothing (the LDS-DMA ring kernel above removes that too, but its rings cap a CU at 16 waves: 5.6-6.1 TB/s);
+//  * half-precision rows were read with 8-byte loads (512 B per wave instruction): 5.0 TB/s where fp32 reads 5.9.
+// Here every load is 16 bytes (a *piece*: 4 fp32 or 8 half components).  A row chunk is LPR pieces (64, 32 or 16 lanes), so a
+// wave instruction covers 64 / LPR rows x LPR x 16 bytes = 1 KiB whatever the row length: fp16 F = 768 (96 pieces) takes LPR = 32
+// (three full chunks) instead of 1.5 chunks of 64; lanes that share a piece column combine once at the end (one xor-shuffle per
+// level).  Rows are walked in blocks of INFL loads per lane; block k + 1 is issued BEFORE block k is reduced (two register
+// sets, ping-pong), so 8-16 loads per lane are in flight from the first block to the last.  No predicated loads: a row past the
+// end is clamped to the last row (a cache hit) and its values are discarded by the accumulator's `valid` flag, so the last
+// block costs one round trip like any other.
+template <typename E, int OP, int NW, int LPR, int INFL>
+__global__ __launch_bounds__(64 * NW) void colreduce2_kernel(const E* __restrict__ x, int64_t B, int T, int64_t F, int64_t sb,
+                                                              int64_t st, int t_begin, int t_end, float denom, int64_t tail_from,
+                                                              uint16_t* __restrict__ cand, float* __restrict__ outf) {
+  constexpr int EPP = 16 / (int)sizeof(E);
+  constexpr int RPI = 64 / LPR;  // rows per wave instruction
+  constexpr int CW = LPR * EPP;  // components per chunk
   constexpr bool SUM = (OP == OP_SUM || OP == OP_ABSSUM);
-  constexpr int kSlot = kColRows * 1024;
-  extern __shared__ __align__(1024) unsigned char smem[];  // NW rings of DEPTH slots + 1 spare KiB
-  typedef __attribute__((address_space(3))) void lds_void;
-  typedef const __attribute__((address_space(1))) void glb_void;
+  constexpr bool ABS = (OP == OP_ABSMAX || OP == OP_ABSSUM);
+  constexpr int STEP = NW * RPI;  // rows one instruction of every wave of the workgroup covers
+  __shared__ float s_part[NW][CW];
   const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  unsigned char* ring = smem + w * (DEPTH * kSlot);
-  unsigned char* spare = smem + NW * DEPTH * kSlot;
+  const int w = threadIdx.x >> 6;
+  const int sub = lane / LPR, pl = lane % LPR;
   const int64_t nchunk = (F + CW - 1) / CW;
   const int64_t ntask = B * nchunk;
   const int64_t rot = (tail_from > 0 && tail_from < ntask) ? tail_from : 0;
-  const int rows = t_end - t_begin;
-  const int nb_total = (rows + kColRows - 1) / kColRows;
-  const int nbw = w < nb_total ? (nb_total - w + NW - 1) / NW : 0;  // batches of this wave: w, w + NW, ...
-  const unsigned char* x0 = reinterpret_cast<const unsigned char*>(x);
-  auto wait_batches = [&](int younger) __attribute__((always_inline)) {  // at most `younger` batches still in flight
-    switch (younger) {
-      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-      case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-      case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-      case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  const int tw = t_begin + w * RPI + sub;  // this lane's first row
+  const int last = t_end - 1;
+  const int rows_w = t_end - (t_begin + w * RPI);                 // rows from the wave's first row on
+  const int ninst = rows_w > 0 ? (rows_w + STEP - 1) / STEP : 0;  // wave instructions that touch a valid row
+  const int nblk = (ninst + INFL - 1) / INFL;
+  const int64_t row_pieces = st * (int64_t)sizeof(E) / 16;
+  auto elems = [&](const u32x4& v, float(&e)[EPP]) __attribute__((always_inline)) {
+    if constexpr (EPP == 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) e[i] = bits_f32(v[i]);
+    } else {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) unpack2<E>(v[d], e[2 * d], e[2 * d + 1]);
+    }
+    if constexpr (ABS) {
+#pragma unroll
+      for (int i = 0; i < EPP; ++i) e[i] = __builtin_fabsf(e[i]);
     }
   };
-  static_assert(kColRows == 4 && DEPTH >= 2 && DEPTH <= 4, "the vmcnt table above");
   for (int64_t ti = blockIdx.x; ti < ntask; ti += gridDim.x) {
     int64_t task = ti + rot;
     if (task >= ntask) task -= ntask;
     const int64_t b = task / nchunk;
-    const int64_t f0 = (task % nchunk) * CW + (int64_t)lane * EPP;
-    const bool in = f0 < F;  // F % EPP == 0 on this path; lane 0 of a chunk is always in
-    const unsigned char* base = x0 + (b * sb + (in ? f0 : 0)) * (int64_t)sizeof(E);
-    const int64_t row_bytes = st * (int64_t)sizeof(E);
-    const bool stream = task < tail_from;  // wave-uniform cache policy (top of this file)
-    auto issue = [&](int jb) __attribute__((always_inline)) {
-      const int t0 = t_begin + kColRows * (w + NW * jb);
-      unsigned char* d = ring + (jb % DEPTH) * kSlot;
+    const int64_t f0 = (task % nchunk) * CW + (int64_t)pl * EPP;
+    const bool in = f0 < F;  // F % EPP == 0 on this path; lanes past the row re-read its first piece and are never stored
+    const u32x4* base = reinterpret_cast<const u32x4*>(x + b * sb + (in ? f0 : 0));
+    // max ops: v_max_f32 drops NaN, torch.amax propagates it.  As in K1 a running SUM rides along (v_pk_add_f32: NaN in => NaN
+    // out) and only columns whose sum is NaN (a NaN, or +inf with -inf) are looked at again, exactly.  Rows past the end are
+    // CLAMPED to the last row: a duplicate changes neither a max nor the detector's verdict; sums mask them instead.
+    float m[EPP];
+    f32x2 det[EPP / 2];
 #pragma unroll
-      for (int r = 0; r < kColRows; ++r) {
-        const bool ok = t0 + r < t_end;
-        unsigned char* dst = ok ? d + r * 1024 : spare;
-        const unsigned char* src = ok ? base + (int64_t)(t0 + r) * row_bytes : x0;
-        if ((ok && in) || lane == 0) {
-          if (stream) __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 2 /* nt */);
-          else __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
+    for (int e = 0; e < EPP; ++e) m[e] = SUM ? 0.f : -__builtin_huge_valf();
+#pragma unroll
+    for (int e = 0; e < EPP / 2; ++e) det[e] = f32x2{0.f, 0.f};
+    auto walk = [&](auto NT) __attribute__((always_inline)) {
+      constexpr bool nt = decltype(NT)::value;
+      auto load = [&](u32x4(&v)[INFL], int k) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < INFL; ++j) {
+          int row = tw + (k * INFL + j) * STEP;
+          row = row < last ? row : last;
+          const u32x4* p = base + (int64_t)row * row_pieces;
+          if constexpr (nt) v[j] = __builtin_nontemporal_load(p);
+          else v[j] = *p;
+        }
+      };
+      auto reduce = [&](const u32x4(&v)[INFL], int k) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < INFL; ++j) {
+          float e[EPP];
+          elems(v[j], e);
+          if constexpr (SUM) {
+            const bool ok = tw + (k * INFL + j) * STEP <= last;
+#pragma unroll
+            for (int i = 0; i < EPP; ++i) m[i] += ok ? e[i] : 0.f;
+          } else {
+#pragma unroll
+            for (int i = 0; i < EPP; ++i) m[i] = __builtin_fmaxf(m[i], e[i]);
+#pragma unroll
+            for (int i = 0; i < EPP / 2; ++i) det[i] += f32x2{e[2 * i], e[2 * i + 1]};
+          }
+        }
+      };
+      u32x4 va[INFL], vb[INFL];
+      if (nblk > 0) load(va, 0);
+#pragma unroll 1
+      for (int k = 0; k < nblk; k += 2) {
+        const bool more1 = k + 1 < nblk;
+        if (more1) load(vb, k + 1);
+        reduce(va, k);
+        if (more1) {
+          if (k + 2 < nblk) load(va, k + 2);
+          reduce(vb, k + 1);
         }
       }
     };
-    Acc<OP> acc[EPP];
+    if (task < tail_from) walk(std::true_type());
+    else walk(std::false_type());
+    if constexpr (!SUM) {
+      bool sus = false;
 #pragma unroll
-    for (int e = 0; e < EPP; ++e) acc[e].init();
-    for (int jb = 0; jb < DEPTH - 1 && jb < nbw; ++jb) issue(jb);
-#pragma unroll 1
-    for (int jb = 0; jb < nbw; ++jb) {
-      if (jb + DEPTH - 1 < nbw) issue(jb + DEPTH - 1);  // into the slot that was reduced one iteration ago
-      const int left = nbw - 1 - jb;
-      wait_batches(left < DEPTH - 1 ? left : DEPTH - 1);
-      const int t0 = t_begin + kColRows * (w + NW * jb);
-      const unsigned char* sl = ring + (jb % DEPTH) * kSlot + lane * 16;
-      u32x4 v[kColRows];
+      for (int i = 0; i < EPP / 2; ++i) sus |= (det[i][0] != det[i][0]) | (det[i][1] != det[i][1]);
+      if (__builtin_expect(__any(sus), 0)) {  // rare: a NaN, or +inf and -inf in one column — look again, exactly
+        bool nan[EPP];
 #pragma unroll
-      for (int r = 0; r < kColRows; ++r) v[r] = *reinterpret_cast<const u32x4*>(sl + r * 1024);
+        for (int i = 0; i < EPP; ++i) nan[i] = false;
+        if (sus) {
+          for (int row = tw; row <= last; row += STEP) {
+            float e[EPP];
+            elems(base[(int64_t)row * row_pieces], e);
 #pragma unroll
-      for (int r = 0; r < kColRows; ++r) {
-        const bool ok = t0 + r < t_end;
-        if constexpr (EPP == 4) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[e].add(bits_f32(v[r][e]), ok);
-        } else {
-#pragma unroll
-          for (int d = 0; d < 4; ++d) {
-            float lo, hi;
-            unpack2<E>(v[r][d], lo, hi);
-            acc[2 * d].add(lo, ok);
-            acc[2 * d + 1].add(hi, ok);
+            for (int i = 0; i < EPP; ++i) nan[i] |= (e[i] != e[i]);
           }
         }
+#pragma unroll
+        for (int i = 0; i < EPP; ++i) m[i] = nan[i] ? bits_f32(0x7FC00000u) : m[i];
       }
     }
-    // combine the waves: each leaves its partials in its own ring (all of its DMAs and reads are done)
-    float* part = reinterpret_cast<float*>(ring);
 #pragma unroll
-    for (int e = 0; e < EPP; ++e) part[lane * EPP + e] = acc[e].lane_value();
+    for (int e = 0; e < EPP; ++e) {
+      float r = m[e];
+      if constexpr (RPI >= 4) r = combine<SUM>(r, __shfl_xor(r, 16, 64));
+      if constexpr (RPI >= 2) r = combine<SUM>(r, __shfl_xor(r, 32, 64));
+      if (lane < LPR) s_part[w][lane * EPP + e] = r;
+    }
     __syncthreads();
     for (int f = threadIdx.x; f < CW; f += 64 * NW) {
       const int64_t fg = (task % nchunk) * CW + f;
       if (fg < F) {
-        float r = reinterpret_cast<const float*>(smem)[f];
+        float v = s_part[0][f];
 #pragma unroll
-        for (int i = 1; i < NW; ++i) r = combine<SUM>(r, reinterpret_cast<const float*>(smem + i * (DEPTH * kSlot))[f]);
-        r = round_to_dtype<E>(finish<OP>(r, denom));  // the reference aggregates in the activation's dtype
-        store_outputs(r, b * F + fg, cand, outf);
+        for (int i = 1; i < NW; ++i) v = combine<SUM>(v, s_part[i][f]);
+        v = round_to_dtype<E>(finish<OP>(v, denom));  // the reference aggregates in the activation's dtype
+        store_outputs(v, b * F + fg, cand, outf);
       }
     }
     __syncthreads();
@@ -1311,76 +1342,96 @@ void dispatch_rowreduce(ProfScope& prof, const float* x, int64_t R, int S, float
   else launch_rowreduce<64, 4, OP>(prof, x, R, S, denom, cand, outf, st);
 }
 
-// colreduce through the LDS-DMA rings when the layout allows and the input is large enough to be bandwidth-bound.
-// SL_COLREDUCE_IMPL = vgpr | dma (default: dma where legal), SL_COLREDUCE_DEPTH = 2 | 3 | 4, SL_COLREDUCE_NW = 4 | 8.
-template <typename T, int OP, int NW, int DEPTH>
-void launch_colreduce_dma_as(ProfScope& prof, const T* x, int64_t B, int T_, int64_t F, int64_t sb, int64_t st_, int t0, int t1,
-                             float denom, int64_t tail_from, uint16_t* cand, float* outf, hipStream_t st) {
-  constexpr int CW = 64 * (16 / (int)sizeof(T));
-  const int lds = NW * DEPTH * kColRows * 1024 + 1024;
-  auto kernel = colreduce_dma_kernel<T, OP, NW, DEPTH>;
-  static bool once = [&] {
-    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    return true;
-  }();
-  (void)once;
+// colreduce2: the default component-contiguous kernel where 16-byte pieces are legal (see the kernel's header).
+// loads per lane and block, two blocks in flight.  4 (tools/k2_lab.py): 72 VGPRs in fp32 / 100 in half precision (6-7 / 4 waves
+// per SIMD); with 8 the half-precision kernels need 140 registers and fall from 5.3 to 4.0 TB/s, fp32 gains nothing
+constexpr int kCol2Infl = 4;
+template <typename T, int OP, int NW, int LPR>
+void launch_colreduce2_as(ProfScope& prof, const T* x, int64_t B, int T_, int64_t F, int64_t sb, int64_t st_, int t0, int t1,
+                          float denom, int64_t tail_from, uint16_t* cand, float* outf, hipStream_t st) {
+  constexpr int CW = LPR * (16 / (int)sizeof(T));
   int64_t blocks = B * ((F + CW - 1) / CW);
   const int64_t cap = (int64_t)num_cus() * 8;
   if (blocks > cap) blocks = cap;
-  SL_LAUNCH(prof, kernel, dim3((unsigned)blocks), dim3(64 * NW), lds, st, x, B, T_, F, sb, st_, t0, t1, denom, tail_from, cand, outf);
+  SL_LAUNCH(prof, (colreduce2_kernel<T, OP, NW, LPR, kCol2Infl>), dim3((unsigned)blocks), dim3(64 * NW), 0, st, x, B, T_, F, sb, st_, t0,
+            t1, denom, tail_from, cand, outf);
 }
 
 template <typename T, int OP>
-bool launch_colreduce_dma(ProfScope& prof, const T* x, int64_t B, int T_, int64_t F, int64_t sb, int64_t st_, int t0, int t1,
-                          float denom, uint16_t* cand, float* outf, hipStream_t st) {
-  static const int impl = [] {
+bool launch_colreduce2(ProfScope& prof, const T* x, int64_t B, int T_, int64_t F, int64_t sb, int64_t st_, int t0, int t1,
+                       float denom, uint16_t* cand, float* outf, hipStream_t st) {
+  static const int impl = [] {  // SL_COLREDUCE_IMPL = v2 (default) | vgpr (rounds 1-3) | dma (LDS-DMA rings; -DSL_K2_DMA_LAB builds only)
     const char* e = getenv("SL_COLREDUCE_IMPL");
-    return e ? (strcmp(e, "vgpr") == 0 ? 0 : 1) : 1;
-  }();
-  static const int forced_depth = [] {
-    const char* e = getenv("SL_COLREDUCE_DEPTH");
-    return e ? atoi(e) : 0;
+    return e ? (strcmp(e, "vgpr") == 0 ? 0 : strcmp(e, "dma") == 0 ? 2 : 1) : 1;
   }();
   static const int forced_nw = [] {
     const char* e = getenv("SL_COLREDUCE_NW");
     return e ? atoi(e) : 0;
   }();
+  static const int forced_lpr = [] {
+    const char* e = getenv("SL_COLREDUCE_LPR");
+    return e ? atoi(e) : 0;
+  }();
   constexpr int EPP = 16 / (int)sizeof(T);
-  constexpr int CW = 64 * EPP;
   const int64_t rows = t1 - t0;
-  const int64_t bytes = B * rows * F * (int64_t)sizeof(T);
-  if (!impl || ((uintptr_t)x & 15) != 0 || (F % EPP) != 0 || ((st_ * (int64_t)sizeof(T)) & 15) != 0 ||
-      ((sb * (int64_t)sizeof(T)) & 15) != 0 || rows < 16 || bytes < (8ll << 20))
+  if (impl != 1 || ((uintptr_t)x & 15) != 0 || (F % EPP) != 0 || ((st_ * (int64_t)sizeof(T)) & 15) != 0 ||
+      ((sb * (int64_t)sizeof(T)) & 15) != 0 || rows < 1)
     return false;
-  const int64_t nchunk = (F + CW - 1) / CW, tasks = B * nchunk, cus = num_cus();
-  if (tasks * 2 < cus) return false;  // few long tasks: the 16-wave VGPR kernel
-  // cache policy (top of this file), in tasks = (b, chunk) pairs, b-major like the bytes
+  // lanes per row: the widest chunk that wastes no lane, else the one that wastes least (ties: wider = fewer tasks)
+  const int64_t pr = F / EPP;  // pieces per row
+  int lpr = 64;
+  double best = 0;
+  for (int c : {64, 32, 16}) {
+    const double util = (double)pr / (double)(((pr + c - 1) / c) * c);
+    if (util > best + 1e-9) best = util, lpr = c;
+  }
+  if (forced_lpr == 64 || forced_lpr == 32 || forced_lpr == 16) lpr = forced_lpr;
+  const int64_t cw = (int64_t)lpr * EPP, nchunk = (F + cw - 1) / cw, tasks = B * nchunk, cus = num_cus();
   const int64_t nt_min_bytes = nt_min_bytes_(), tail_bytes = tail_bytes_();
   const int64_t per_b = (int64_t)T_ * F * (int64_t)sizeof(T), all = B * per_b;
   int64_t tail_from = 0;
   if (all >= nt_min_bytes) tail_from = tail_bytes > 0 ? (all > tail_bytes ? (all - tail_bytes) / per_b * nchunk : 0) : INT64_MAX;
-  int nw = (tasks < 2 * cus && rows >= 64) ? 8 : 4;
-  if (forced_nw == 4 || forced_nw == 8) nw = forced_nw;
-  int depth = kColDepthDefault;
-  if (forced_depth >= 2 && forced_depth <= 4) depth = forced_depth;
-#define SL_COLDMA(NW_, D_) launch_colreduce_dma_as<T, OP, NW_, D_>(prof, x, B, T_, F, sb, st_, t0, t1, denom, tail_from, cand, outf, st)
-  if (nw == 8) {
-    if (depth == 2) SL_COLDMA(8, 2);
-    else if (depth == 3) SL_COLDMA(8, 3);
-    else SL_COLDMA(8, 4);
+  // waves per task split the reduced axis; a wave instruction covers 64 / lpr rows, so short axes want few waves
+  const int64_t inst_rows = rows * lpr / 64;  // wave instructions per task
+  // measured (profiles/r04_k2_lab.txt): fp32 (72 registers, 24+ waves per CU) gains 2-5 % from 8 waves up to 4 tasks per CU
+  // ((256, 197, 768): 6.09 -> 6.19 TB/s cold, 5.67 -> 5.96 behind a producer); the half-precision kernels (100 registers, 16
+  // waves per CU) LOSE 15 % with 8 once there are two tasks per CU ((256, 257, 1024) bf16: 6.07 -> 5.15)
+  int nw = 4;
+  if (tasks * 2 < cus && inst_rows >= 128 && lpr == 64) nw = 16;
+  else if (tasks < (sizeof(T) == 4 ? 4 : 1) * cus && inst_rows >= 64) nw = 8;
+  if (forced_nw == 4 || forced_nw == 8 || (forced_nw == 16 && lpr == 64)) nw = forced_nw;
+#define SL_COL2(NW_, LPR_) launch_colreduce2_as<T, OP, NW_, LPR_>(prof, x, B, T_, F, sb, st_, t0, t1, denom, tail_from, cand, outf, st)
+#define SL_COL2_NW(LPR_)                 \
+  do {                                   \
+    if (nw == 16) SL_COL2(16, LPR_);     \
+    else if (nw == 8) SL_COL2(8, LPR_);  \
+    else SL_COL2(4, LPR_);               \
+  } while (0)
+  if (lpr == 64) {
+    SL_COL2_NW(64);
+  } else if (lpr == 32) {
+    if (nw == 8) SL_COL2(8, 32);
+    else SL_COL2(4, 32);
   } else {
-    if (depth == 2) SL_COLDMA(4, 2);
-    else if (depth == 3) SL_COLDMA(4, 3);
-    else SL_COLDMA(4, 4);
+    if (nw == 8) SL_COL2(8, 16);
+    else SL_COL2(4, 16);
   }
-#undef SL_COLDMA
+#undef SL_COL2_NW
+#undef SL_COL2
   return true;
 }
+
+#ifdef SL_K2_DMA_LAB  // lab only (tools/k2_lab.py, profiles/r04_k2_lab.txt): K2 through LDS-DMA rings — measured, lost, not shipped
+#include "../../tools/native/colreduce_dma_lab.hpp"
+#endif
 
 template <typename T, int OP>
 void launch_colreduce(ProfScope& prof, const T* x, int64_t B, int T_, int64_t F, int64_t sb, int64_t st_, int t0, int t1,
                       float denom, uint16_t* cand, float* outf, hipStream_t st) {
+  if (launch_colreduce2<T, OP>(prof, x, B, T_, F, sb, st_, t0, t1, denom, cand, outf, st)) return;
+#ifdef SL_K2_DMA_LAB
   if (launch_colreduce_dma<T, OP>(prof, x, B, T_, F, sb, st_, t0, t1, denom, cand, outf, st)) return;
+#endif
   int64_t blocks = B * ((F + 255) / 256);
   const int64_t cap = (int64_t)num_cus() * 8;
   if (blocks > cap) blocks = cap;
