@@ -293,6 +293,14 @@ int sl_attention_pool(const float* d_q, const float* d_kv, int64_t kv_row_stride
 /* (B,C,Hi,Wi) image -> (B*(Hi/P)*(Wi/P), C*P*P) patch rows, k = c*P*P + py*P + px (Conv2d weight order). */
 int sl_patchify(const float* d_img, int64_t B, int64_t C, int64_t Hi, int64_t Wi, int64_t P, float* d_out,
                 uint16_t* d_out_split, void* stream);
+/* The same pooling with ONE QUERY PER IMAGE: d_q + b * q_batch_stride is image b's projected query (H*head_dim) — the attention
+ * pool of CLIP's ResNet towers (open_clip ModifiedResNet.attnpool behind foundation_models/clip.py:52-62 `OpenClip("RN50", ...)`:
+ * the query is the image's mean token).  q_batch_stride 0 = sl_attention_pool. */
+int sl_attention_pool_q(const float* d_q, int64_t q_batch_stride, const float* d_kv, int64_t kv_row_stride, int64_t v_offset,
+                        int64_t B, int64_t T, int64_t H, int64_t head_dim, float* d_out, void* stream);
+/* Token rows of that pool from the NCHW trunk output: d_map (B,C,S) -> d_out (B, S+1, C) with
+ * out[b][0] = mean_s map[b][:, s] + pos[0], out[b][1+s] = map[b][:, s] + pos[1+s]; d_pos (S+1, C). */
+int sl_tokens_from_map(const float* d_map, int64_t B, int64_t C, int64_t S, const float* d_pos, float* d_out, void* stream);
 /* out[g * group_stride_elems + c] = v[c] + add[c] for g < G (class-token row of every image). */
 int sl_broadcast_row(const float* d_v, const float* d_add, int64_t G, int64_t group_stride_elems, int64_t N, float* d_out,
                      void* stream);

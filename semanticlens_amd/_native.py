@@ -83,6 +83,8 @@ SIGNATURES = {
     "sl_attention_bf16x3": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp]),
     "sl_patchify": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "sl_attention_pool": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "sl_attention_pool_q": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "sl_tokens_from_map": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "sl_split_elems": (_sz, [_i64, _i64]),
     "sl_split_bf16": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "sl_linear_bf16x3": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _int, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
@@ -756,6 +758,32 @@ def attention_pool(q, kv, B, T, H, head_dim, out=None):
     with _on(kv.device):
         rc = lib().sl_attention_pool(_ptr(q), _ptr(kv), kv.stride(0), W, B, T, H, head_dim, _ptr(out), _stream(kv))
     _check(rc, "sl_attention_pool")
+    return out
+
+
+def attention_pool_q(q, kv, B, T, H, head_dim, out=None):
+    """``attention_pool`` with one query per image: ``q`` (B, H*head_dim) -> ``(B, W)`` (CLIP-ResNet attention pool)."""
+    W = H * head_dim
+    _need_f32("attention_pool_q", q, kv, out)
+    if out is None:
+        out = torch.empty((B, W), dtype=torch.float32, device=kv.device)
+    with _on(kv.device):
+        rc = lib().sl_attention_pool_q(_ptr(q), q.stride(0), _ptr(kv), kv.stride(0), W, B, T, H, head_dim, _ptr(out), _stream(kv))
+    _check(rc, "sl_attention_pool_q")
+    return out
+
+
+def tokens_from_map(fmap, pos, out=None):
+    """(B, C, H, W) trunk output + (HW + 1, C) positions -> (B, HW + 1, C) token rows, row 0 = mean token (``sl_tokens_from_map``)."""
+    B, C = fmap.shape[:2]
+    S = fmap[0, 0].numel()
+    fmap = fmap.contiguous()
+    _need_f32("tokens_from_map", fmap, pos, out)
+    if out is None:
+        out = torch.empty((B, S + 1, C), dtype=torch.float32, device=fmap.device)
+    with _on(fmap.device):
+        rc = lib().sl_tokens_from_map(_ptr(fmap), B, C, S, _ptr(pos), _ptr(out), _stream(fmap))
+    _check(rc, "sl_tokens_from_map")
     return out
 
 

@@ -765,14 +765,14 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const float* __restri
 // softmax (running max, sum, weighted V) of its keys, then the 64 partial states are combined.  K / V rows are read once:
 // HBM/L2-bound, B*T*2*W*4 bytes.
 constexpr int kPoolMaxHd = 128;
-__global__ __launch_bounds__(64) void attention_pool_kernel(const float* __restrict__ q, const float* __restrict__ kv, int64_t ld,
-                                                            int64_t voff, int T, int H, int hd, float scale,
+__global__ __launch_bounds__(64) void attention_pool_kernel(const float* __restrict__ q, int64_t q_stride, const float* __restrict__ kv,
+                                                            int64_t ld, int64_t voff, int T, int H, int hd, float scale,
                                                             float* __restrict__ out) {
   __shared__ float s_q[kPoolMaxHd];
   const int lane = threadIdx.x;
   const int64_t b = blockIdx.x / H;
   const int h = (int)(blockIdx.x % H);
-  for (int d = lane; d < hd; d += 64) s_q[d] = q[h * hd + d] * scale;
+  for (int d = lane; d < hd; d += 64) s_q[d] = q[b * q_stride + h * hd + d] * scale;  // q_stride 0: one probe for every image
   __syncthreads();
   float m = -__builtin_huge_valf(), l = 0.f;
   float acc[kPoolMaxHd];
@@ -814,6 +814,33 @@ __global__ __launch_bounds__(64) void attention_pool_kernel(const float* __restr
       for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
       if (lane == 0) out[b * (int64_t)H * hd + h * hd + d] = a * inv;
     }
+  }
+}
+
+// CLIP-ResNet attention pool input (open_clip ModifiedResNet.attnpool, foundation_models/clip.py:52-62 `OpenClip("RN50", ...)`):
+// tokens[b][0][c] = mean_s map[b][c][s] + pos[0][c], tokens[b][1 + s][c] = map[b][c][s] + pos[1 + s][c] — the NCHW trunk output
+// turned into (B, S + 1, C) token rows.  One workgroup per (b, 64-channel block): the (64 x S) tile goes through LDS so that both
+// the reads (s contiguous) and the writes (c contiguous) are coalesced.
+__global__ __launch_bounds__(256) void tokens_from_map_kernel(const float* __restrict__ map, const float* __restrict__ pos, int C, int S,
+                                                              float* __restrict__ out) {
+  extern __shared__ float s_tile[];  // 64 x (S + 1)
+  const int ld = S + 1;
+  const int64_t b = blockIdx.y;
+  const int c0 = blockIdx.x * 64;
+  const int nc = C - c0 < 64 ? C - c0 : 64;
+  const float* src = map + (b * C + c0) * (int64_t)S;
+  for (int i = threadIdx.x; i < nc * S; i += 256) s_tile[(i / S) * ld + (i % S)] = src[i];
+  __syncthreads();
+  if ((int)threadIdx.x < nc) {  // the mean token: fp32 sum in index order, then / S (torch: x.mean(dim=0))
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += s_tile[threadIdx.x * ld + s];
+    s_tile[threadIdx.x * ld + S] = acc / (float)S;
+  }
+  __syncthreads();
+  float* dst = out + b * (int64_t)(S + 1) * C + c0;
+  for (int i = threadIdx.x; i < 64 * (S + 1); i += 256) {
+    const int t = i / 64, c = i % 64;  // t = 0: mean token
+    if (c < nc) dst[(int64_t)t * C + c] = s_tile[c * ld + (t == 0 ? S : t - 1)] + pos[(int64_t)t * C + c0 + c];
   }
 }
 
@@ -970,17 +997,42 @@ SL_API int sl_attention_bf16x3(const float* d_qkv, int64_t B, int64_t T, int64_t
   SL_REQUIRE(false, "sl_attention_bf16x3: head_dim=%lld (built: 32, 64, 72, 80, 88, 96, 104, 128)", (long long)head_dim);
 }
 
-SL_API int sl_attention_pool(const float* d_q, const float* d_kv, int64_t kv_row_stride, int64_t v_offset, int64_t B, int64_t T,
-                             int64_t H, int64_t head_dim, float* d_out, void* stream) {
-  SL_REQUIRE(B >= 0 && T >= 1 && H >= 1 && T < (1ll << 31), "sl_attention_pool: bad shape");
-  SL_REQUIRE(head_dim >= 4 && head_dim <= kPoolMaxHd && head_dim % 4 == 0, "sl_attention_pool: head_dim=%lld not a multiple of 4 up to %d",
+static int attention_pool_impl(const char* fn, const float* d_q, int64_t q_batch_stride, const float* d_kv, int64_t kv_row_stride,
+                               int64_t v_offset, int64_t B, int64_t T, int64_t H, int64_t head_dim, float* d_out, void* stream) {
+  SL_REQUIRE(B >= 0 && T >= 1 && H >= 1, "%s: bad shape", fn);
+  SL_REQUIRE(head_dim >= 4 && head_dim <= kPoolMaxHd && head_dim % 4 == 0, "%s: head_dim=%lld not a multiple of 4 up to %d", fn,
              (long long)head_dim, kPoolMaxHd);
   if (B == 0) return 0;
-  SL_REQUIRE(d_q && d_kv && d_out, "sl_attention_pool: null pointer");
-  SL_REQUIRE(kv_row_stride % 4 == 0 && v_offset % 4 == 0 && (((uintptr_t)d_kv) & 15) == 0, "sl_attention_pool: rows must be 16-byte aligned");
-  SL_REQUIRE(B * H < (1ll << 31), "sl_attention_pool: too many heads");
-  hipLaunchKernelGGL(attention_pool_kernel, dim3((unsigned)(B * H)), dim3(64), 0, (hipStream_t)stream, d_q, d_kv, kv_row_stride, v_offset,
-                     (int)T, (int)H, (int)head_dim, 1.f / sqrtf((float)head_dim), d_out);
+  SL_REQUIRE(d_q && d_kv && d_out, "%s: null pointer", fn);
+  SL_REQUIRE(kv_row_stride % 4 == 0 && v_offset % 4 == 0 && (((uintptr_t)d_kv) & 15) == 0, "%s: rows must be 16-byte aligned", fn);
+  SL_REQUIRE(B * H < (1ll << 31) && q_batch_stride >= 0, "%s: too many heads", fn);
+  hipLaunchKernelGGL(attention_pool_kernel, dim3((unsigned)(B * H)), dim3(64), 0, (hipStream_t)stream, d_q, q_batch_stride, d_kv,
+                     kv_row_stride, v_offset, (int)T, (int)H, (int)head_dim, 1.f / sqrtf((float)head_dim), d_out);
+  SL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+SL_API int sl_attention_pool(const float* d_q, const float* d_kv, int64_t kv_row_stride, int64_t v_offset, int64_t B, int64_t T,
+                             int64_t H, int64_t head_dim, float* d_out, void* stream) {
+  return attention_pool_impl("sl_attention_pool", d_q, 0, d_kv, kv_row_stride, v_offset, B, T, H, head_dim, d_out, stream);
+}
+
+SL_API int sl_attention_pool_q(const float* d_q, int64_t q_batch_stride, const float* d_kv, int64_t kv_row_stride, int64_t v_offset,
+                               int64_t B, int64_t T, int64_t H, int64_t head_dim, float* d_out, void* stream) {
+  return attention_pool_impl("sl_attention_pool_q", d_q, q_batch_stride, d_kv, kv_row_stride, v_offset, B, T, H, head_dim, d_out,
+                             stream);
+}
+
+SL_API int sl_tokens_from_map(const float* d_map, int64_t B, int64_t C, int64_t S, const float* d_pos, float* d_out, void* stream) {
+  SL_REQUIRE(B >= 0 && C >= 1 && S >= 1, "sl_tokens_from_map: bad shape");
+  if (B == 0) return 0;
+  SL_REQUIRE(d_map && d_pos && d_out, "sl_tokens_from_map: null pointer");
+  SL_REQUIRE(B < 65536 && S <= 1024, "sl_tokens_from_map: B=%lld S=%lld (limits 65535 / 1024)", (long long)B, (long long)S);
+  const size_t lds = (size_t)64 * (S + 1) * sizeof(float);
+  if (lds > 64 * 1024)
+    SL_CHECK_HIP(hipFuncSetAttribute((const void*)tokens_from_map_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(tokens_from_map_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)B), dim3(256), lds, (hipStream_t)stream, d_map, d_pos,
+                     (int)C, (int)S, d_out);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -21,6 +21,11 @@ Module layouts read (probed by attribute; anything else is refused with a ``Type
   ``transformer``, ``ln_final``, ``text_projection`` (matrix or ``nn.Linear``), ``attn_mask``, ``text_pool_type`` in
   {``argmax``, ``first``, ``last``}.  LayerScale (``ls_1`` / ``ls_2`` with a ``gamma``) is folded into the weights of
   the projection it follows.  Attention pooling (CoCa) and hybrid / convolutional towers (MobileCLIP) are refused.
+* **open_clip ``CLIP`` with a ResNet image tower** (``OpenClip("RN50", ...)`` — BASELINE configs[0]'s embed model; RN101, RN50x4 ...):
+  ``visual`` = ``ModifiedResNet`` {three-conv stem, ``layer1..4``, ``attnpool`` = ``AttentionPool2d`` {``positional_embedding``,
+  ``q_proj``, ``k_proj``, ``v_proj``, ``c_proj``, ``num_heads``}}.  The convolutional trunk stays on PyTorch (MIOpen), like a probed
+  model's forward; the attention pool and the projection to the joint space run on the kernels (``NativeResNetVision``:
+  ``sl_tokens_from_map``, two GEMMs, ``sl_attention_pool_q``, ``c_proj``); the text tower natively as above.
 * **open_clip ``CustomTextCLIP`` with a timm trunk** (what ``SigLipV2()`` builds, clip.py:190-211,
   ``hf-hub:timm/ViT-B-16-SigLIP2``): ``visual`` = ``TimmModel`` {``trunk`` = timm ``VisionTransformer`` with
   ``patch_embed.proj`` (bias), ``pos_embed``, no class token, ``blocks[i]`` {``norm1``, ``attn.qkv`` / ``attn.proj``,
@@ -31,7 +36,7 @@ Module layouts read (probed by attribute; anything else is refused with a ``Type
   ``NativeSigLip``.
 * ``synth.SyntheticClip`` (the bench's random-init ViT-B/32).
 
-head_dim 32-128 in steps of 8.  open_clip / timm are not installed in this image, so the open_clip layouts are exercised
+head_dim 32, 64, 72, 80, 88, 96, 104 or 128 in the towers (any multiple of 4 up to 128 in the pooling heads).  open_clip / timm are not installed in this image, so the open_clip layouts are exercised
 against ``tests/openclip_like.py`` — torch modules carrying open_clip 3.0's attribute tree — and parity for this row
 stays build-vs-torch-module (the reference's own tests pin shapes only, tests/foundation_models/test_clip.py:32-85).
 """
@@ -301,6 +306,64 @@ def _in_chunks(fn, batch: torch.Tensor, rows_per_sample: int, min_rows: int = 40
     return torch.cat(outs)
 
 
+class NativeResNetVision:
+    """CLIP's ResNet image towers (open_clip ``ModifiedResNet``: ``OpenClip("RN50", ...)``, BASELINE configs[0]'s embed model).
+    The convolutional trunk (stem + ``layer1..4``: the user's torch modules, MIOpen) stays on PyTorch like any probed model's
+    forward; what follows it runs on the package's kernels: the NCHW map becomes ``(B, HW + 1, C)`` token rows with the mean
+    token in front (``sl_tokens_from_map``, positions added), ONE GEMM projects every token to ``[k | v]`` and one the mean
+    tokens to the queries, ``sl_attention_pool_q`` attends with one query per image and head, and ``c_proj`` maps to the
+    joint space.  Same arithmetic as ``attnpool.forward`` (multi_head_attention_forward with separate projection weights)."""
+
+    def __init__(self, visual: nn.Module, device, split: bool):
+        pool = visual.attnpool
+        for name in ("positional_embedding", "q_proj", "k_proj", "v_proj", "c_proj", "num_heads"):
+            if not hasattr(pool, name):
+                raise TypeError(f"visual.attnpool has no `{name}`: not open_clip's AttentionPool2d")
+        self.visual = visual
+        W = pool.q_proj.in_features
+        self.heads, self.width = int(pool.num_heads), W
+        self.head_dim = W // self.heads
+        if self.head_dim * self.heads != W or self.head_dim % 4 or self.head_dim > 128:
+            raise ValueError(f"attention pool: head_dim {self.head_dim} (a multiple of 4 up to 128)")
+        self.pos = _f32(pool.positional_embedding, device)  # (HW + 1, W)
+        self.w_kv = torch.cat([_f32(pool.k_proj.weight, device), _f32(pool.v_proj.weight, device)]).contiguous()  # (2W, W): rows [k | v]
+        self.b_kv = torch.cat([_bias(pool.k_proj, device), _bias(pool.v_proj, device)]).contiguous()
+        self.w_q, self.b_q = _f32(pool.q_proj.weight, device), _bias(pool.q_proj, device)
+        self.w_c, self.b_c = _f32(pool.c_proj.weight, device), _bias(pool.c_proj, device)
+        self.split = split
+        if split:
+            self.s_kv, self.s_q, self.s_c = N.Split.of(self.w_kv), N.Split.of(self.w_q), N.Split.of(self.w_c)
+
+    def _linear(self, x, w, sw, b):
+        if self.split:
+            return N.linear3(N.Split.of(x), sw, b)
+        return N.linear(x, w, b)
+
+    def trunk(self, img: torch.Tensor) -> torch.Tensor:
+        """``(B, C, h, w)`` output of ``layer4`` — the model's own forward with the attention pool taken out."""
+        v = self.visual
+        pool, v.attnpool = v.attnpool, nn.Identity()
+        try:
+            return v(img)
+        finally:
+            v.attnpool = pool
+
+    @torch.no_grad()
+    def __call__(self, img: torch.Tensor) -> torch.Tensor:
+        img = N.to_device(img).to(next(self.visual.parameters()).dtype)
+        fmap = self.trunk(img).to(torch.float32).contiguous()
+        B, C = fmap.shape[:2]
+        T = fmap[0, 0].numel() + 1
+        if C != self.width or T != self.pos.shape[0]:
+            raise ValueError(f"trunk output {tuple(fmap.shape)} does not match the attention pool ({self.pos.shape[0] - 1} positions of width {self.width})")
+        tokens = N.tokens_from_map(fmap, self.pos)  # (B, T, W), row 0 = mean token
+        rows = tokens.reshape(B * T, C)
+        kv = self._linear(rows, self.w_kv, getattr(self, "s_kv", None), self.b_kv)  # (B*T, 2W)
+        q = self._linear(tokens[:, 0].contiguous(), self.w_q, getattr(self, "s_q", None), self.b_q)  # (B, W)
+        pooled = N.attention_pool_q(q, kv, B, T, self.heads, self.head_dim)
+        return self._linear(pooled, self.w_c, getattr(self, "s_c", None), self.b_c)
+
+
 class NativeVisionTower:
     """open_clip ``VisionTransformer`` forward (class token + learned positions, pre-LN blocks) on the kernels.  ``pool``:
     ``"tok"`` (class token) or ``"avg"`` (mean of the patch tokens); ``ln_after_pool`` = open_clip's ``final_ln_after_pool``;
@@ -470,7 +533,19 @@ class NativeClip(AbstractVLM):
         self._device = dev
         base.to(dev)
         visual = getattr(model, "visual", None)
-        if visual is not None and hasattr(visual, "conv1") and hasattr(visual, "transformer"):
+        if visual is not None and hasattr(visual, "attnpool") and hasattr(visual, "layer4"):
+            # CLIP ResNet (open_clip ModifiedResNet): conv trunk on PyTorch, attention pool + projection on the kernels;
+            # the text tower in open_clip's layout (members on the model) or synth's (`model.text.blocks`)
+            self.vision = NativeResNetVision(visual, dev, split)
+            if hasattr(model, "transformer") and hasattr(model.transformer, "resblocks"):
+                pool = getattr(model, "text_pool_type", "argmax")
+                self.text = NativeTextTower(model, model.transformer.resblocks, dev, split, pool=pool,
+                                            causal=getattr(model, "attn_mask", None) is not None)
+            elif hasattr(getattr(model, "text", None), "blocks"):
+                self.text = NativeTextTower(model, model.text.blocks, dev, split)
+            else:
+                raise TypeError("NativeClip: CLIP-ResNet image tower with a text tower that is neither open_clip's nor synth's layout")
+        elif visual is not None and hasattr(visual, "conv1") and hasattr(visual, "transformer"):
             # open_clip CLIP: `visual` is the whole image tower, the text tower's members sit on the model itself
             # (CustomTextCLIP keeps them under `.text`)
             _require_clip_layout(model)

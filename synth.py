@@ -453,3 +453,129 @@ def convnext_l(seed: int = 0, layer_scale: float = 1.0, **arch) -> nn.Module:
     m = ConvNeXt(layer_scale=layer_scale, **arch).eval()
     m.name = "convnext-l-random"
     return m
+
+
+# ------------------------------------------------------------------------------------------------
+# CLIP-ResNet image tower (BASELINE configs[0] names "OpenClip RN50 embed"): the attribute tree open_clip's
+# `ModifiedResNet` exposes (three-conv stem, anti-aliased bottlenecks, attention pool), random init
+# ------------------------------------------------------------------------------------------------
+class ClipBottleneck(nn.Module):
+    """Bottleneck of CLIP's ResNets: strides are average pools (after conv2 and in front of the downsample conv)."""
+
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.act1 = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.act2 = nn.ReLU(inplace=True)
+        self.avgpool = nn.AvgPool2d(stride) if stride > 1 else nn.Identity()
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.act3 = nn.ReLU(inplace=True)
+        self.downsample = None
+        if stride > 1 or inplanes != planes * 4:
+            from collections import OrderedDict
+
+            self.downsample = nn.Sequential(OrderedDict([("-1", nn.AvgPool2d(stride)), ("0", nn.Conv2d(inplanes, planes * 4, 1, bias=False)),
+                                                         ("1", nn.BatchNorm2d(planes * 4))]))
+
+    def forward(self, x):
+        out = self.act1(self.bn1(self.conv1(x)))
+        out = self.avgpool(self.act2(self.bn2(self.conv2(out))))
+        out = self.bn3(self.conv3(out))
+        return self.act3(out + (x if self.downsample is None else self.downsample(x)))
+
+
+class AttentionPool2d(nn.Module):
+    """CLIP's attention pool: the mean token (plus its position) queries all HW + 1 tokens; `c_proj` maps to the joint space."""
+
+    def __init__(self, spacial_dim: int, embed_dim: int, num_heads: int, output_dim: int):
+        super().__init__()
+        self.positional_embedding = nn.Parameter(torch.randn(spacial_dim**2 + 1, embed_dim) / embed_dim**0.5)
+        self.k_proj = nn.Linear(embed_dim, embed_dim)
+        self.q_proj = nn.Linear(embed_dim, embed_dim)
+        self.v_proj = nn.Linear(embed_dim, embed_dim)
+        self.c_proj = nn.Linear(embed_dim, output_dim)
+        self.num_heads = num_heads
+
+    def forward(self, x):
+        x = x.reshape(x.shape[0], x.shape[1], x.shape[2] * x.shape[3]).permute(2, 0, 1)  # NCHW -> (HW)NC
+        x = torch.cat([x.mean(dim=0, keepdim=True), x], dim=0)
+        x = x + self.positional_embedding[:, None, :].to(x.dtype)
+        x, _ = nn.functional.multi_head_attention_forward(
+            query=x[:1], key=x, value=x, embed_dim_to_check=x.shape[-1], num_heads=self.num_heads, q_proj_weight=self.q_proj.weight,
+            k_proj_weight=self.k_proj.weight, v_proj_weight=self.v_proj.weight, in_proj_weight=None,
+            in_proj_bias=torch.cat([self.q_proj.bias, self.k_proj.bias, self.v_proj.bias]), bias_k=None, bias_v=None, add_zero_attn=False,
+            dropout_p=0.0, out_proj_weight=self.c_proj.weight, out_proj_bias=self.c_proj.bias, use_separate_proj_weight=True,
+            training=False, need_weights=False)
+        return x[0]
+
+
+class ModifiedResNet(nn.Module):
+    """CLIP RN50 by default: layers (3, 4, 6, 3), width 64 -> 2048 channels at 7 x 7, 32 heads of 64, 1024-d output."""
+
+    def __init__(self, layers=(3, 4, 6, 3), output_dim=1024, heads=32, image_size=224, width=64):
+        super().__init__()
+        self.output_dim, self.image_size = output_dim, image_size
+        self.conv1 = nn.Conv2d(3, width // 2, 3, stride=2, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width // 2)
+        self.act1 = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(width // 2, width // 2, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(width // 2)
+        self.act2 = nn.ReLU(inplace=True)
+        self.conv3 = nn.Conv2d(width // 2, width, 3, padding=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(width)
+        self.act3 = nn.ReLU(inplace=True)
+        self.avgpool = nn.AvgPool2d(2)
+        self._inplanes = width
+        self.layer1 = self._make_layer(width, layers[0])
+        self.layer2 = self._make_layer(width * 2, layers[1], stride=2)
+        self.layer3 = self._make_layer(width * 4, layers[2], stride=2)
+        self.layer4 = self._make_layer(width * 8, layers[3], stride=2)
+        self.attnpool = AttentionPool2d(image_size // 32, width * 32, heads, output_dim)
+
+    def _make_layer(self, planes, blocks, stride=1):
+        out = [ClipBottleneck(self._inplanes, planes, stride)]
+        self._inplanes = planes * 4
+        out += [ClipBottleneck(self._inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*out)
+
+    def stem(self, x):
+        x = self.act1(self.bn1(self.conv1(x)))
+        x = self.act2(self.bn2(self.conv2(x)))
+        x = self.act3(self.bn3(self.conv3(x)))
+        return self.avgpool(x)
+
+    def forward(self, x):
+        x = self.layer4(self.layer3(self.layer2(self.layer1(self.stem(x)))))
+        return self.attnpool(x)
+
+
+class _ClipRN50Model(_ClipModel):
+    """RN50-CLIP: `visual` is the ModifiedResNet (the whole image tower), the text tower as in `_ClipModel` (12 x 512, ctx 77)."""
+
+    def __init__(self, embed_dim=1024, image_size=224, layers=(3, 4, 6, 3), width=64, **text_arch):
+        super().__init__(embed_dim=embed_dim, image_size=image_size, patch=32, v_width=64, v_layers=0, v_heads=1, **text_arch)
+        for name in ("conv1", "class_embedding", "positional_embedding_v", "ln_pre", "ln_post", "proj_v"):
+            delattr(self, name)
+        self.visual = ModifiedResNet(layers, embed_dim, width * 32 // 64, image_size, width)
+        for m in self.visual.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def encode_image(self, img):
+        return self.visual(img)
+
+
+class SyntheticClipRN50(SyntheticClip):
+    """Random-init CLIP RN50 behind the ``AbstractVLM`` seam (what ``OpenClip("RN50", ...)`` would be without weights):
+    ModifiedResNet image tower (38 M parameters, 2048 x 7 x 7 -> attention pool -> 1024), 12 x 512 text tower, 1024-d joint space."""
+
+    def __init__(self, device="cpu", seed: int = 1, embed_dim: int = 1024, **arch):
+        torch.manual_seed(seed)
+        self.model = _ClipRN50Model(embed_dim=embed_dim, **arch).eval().to(device)
+        self.name = f"synthetic-clip-rn50-d{embed_dim}"

@@ -89,17 +89,24 @@ def test_configs1_concept_db_matches_oracle(world, tie_mode, single_pass):
         assert (ids >= 0).mean() > 0.9
 
 
-def test_configs1_native_embeddings_within_tolerance_of_the_torch_module(world):
-    """north_star: embedding values within 1e-4 (fp32) — NativeClip (split-bf16 x3 and fp32-MFMA GEMMs) vs the torch ViT-B/32."""
+def test_configs1_native_embeddings_within_tolerance_of_float64(world):
+    """north_star: embedding values within 1e-4 (fp32).  NativeClip (split-bf16 x3 and fp32-MFMA GEMMs) against the SAME weights
+    run in float64 on the device, absolute bar on the un-normalised ViT-B/32 features of a full 256-image batch (VERDICT r03 #8:
+    the round-3 test compared with the fp32 torch module, relative to the feature scale)."""
+    import copy
+
     model, base, DS = world
     ds = DS("fm")
     u8 = torch.stack([ds[i] for i in range(BATCH)]).to(DEV)
     x = base.preprocess(u8)
-    want = base.encode_image(x)
-    scale = want.abs().max().item()
+    with torch.no_grad():
+        want = copy.deepcopy(base.model).double().encode_image(x.double())
     for gemm in ("bf16x3", "f32"):
         got = NativeClip(base, gemm=gemm).encode_image(x)
-        assert (got - want).abs().max().item() < 1e-4 * scale, gemm
+        worst = (got.double() - want).abs().max().item()
+        assert worst < 1e-4, (gemm, worst, want.abs().max().item())
+        cos = torch.nn.functional.cosine_similarity(got.double(), want, dim=-1)
+        assert (1 - cos).abs().max().item() < 1e-9, gemm
 
 
 def test_small_loader_batches_are_embedded_in_large_ones_with_the_same_bits(world):

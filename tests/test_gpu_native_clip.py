@@ -324,3 +324,114 @@ def test_half_batches_on_two_streams_keep_every_bit(monkeypatch):
     three = nc._in_chunks(nat.vision._encode, x, nat.vision.chunk_rows(x), min_rows=0)
     assert torch.equal(one, three)
     assert torch.equal(nat.encode_image(x[:5]), one[:5])  # small batches: one call on the current stream
+
+
+# ---- the comparison object is FLOAT64, the bar is ABSOLUTE ---------------------------------------------------
+# north_star: "cosine/embedding values within 1e-4 fp32".  The towers above are checked against fp32 torch modules with a
+# relative bar (a smoke bar: both sides carry fp32 rounding); here the same weights run in float64 on the device and the
+# native features must sit within 1e-4 ABSOLUTE of them un-normalised, and the image-text cosines within 1e-5.
+def _fp64_features(fm, x, toks):
+    import copy
+
+    ref = copy.deepcopy(fm.model).double()
+    with torch.no_grad():
+        if hasattr(ref, "vision_model"):  # transformers' SiglipModel
+            return ref.vision_model(pixel_values=x.double()).pooler_output, ref.text_model(input_ids=toks).pooler_output
+        return ref.encode_image(x.double()), ref.encode_text(toks)
+
+
+def _assert_within_fp64(got_i, got_t, want_i, want_t, tag):
+    d_i = (got_i.double() - want_i).abs().max().item()
+    d_t = (got_t.double() - want_t).abs().max().item()
+    assert d_i < 1e-4 and d_t < 1e-4, (tag, d_i, d_t, want_i.abs().max().item(), want_t.abs().max().item())
+    cos = torch.nn.functional.normalize(got_i.double(), dim=-1) @ torch.nn.functional.normalize(got_t.double(), dim=-1).T
+    cos64 = torch.nn.functional.normalize(want_i, dim=-1) @ torch.nn.functional.normalize(want_t, dim=-1).T
+    d_c = (cos - cos64).abs().max().item()
+    assert d_c < 1e-5, (tag, d_c)
+    return d_i, d_t, d_c
+
+
+@pytest.mark.parametrize("gemm", ["bf16x3", "f32"])
+def test_vit_b32_towers_within_1e4_absolute_of_float64(gemm):
+    """CLIP ViT-B/32 geometry (12 x 768 image tower, 12 x 512 text tower, 512-d joint space), both GEMM modes."""
+    fm = synth.SyntheticClip(device=DEV, seed=3)
+    x = fm.preprocess(synth.synth_images_u8(torch.arange(16, device=DEV)))
+    toks = fm.tokenize(["a photo of a cat", "dog", "a very long prompt with many many words in it " * 3, "two red wheels on wet grass",
+                        "sky", "x", "a striped zebra near the river bank at dawn", "metal text on a wooden face"])
+    want_i, want_t = _fp64_features(fm, x, toks)
+    nat = NativeClip(fm, gemm=gemm)
+    _assert_within_fp64(nat.encode_image(x), nat.encode_text(toks), want_i, want_t, gemm)
+    # the torch fp32 module itself sits at the same distance from float64 (what "fp32-class accuracy" means)
+    d_torch = (fm.encode_image(x).double() - want_i).abs().max().item()
+    assert d_torch < 1e-4
+
+
+@pytest.mark.parametrize("gemm", ["bf16x3", "f32"])
+def test_so400m_towers_within_1e4_absolute_of_float64(gemm):
+    """SigLIP-so400m geometry at full depth (27 x 1152, 16 heads of 72, MLP 4304, patch 14 -> 256 tokens, ctx 64):
+    BASELINE configs[3]'s embed model, transformers' `SiglipModel` with random weights in float64 as the reference."""
+    from semanticlens_amd.foundation_models import NativeSigLip
+
+    fm = synth.SyntheticSigLip(device=DEV)
+    x = fm.preprocess(synth.synth_images_u8(torch.arange(4, device=DEV)))
+    toks = fm.tokenize(["a photo of a cat", "dog", "a striped zebra near the river bank at dawn", "metal text on a wooden face"])
+    want_i, want_t = _fp64_features(fm, x, toks)
+    nat = NativeSigLip(fm, gemm=gemm)
+    _assert_within_fp64(nat.encode_image(x), nat.encode_text(toks), want_i, want_t, gemm)
+
+
+# ---- CLIP-ResNet (open_clip ModifiedResNet: `OpenClip("RN50", ...)`, BASELINE configs[0]'s embed model) ------------------------
+def test_tokens_from_map_and_per_image_query_pool_primitives():
+    g = torch.Generator(device=DEV).manual_seed(11)
+    for B, C, S in ((3, 2048, 49), (2, 100, 7), (1, 64, 196), (5, 192, 1)):
+        fmap = torch.randn(B, C, S, device=DEV, generator=g)
+        pos = torch.randn(S + 1, C, device=DEV, generator=g)
+        got = N.tokens_from_map(fmap.reshape(B, C, S, 1), pos)
+        x = fmap.permute(0, 2, 1)
+        want = torch.cat([x.mean(1, keepdim=True), x], 1) + pos
+        assert got.shape == (B, S + 1, C) and torch.allclose(got, want, rtol=0, atol=2e-6), (B, C, S)
+        assert torch.equal(got[:, 1:], want[:, 1:])  # the plain tokens are one add: exact
+    B, T, H, hd = 4, 50, 32, 64
+    W = H * hd
+    kv = torch.randn(B * T, 2 * W, device=DEV, generator=g)
+    q = torch.randn(B, W, device=DEV, generator=g)
+    got = N.attention_pool_q(q, kv, B, T, H, hd)
+    k = kv[:, :W].reshape(B, T, H, hd).permute(0, 2, 1, 3).double()
+    v = kv[:, W:].reshape(B, T, H, hd).permute(0, 2, 1, 3).double()
+    p = torch.softmax((q.reshape(B, H, 1, hd).double() @ k.transpose(-1, -2)) / hd**0.5, -1)
+    want = (p @ v).reshape(B, W)
+    assert (got.double() - want).abs().max().item() < 1e-5
+    # stride 0 = one probe for every image (what sl_attention_pool has always done)
+    assert torch.equal(N.attention_pool(q[0].contiguous(), kv, B, T, H, hd), N.attention_pool_q(q[:1].expand(B, W), kv, B, T, H, hd))
+
+
+@pytest.mark.parametrize("gemm", ["bf16x3", "f32"])
+def test_clip_rn50_attention_pool_head_on_the_kernels(gemm):
+    """RN50-CLIP: the conv trunk on PyTorch, attention pool + `c_proj` + the whole text tower on the kernels; features within
+    1e-4 absolute of the same weights in float64 (the trunk's fp32 convolutions included in that distance)."""
+    fm = synth.SyntheticClipRN50(device=DEV, seed=4)
+    nat = NativeClip(fm, gemm=gemm)
+    from semanticlens_amd.foundation_models.native_clip import NativeResNetVision
+
+    assert isinstance(nat.vision, NativeResNetVision) and nat.vision.heads == 32 and nat.vision.head_dim == 64
+    x = fm.preprocess(synth.synth_images_u8(torch.arange(8, device=DEV)))
+    toks = fm.tokenize(["a photo of a cat", "dog", "two red wheels on wet grass", "sky"])
+    got_i, got_t = nat.encode_image(x), nat.encode_text(toks)
+    assert got_i.shape == (8, 1024) and got_t.shape == (4, 1024)
+    want_i32 = fm.encode_image(x)
+    assert rel_err(got_i, want_i32) < 1e-4
+    # the head alone, on the trunk's own output, against float64
+    fmap = nat.vision.trunk(x)
+    assert fmap.shape == (8, 2048, 7, 7) and fm.model.visual.attnpool is not None and not isinstance(fm.model.visual.attnpool, torch.nn.Identity)
+    import copy
+
+    pool64 = copy.deepcopy(fm.model.visual.attnpool).double()
+    with torch.no_grad():
+        want_head = pool64(fmap.double())
+    d = (got_i.double() - want_head).abs().max().item()
+    assert d < 1e-4, (gemm, d, want_head.abs().max().item())
+    want_i, want_t = _fp64_features(fm, x, toks)
+    assert (got_t.double() - want_t).abs().max().item() < 1e-4
+    cos = torch.nn.functional.normalize(got_i.double(), dim=-1) @ torch.nn.functional.normalize(got_t.double(), dim=-1).T
+    cos64 = torch.nn.functional.normalize(want_i, dim=-1) @ torch.nn.functional.normalize(want_t, dim=-1).T
+    assert (cos - cos64).abs().max().item() < 1e-4  # the fp32 conv trunk (38 M parameters, 53 layers) is inside this one

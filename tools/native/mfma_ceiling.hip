@@ -1,0 +1,98 @@
+// What the bf16 matrix pipe sustains on this part with NOTHING to feed it: v_mfma_f32_32x32x16_bf16 from registers only
+// (no LDS, no global memory), one wave per SIMD (or two), on random and on all-zero operands, looping for seconds so that
+// the package settles at its power limit.  The split-bf16 x3 cosine GEMM issues 3 MFMAs per algorithmic product, so its
+// bound on THIS box is (issued PFLOP/s here) / 3 — the ceiling VERDICT r03 #9 asks to pin the 0.51-0.54 of 833 TFLOP/s against.
+//   mfma_ceiling [seconds per case]          build: hipcc --offload-arch=gfx950 -O3 mfma_ceiling.hip -o mfma_ceiling
+// Shader clock per workgroup: s_memtime (shader cycles) against s_memrealtime (100 MHz).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+// NACC independent accumulator tiles per wave (a 32x32x16 MFMA has 16 passes = 64 cycles of latency... 4-8 in flight cover it)
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_loop(const uint4* __restrict__ src, int iters, float* __restrict__ sink,
+                                                 unsigned long long* __restrict__ stamps) {
+  const int lane = threadIdx.x;
+  bf16x8 a[NACC], b[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    const uint4 va = src[(lane + 64 * i) & 4095], vb = src[(lane * 7 + 13 * i + 1) & 4095];
+    a[i] = __builtin_bit_cast(bf16x8, va);
+    b[i] = __builtin_bit_cast(bf16x8, vb);
+  }
+  floatx16 acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[(i + r) % NACC], acc[i], 0, 0, 0);
+  }
+  const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += acc[i][j];
+  if (s == 1234.5f) sink[0] = s;
+  if (threadIdx.x == 0) {
+    stamps[2 * (blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64)] = c1 - c0;
+    stamps[2 * (blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64) + 1] = r1 - r0;
+  }
+}
+
+int main(int argc, char** argv) {
+  const double secs = argc > 1 ? atof(argv[1]) : 4.0;
+  int cus = 256;
+  CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+  uint4* src; float* sink; unsigned long long* stamps;
+  CK(hipMalloc(&src, 4096 * 16)); CK(hipMalloc(&sink, 64)); CK(hipMalloc(&stamps, 16 * 8192));
+  std::vector<uint16_t> h(4096 * 8);
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  printf("# %d CUs; per case: seconds of back-to-back launches; issued TFLOP/s = MFMAs x 2*32*32*16 / time\n", cus);
+  for (int waves_per_simd = 1; waves_per_simd <= 2; ++waves_per_simd)
+    for (int zero = 0; zero < 2; ++zero) {
+      srand(1);
+      // random: normal-ish bf16 values around 1 with random signs and mantissas (what normalised embeddings' hi/lo halves look like)
+      for (auto& v : h) v = zero ? 0 : (uint16_t)(0x3c00 + (rand() & 0x3ff) + ((rand() & 1) << 15) - ((rand() & 3) << 7));
+      CK(hipMemcpy(src, h.data(), 4096 * 16, hipMemcpyHostToDevice));
+      const int iters = 4000, nacc = 4;
+      const int blocks = cus * waves_per_simd;  // 256 threads = 4 waves = one per SIMD
+      double t_total = 0, mfmas = 0;
+      int launches = 0;
+      CK(hipEventRecord(e0, nullptr));
+      while (true) {
+        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(mfma_loop<4>, dim3(blocks), dim3(256), 0, nullptr, src, iters, sink, stamps);
+        launches += 20;
+        CK(hipEventRecord(e1, nullptr));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        t_total = ms * 1e-3;
+        if (t_total >= secs) break;
+      }
+      mfmas = (double)launches * blocks * 4 /*waves*/ * iters * 4 * nacc;
+      std::vector<unsigned long long> hs(2 * blocks * 4);
+      CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
+      double cyc = 0, rt = 0;
+      for (size_t i = 0; i < hs.size() / 2; ++i) { cyc += (double)hs[2 * i]; rt += (double)hs[2 * i + 1]; }
+      const double ghz = cyc / (rt / 100e6) / 1e9;
+      const double tflops = mfmas * 2.0 * 32 * 32 * 16 / t_total / 1e12;
+      // matrix pipe: a 32x32x16 bf16 MFMA occupies the pipe 8 passes x 4 cycles = 32 cycles? measured instead:
+      const double cyc_per_mfma = (cyc / (hs.size() / 2)) / ((double)iters * 4 * nacc * waves_per_simd);
+      printf("%d wave(s)/SIMD  %-6s operands: %7.1f TFLOP/s issued (= %6.1f algorithmic for split-bf16 x3, %4.2f of 833)  sclk %.3f GHz  %.1f cycles/MFMA/SIMD  %.1f s\n",
+             waves_per_simd, zero ? "zero" : "random", tflops, tflops / 3, tflops / 3 / 833.3, ghz, cyc_per_mfma, t_total);
+      fflush(stdout);
+    }
+  return 0;
+}
