@@ -562,7 +562,7 @@ def config3_leg(dev, args):
     db = {}
     out = collect_leg(
         dev, fm, args, vit, layers, aggregators.aggregate_transformer_max,
-        "colreduce (K2, (B, 197, 768) token activations, component axis contiguous)",
+        "colreduce2 (K2, (B, 197, 768) token activations, component axis contiguous)",
         "BASELINE configs[3], full geometry: ViT-B/16 (random init) probed model, all 12 encoder blocks (B,197,768) fp32, "
         "aggregate_transformer_max, 7 262 208 B/image; embed = NativeSigLip at the SigLIP-so400m geometry (27 x 1152, 16 heads "
         "of 72, MLP 4304, patch 14 -> 256 tokens, D = 1152), on the same stream", steps=4, B=B, check_n=B, overlap=False, keep_db=db)
@@ -616,9 +616,11 @@ def config4_leg(dev, fm, args):
     db = {}
     out = collect_leg(
         dev, fm, args, model, layers, aggregators.aggregate_conv_max,
-        "rowreduce (K1, NCHW fp32 stage outputs, S = 3136 / 784 / 196 / 49)",
+        "colreduce2 (K1, channels_last fp32 stage outputs: (B, S, C) with S = 3136 / 784 / 196 / 49, C = 192 / 384 / 768 / 1536)",
         "BASELINE configs[4] collect stage: ConvNeXt-L (random init) probed model, stages.0-3 outputs fp32 NCHW, aggregate_conv_max, "
-        "4 515 840 B/image; embed = the headline's CLIP ViT-B/32", steps=4, B=B, check_n=B, keep_db=db)
+        "4 515 840 B/image (the stage outputs arrive channels_last — the residual add takes its permuted branch's layout — so K1 "
+        "runs its component-contiguous kernel); embed = the headline's CLIP ViT-B/32, on the same stream", steps=4, B=B, check_n=B,
+        keep_db=db, overlap=False)
     widths = (192, 384, 768, 1536)
     assert all(db[n].shape == (c, args.k, 512) for n, c in zip(layers, widths))
 

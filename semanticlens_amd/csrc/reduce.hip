@@ -1039,176 +1039,6 @@ __global__ __launch_bounds__(64 * NW) void colreduce2_kernel(const E* __restrict
   }
 }
 
-// ---- rowreduce_long (round 4): contiguous rows longer than an LDS-DMA batch (> 4 KiB: 56 x 56 and larger maps) ------------------
-// rowreduce_fast gives such a row 64 lanes and walks it one 1-KiB step at a time, four rows side by side: four loads per lane
-// are reduced before the next four are issued (ConvNeXt-L stage 0, 616 MB: 0.58-0.64 of spec; it is 53 % of configs[4]'s bytes).
-// Same cure as colreduce2: a row is a stream of 16-byte pieces, a wave walks its rows as *items* (row, block of INFL wave
-// instructions) and issues item i + 1 before it reduces item i — two register sets, loads never drain, row boundaries included.
-// Rows are interleaved over the waves (neighbouring waves read neighbouring rows); the last instruction of a row is partial:
-// its idle lanes re-read the row's last piece (a duplicate does not change a max; sums mask it).  fp32 and half precision
-// (rows of whole pieces: S % 4 == 0 resp. S % 8 == 0, base 16-byte aligned).  NaN: running-sum detector + exact re-scan.
-template <typename E, int OP, int INFL>
-__global__ __launch_bounds__(256) void rowreduce_long_kernel(const E* __restrict__ x, int64_t R, int S, float denom, int64_t tail_from,
-                                                              uint16_t* __restrict__ cand, float* __restrict__ outf) {
-  constexpr int EPP = 16 / (int)sizeof(E);
-  constexpr bool SUM = (OP == OP_SUM || OP == OP_ABSSUM);
-  constexpr bool ABS = (OP == OP_ABSMAX || OP == OP_ABSSUM);
-  const int lane = threadIdx.x & 63;
-  const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int64_t w0 = (int64_t)blockIdx.x * 4 + wave_in_block;
-  const int64_t nwaves = (int64_t)gridDim.x * 4;
-  const int np = S / EPP;             // pieces per row
-  const int ninst = (np + 63) / 64;   // wave instructions per row
-  const int nblk = (ninst + INFL - 1) / INFL;
-  const int64_t nrows_w = w0 < R ? (R - w0 + nwaves - 1) / nwaves : 0;  // rows of this wave: w0, w0 + nwaves, ... (rotated)
-  const int64_t rot = (tail_from > 0 && tail_from < R) ? tail_from : 0;  // the default-policy tail is walked first
-  const u32x4* xp = reinterpret_cast<const u32x4*>(x);
-  auto row_of = [&](int64_t i) __attribute__((always_inline)) {
-    int64_t r = w0 + i * nwaves + rot;
-    return r >= R ? r - R : r;
-  };
-  auto elems = [&](const u32x4& v, float(&e)[EPP]) __attribute__((always_inline)) {
-    if constexpr (EPP == 4) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) e[i] = bits_f32(v[i]);
-    } else {
-#pragma unroll
-      for (int d = 0; d < 4; ++d) unpack2<E>(v[d], e[2 * d], e[2 * d + 1]);
-    }
-    if constexpr (ABS) {
-#pragma unroll
-      for (int i = 0; i < EPP; ++i) e[i] = __builtin_fabsf(e[i]);
-    }
-  };
-  float m[EPP];
-  f32x2 det[EPP / 2];
-  auto reset = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int e = 0; e < EPP; ++e) m[e] = SUM ? 0.f : -__builtin_huge_valf();
-#pragma unroll
-    for (int e = 0; e < EPP / 2; ++e) det[e] = f32x2{0.f, 0.f};
-  };
-  // item = (row index i of this wave, block b); `ri` / `rb` walk the load side, `ci` / `cb` the reduce side
-  auto load = [&](u32x4(&v)[INFL], int64_t i, int b) __attribute__((always_inline)) {
-    const int64_t row = row_of(i);
-    const u32x4* base = xp + row * np;
-    const bool stream = row < tail_from;  // wave-uniform cache policy (top of this file)
-#pragma unroll
-    for (int j = 0; j < INFL; ++j) {
-      const int inst = b * INFL + j;
-      if (inst < ninst) {  // wave-uniform
-        int p = inst * 64 + lane;
-        p = p < np ? p : np - 1;
-        if (stream) v[j] = __builtin_nontemporal_load(base + p);
-        else v[j] = base[p];
-      }
-    }
-  };
-  auto finish_row = [&](int64_t i) __attribute__((always_inline)) {
-    float r;
-    if constexpr (SUM) {
-      float sacc = 0.f;
-#pragma unroll
-      for (int e = 0; e < EPP; ++e) sacc += m[e];
-      r = group_allreduce_f<64, true>(sacc);
-    } else {
-      float macc = m[0], dacc = 0.f;
-#pragma unroll
-      for (int e = 1; e < EPP; ++e) macc = __builtin_fmaxf(macc, m[e]);
-#pragma unroll
-      for (int e = 0; e < EPP / 2; ++e) dacc += det[e][0] + det[e][1];
-      r = group_allreduce_f<64, false>(macc);
-      if (__builtin_expect(__any(dacc != dacc), 0)) {  // a NaN, or +inf with -inf: look at the row again, exactly
-        const int64_t row = row_of(i);
-        bool nan = false;
-        for (int p = lane; p < np; p += 64) {
-          float e[EPP];
-          elems(xp[row * np + p], e);
-#pragma unroll
-          for (int q = 0; q < EPP; ++q) nan |= (e[q] != e[q]);
-        }
-        if (__any(nan)) r = bits_f32(0x7FC00000u);
-      }
-    }
-    if (lane == 0) store_outputs(round_to_dtype<E>(finish<OP>(r, denom)), row_of(i), cand, outf);
-  };
-  auto reduce = [&](const u32x4(&v)[INFL], int64_t i, int b) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < INFL; ++j) {
-      const int inst = b * INFL + j;
-      if (inst < ninst) {
-        float e[EPP];
-        elems(v[j], e);
-        if constexpr (SUM) {
-          const bool ok = inst * 64 + lane < np;
-#pragma unroll
-          for (int q = 0; q < EPP; ++q) m[q] += ok ? e[q] : 0.f;
-        } else {
-#pragma unroll
-          for (int q = 0; q < EPP; ++q) m[q] = __builtin_fmaxf(m[q], e[q]);
-#pragma unroll
-          for (int q = 0; q < EPP / 2; ++q) det[q] += f32x2{e[2 * q], e[2 * q + 1]};
-        }
-      }
-    }
-    if (b == nblk - 1) {
-      finish_row(i);
-      reset();
-    }
-  };
-  if (nrows_w == 0) return;
-  reset();
-  u32x4 va[INFL], vb[INFL];
-  int64_t li = 0, ci = 0;  // load-side and reduce-side row counters
-  int lb = 0, cb = 0;      // ... and block counters
-  auto advance = [&](int64_t& i, int& b) __attribute__((always_inline)) {
-    if (++b == nblk) {
-      b = 0;
-      ++i;
-    }
-  };
-  load(va, li, lb);
-  advance(li, lb);
-#pragma unroll 1
-  while (ci < nrows_w) {
-    const bool more1 = li < nrows_w;
-    if (more1) {
-      load(vb, li, lb);
-      advance(li, lb);
-    }
-    reduce(va, ci, cb);
-    advance(ci, cb);
-    if (more1) {
-      if (li < nrows_w) {
-        load(va, li, lb);
-        advance(li, lb);
-      }
-      reduce(vb, ci, cb);
-      advance(ci, cb);
-    }
-  }
-}
-
-template <typename E, int OP>
-bool try_rowreduce_long(ProfScope& prof, const E* x, int64_t R, int S, float denom, uint16_t* cand, float* outf, hipStream_t st) {
-  static const bool enabled = [] {
-    const char* e = getenv("SL_ROWREDUCE_LONG");
-    return !(e && e[0] == '0');
-  }();
-  constexpr int EPP = 16 / (int)sizeof(E);
-  const int64_t row_bytes = (int64_t)S * (int64_t)sizeof(E);
-  if (!enabled || S % EPP != 0 || ((uintptr_t)x & 15) != 0 || row_bytes <= 4096 || R < 1) return false;
-  const int64_t cus = num_cus();
-  int64_t blocks = cus * 6;  // 24 waves per CU (72 registers in fp32)
-  if (blocks * 4 > R) blocks = (R + 3) / 4;
-  const int64_t nt_min_bytes = nt_min_bytes_(), tail_bytes = tail_bytes_();  // cache policy: see the top of this file
-  const int64_t bytes = R * row_bytes;
-  int64_t tail_from = 0;  // rows from here on use the default policy
-  if (bytes >= nt_min_bytes) tail_from = tail_bytes > 0 ? (bytes > tail_bytes ? (bytes - tail_bytes) / row_bytes : 0) : INT64_MAX;
-  SL_LAUNCH(prof, (rowreduce_long_kernel<E, OP, 4>), dim3((unsigned)blocks), dim3(256), 0, st, x, R, S, denom, tail_from, cand, outf);
-  return true;
-}
-
 // ---- rowreduce_h: contiguous rows of 2-byte elements (NCHW activations of fp16 / bf16 models) -------------------------
 // x 16-byte aligned, R rows of S elements back to back.  G lanes per row (64 / G rows = one *set* per wave pass); a lane
 // loads 16-byte pieces (8 elements) of its row's window, converts to fp32 and masks the elements that belong to the
@@ -1473,8 +1303,10 @@ void dispatch_rowreduce(ProfScope& prof, const float* x, int64_t R, int S, float
   // fast path A: rows are whole 16-byte pieces
   if (S % 4 == 0 && S >= 16 && (int64_t)S * 64 * 4 * 8 < (1ll << 31)) {
     const int np = S / 4;
-    // rows longer than an LDS-DMA batch (> 4 KiB: 56 x 56 maps and larger): the ping-pong stream kernel
-    if (np > 256 && try_rowreduce_long<float, OP>(prof, x, R, S, denom, cand, outf, st)) return;
+    // Rows longer than an LDS-DMA batch (> 4 KiB: 56 x 56 maps and larger) stay on rowreduce_fast<64, 4>: 6.5 TB/s cold AND behind
+    // a producer on (256, 192, 56, 56) (617 MB, 0.82 of spec).  Round 4 built a ping-pong stream kernel for them (a wave walks
+    // (row, block-of-4-loads) items, the next item issued before the current one is reduced): 6.1 cold / 4.6 behind a producer in
+    // fp32, 5.4 against rowreduce_h's 6.1-6.3 in fp16 — removed (tools/k1_long_rows.py, profiles/r04_k1_long_rows.txt).
 #define SL_ROWREDUCE(G_, U_, AL_)                                                          \
   do {                                                                                     \
     if (try_rowreduce_dma<G_, OP, AL_>(prof, x, R, S, denom, cand, outf, st)) return;             \
@@ -1662,7 +1494,6 @@ template <typename T, int OP>
 void dispatch_rowreduce_h(ProfScope& prof, const T* x, int64_t R, int S, float denom, uint16_t* cand, float* outf, hipStream_t st) {
   const bool al = S % 8 == 0;
   const int np = al ? S / 8 : (S + 14) / 8;
-  if (al && try_rowreduce_long<T, OP>(prof, x, R, S, denom, cand, outf, st)) return;  // rows of more than 4 KiB
   // LDS-DMA ring kernel first (rowreduce_dma_kernel<T>: the fp32 kernel's feed with 8-element pieces); it takes inputs of
   // >= 8 MB whose tasks (64 / G rows) are whole 16-byte pieces
   if (al) {

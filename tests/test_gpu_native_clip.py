@@ -428,8 +428,13 @@ def test_clip_rn50_attention_pool_head_on_the_kernels(gemm):
     pool64 = copy.deepcopy(fm.model.visual.attnpool).double()
     with torch.no_grad():
         want_head = pool64(fmap.double())
+    # a random-init trunk hands the pool tokens of magnitude ~20, so its softmax logits are in the hundreds and every fp32
+    # implementation — torch's included — sits ~1e-4..1e-3 absolute from float64 on features of scale ~20.  The bar: within 1e-4
+    # of the feature SCALE, and no further from float64 than four times what torch's own fp32 attention pool is
     d = (got_i.double() - want_head).abs().max().item()
-    assert d < 1e-4, (gemm, d, want_head.abs().max().item())
+    scale = want_head.abs().max().item()
+    d_torch = (fm.model.visual.attnpool(fmap).double() - want_head).abs().max().item()
+    assert d < 1e-4 * max(scale, 1.0) and d < max(4 * d_torch, 1e-4), (gemm, d, d_torch, scale)
     want_i, want_t = _fp64_features(fm, x, toks)
     assert (got_t.double() - want_t).abs().max().item() < 1e-4
     cos = torch.nn.functional.normalize(got_i.double(), dim=-1) @ torch.nn.functional.normalize(got_t.double(), dim=-1).T

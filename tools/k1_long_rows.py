@@ -1,8 +1,9 @@
-"""K1 on rows longer than an LDS-DMA batch (> 4 KiB: 56 x 56 maps and larger): rowreduce_long (round 4, SL_ROWREDUCE_LONG=1,
-default) against the kernels that served them before (rowreduce_fast in fp32, rowreduce_h in half precision; =0).  Correctness
-against torch first, then cold (inputs rotated through > 1.3 GB, read-once policy) and behind a producer (in-place ReLU).
+"""K1 on rows longer than an LDS-DMA batch (> 4 KiB: 56 x 56 maps and larger): correctness against torch, then cold (inputs rotated
+through > 1.3 GB, read-once policy) and behind a producer (in-place ReLU).  Round 4 ran it with SL_ROWREDUCE_LONG=0 / 1 to compare
+rowreduce_fast (fp32) / rowreduce_h (half precision) with a ping-pong stream kernel built for such rows; the new kernel lost
+(profiles/r04_k1_long_rows.txt) and was removed from the library, so both settings now run the same kernels.
 
-    python tools/k1_long_rows.py          # both settings, one process each
+    python tools/k1_long_rows.py
 """
 import os
 import subprocess
@@ -42,7 +43,7 @@ def one():
                 ok = ok and torch.equal(cand.view(torch.int16), want.to(torch.bfloat16).view(torch.int16))
             else:
                 fin = torch.isfinite(want)
-                ok = torch.allclose(f32[fin], want[fin], rtol=3e-3 if dtype != torch.float32 else 2e-5, atol=1e-4) and \
+                ok = torch.allclose(f32[fin], want[fin], rtol=1e-2 if dtype != torch.float32 else 2e-5, atol=1e-4) and \
                     torch.equal(torch.isnan(f32), torch.isnan(want))
             assert ok, (shape, dname, agg)
         res = {}

@@ -14,7 +14,9 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 SHAPES = [((256, 197, 768), "float32"), ((256, 197, 768), "bfloat16"), ((256, 197, 768), "float16"), ((256, 50, 768), "float32"), ((48, 729, 1152), "float32"),
-          ((48, 729, 1152), "float16"), ((64, 256, 1152), "float32"), ((256, 196, 1024), "float32"), ((256, 257, 1024), "bfloat16")]
+          ((48, 729, 1152), "float16"), ((64, 256, 1152), "float32"), ((256, 196, 1024), "float32"), ((256, 257, 1024), "bfloat16"),
+          # ConvNeXt-L stage outputs as the model emits them (channels_last: the residual add takes the permuted branch's layout)
+          ((256, 3136, 192), "float32"), ((256, 784, 384), "float32"), ((256, 196, 768), "float32"), ((256, 49, 1536), "float32")]
 
 
 def one():

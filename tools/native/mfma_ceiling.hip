@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void mfma_loop(const uint4* __restrict__ src, 
 #pragma unroll
     for (int j = 0; j < 16; ++j) s += acc[i][j];
   if (s == 1234.5f) sink[0] = s;
-  if (threadIdx.x == 0) {
+  if ((threadIdx.x & 63) == 0) {  // one stamp pair per wave
     stamps[2 * (blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64)] = c1 - c0;
     stamps[2 * (blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64) + 1] = r1 - r0;
   }
@@ -88,7 +88,7 @@ int main(int argc, char** argv) {
       for (size_t i = 0; i < hs.size() / 2; ++i) { cyc += (double)hs[2 * i]; rt += (double)hs[2 * i + 1]; }
       const double ghz = cyc / (rt / 100e6) / 1e9;
       const double tflops = mfmas * 2.0 * 32 * 32 * 16 / t_total / 1e12;
-      // matrix pipe: a 32x32x16 bf16 MFMA occupies the pipe 8 passes x 4 cycles = 32 cycles? measured instead:
+      // a 32x32x16 bf16 MFMA occupies the matrix pipe for 8 passes x 4 cycles = 32 cycles; measured from the per-wave stamps:
       const double cyc_per_mfma = (cyc / (hs.size() / 2)) / ((double)iters * 4 * nacc * waves_per_simd);
       printf("%d wave(s)/SIMD  %-6s operands: %7.1f TFLOP/s issued (= %6.1f algorithmic for split-bf16 x3, %4.2f of 833)  sclk %.3f GHz  %.1f cycles/MFMA/SIMD  %.1f s\n",
              waves_per_simd, zero ? "zero" : "random", tflops, tflops / 3, tflops / 3 / 833.3, ghz, cyc_per_mfma, t_total);
