@@ -655,7 +655,9 @@ def config4_leg(dev, fm, args):
         act, rel = first[name]
         got = cvr._summed(rel).cpu().numpy()
         want = oracle.agg_conv(rel.float().cpu().numpy(), "sum")
-        scale = max(float(np.abs(want).max()), 1e-30)
+        if not (np.isfinite(want).all() and np.isfinite(got).all() and np.abs(want).max() > 0):
+            raise AssertionError(f"config4: the relevance of {name} is not finite / all zero")
+        scale = float(np.abs(want).max())
         worst_rel = max(worst_rel, float(np.abs(got - want).max()) / scale)
     if not worst_rel < 1e-5:
         raise AssertionError(f"config4: summed relevance differs from the oracle by {worst_rel} of its scale")

@@ -21,7 +21,7 @@ only gradient x activation:
   z+         ``(a+, w+, b+)`` and ``(a-, w-, 0)``                            ``nn.Conv*``
   flat       ``(1, 1)``: ``R_out`` spread evenly over the receptive field    the first linear module (module order)
   norm       ``(a,)`` through the module itself                              average pooling
-  pass       ``R_in = R_out``                                                activations, batch norm, dropout
+  pass       ``R_in = R_out``                                                activations, batch / layer / group norm, dropout
   =========  ==============================================================  ==================================
 
   Max pooling and tensor additions keep PyTorch's own gradient (winner-takes-all; an un-canonised residual ``x + f(x)``
@@ -40,8 +40,12 @@ import torch
 from torch import nn
 
 _CONVS = (nn.Conv1d, nn.Conv2d, nn.Conv3d)
+# Layer / group normalisation pass relevance through like batch norm.  zennit's EpsilonPlusFlat maps only BatchNorm to `Pass` and
+# leaves nn.LayerNorm to plain autograd, whose Jacobian scales the incoming "gradient" (here: relevance) by gamma / sigma per
+# block: on ConvNeXt-L (36 LayerNorm blocks, BASELINE configs[4]) the relevance of the early stages overflows to inf / NaN
+# (tests/test_lrp.py::test_layer_norm_passes_relevance_through).  Pass-through keeps the rule set conservative and finite there.
 _PASS = (nn.ReLU, nn.ReLU6, nn.LeakyReLU, nn.ELU, nn.GELU, nn.SiLU, nn.Sigmoid, nn.Tanh, nn.Hardswish, nn.Hardtanh, nn.Softplus,
-         nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d, nn.Dropout, nn.Dropout2d, nn.Identity)
+         nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d, nn.LayerNorm, nn.GroupNorm, nn.Dropout, nn.Dropout2d, nn.Identity)
 _AVGPOOL = (nn.AvgPool1d, nn.AvgPool2d, nn.AvgPool3d, nn.AdaptiveAvgPool1d, nn.AdaptiveAvgPool2d, nn.AdaptiveAvgPool3d)
 
 

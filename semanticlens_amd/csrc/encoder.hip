@@ -130,10 +130,11 @@ int run_linear3(ProfScope& prof, const uint16_t* xs, int64_t M, int64_t K, const
 }
 
 // ---- LayerNorm over the last dim: one wave per row -------------------------------------------------------------
-// Fast path (cols % 4 == 0, cols <= 1024, 16-byte aligned rows): the row is read once into registers (up to four
-// float4 per lane), mean and variance are two wave reductions, the result leaves as 16-byte fp32 stores or as
-// 8-byte packed bf16 hi / lo stores.  Other shapes: three passes over the (L1-resident) row.
-template <bool FAST>
+// Fast path (J > 0: cols % 4 == 0, cols <= 256 J, 16-byte aligned rows): the row is read once into registers (up to J
+// float4 per lane: J = 4 up to 1024 columns, J = 8 up to 2048 — SigLIP-so400m's 1152 took the three-pass path until round 4:
+// 227 us per LayerNorm at 65 536 rows, 2.7 TB/s), mean and variance are two wave reductions, the result leaves as 16-byte
+// fp32 stores or as 8-byte packed bf16 hi / lo stores.  J = 0: any shape, three passes over the (L1-resident) row.
+template <int J>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t rows, int cols,
                                                          int64_t xs, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps,
@@ -142,21 +143,33 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nw = (int64_t)gridDim.x * 4;
-  if constexpr (FAST) {
-    const int nq = cols >> 2;  // float4 chunks per row, <= 256
-    float4 g[4], bt[4];
+  if constexpr (J > 0) {
+    const int nq = cols >> 2;  // float4 chunks per row, <= 64 J
+    // gamma / beta: in registers for J = 4 (32 of 83); for J = 8 they would be 64 of 147 registers (three waves per SIMD, 55 KB
+    // of loads in flight per CU: 4.2 TB/s at so400m's 1152 columns) — there the workgroup keeps them in LDS instead
+    constexpr bool kLds = J > 4;
+    __shared__ float4 s_g[kLds ? 64 * J : 1], s_b[kLds ? 64 * J : 1];
+    float4 g[kLds ? 1 : J], bt[kLds ? 1 : J];
+    if constexpr (kLds) {
+      for (int q = threadIdx.x; q < 64 * J; q += 256) {
+        s_g[q] = q < nq ? reinterpret_cast<const float4*>(gamma)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s_b[q] = q < nq ? reinterpret_cast<const float4*>(beta)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      __syncthreads();
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int q = lane + 64 * j;
-      g[j] = q < nq ? reinterpret_cast<const float4*>(gamma)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-      bt[j] = q < nq ? reinterpret_cast<const float4*>(beta)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = 0; j < J; ++j) {
+        const int q = lane + 64 * j;
+        g[j] = q < nq ? reinterpret_cast<const float4*>(gamma)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        bt[j] = q < nq ? reinterpret_cast<const float4*>(beta)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
     for (int64_t r = wave; r < rows; r += nw) {
       const float4* p = reinterpret_cast<const float4*>(x + r * xs);
-      float4 v[4];
+      float4 v[J];
       float s = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < J; ++j) {
         const int q = lane + 64 * j;
         v[j] = q < nq ? p[q] : make_float4(0.f, 0.f, 0.f, 0.f);
         s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
@@ -165,7 +178,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       const float mean = s / (float)cols;
       float var = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < J; ++j) {
         if (lane + 64 * j < nq) {
           const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
           var += (a * a + b * b) + (c * c + d * d);
@@ -174,11 +187,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       for (int off = 32; off > 0; off >>= 1) var += __shfl_xor(var, off, 64);
       const float rstd = 1.f / sqrtf(var / (float)cols + eps);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < J; ++j) {
         const int q = lane + 64 * j;
         if (q < nq) {
-          const float4 y = make_float4((v[j].x - mean) * rstd * g[j].x + bt[j].x, (v[j].y - mean) * rstd * g[j].y + bt[j].y,
-                                       (v[j].z - mean) * rstd * g[j].z + bt[j].z, (v[j].w - mean) * rstd * g[j].w + bt[j].w);
+          const float4 gj = kLds ? s_g[q] : g[kLds ? 0 : j], bj = kLds ? s_b[q] : bt[kLds ? 0 : j];
+          const float4 y = make_float4((v[j].x - mean) * rstd * gj.x + bj.x, (v[j].y - mean) * rstd * gj.y + bj.y,
+                                       (v[j].z - mean) * rstd * gj.z + bj.z, (v[j].w - mean) * rstd * gj.w + bj.w);
           if (out) *reinterpret_cast<float4*>(out + r * os + q * 4) = y;
           if (osp) store_split4(y, r, q * 4, okp, osp);
         }
@@ -471,8 +485,12 @@ __device__ inline int attn3_vpos(int kk) {
   return (2 * (r >> 3) + h) * 8 + (r & 7);
 }
 
-template <int D>
-__global__ __launch_bounds__(256) void attention_bf16x3_kernel(const float* __restrict__ qkv, int T, int H, int causal, float scale,
+// MAXW waves per (image, head), one 32-query tile each per round.  MAXW = 8 (round 4) for sequences of more than four tiles:
+// SigLIP-so400m's 256 tokens ran as two rounds of four waves, which staged (converted, transposed) K and V twice per
+// workgroup and left each SIMD with ONE wave whose MFMAs and softmax VALU work serialise (253 us per layer at B = 64: 63 us per
+// workgroup, one workgroup per CU by its 97 KB of LDS); eight waves stage once and pair two waves per SIMD.
+template <int D, int MAXW>
+__global__ __launch_bounds__(64 * MAXW) void attention_bf16x3_kernel(const float* __restrict__ qkv, int T, int H, int causal, float scale,
                                                                 float* __restrict__ out, uint16_t* __restrict__ osp) {
   constexpr int kDh = D;
   constexpr int DP = attn3_dp(D), NS = DP / 16;  // k-steps of the score product
@@ -894,12 +912,15 @@ SL_API int sl_layernorm(const float* d_x, int64_t rows, int64_t cols, int64_t x_
   const int64_t cap = (int64_t)num_cus() * 8;
   if (blocks > cap) blocks = cap;
   const uintptr_t ptrs = (uintptr_t)d_x | (uintptr_t)d_gamma | (uintptr_t)d_beta | (uintptr_t)d_out | (uintptr_t)d_out_split;
-  const bool fast = cols % 4 == 0 && cols <= 1024 && x_row_stride % 4 == 0 && out_row_stride % 4 == 0 && (ptrs & 15) == 0;
-  if (fast)
-    hipLaunchKernelGGL(layernorm_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_x, rows, (int)cols,
+  const bool fast = cols % 4 == 0 && cols <= 2048 && x_row_stride % 4 == 0 && out_row_stride % 4 == 0 && (ptrs & 15) == 0;
+  if (fast && cols <= 1024)
+    hipLaunchKernelGGL(layernorm_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_x, rows, (int)cols,
+                       x_row_stride, d_gamma, d_beta, eps, d_out, out_row_stride, d_out_split);
+  else if (fast)
+    hipLaunchKernelGGL(layernorm_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_x, rows, (int)cols,
                        x_row_stride, d_gamma, d_beta, eps, d_out, out_row_stride, d_out_split);
   else
-    hipLaunchKernelGGL(layernorm_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_x, rows, (int)cols,
+    hipLaunchKernelGGL(layernorm_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_x, rows, (int)cols,
                        x_row_stride, d_gamma, d_beta, eps, d_out, out_row_stride, d_out_split);
   SL_CHECK_HIP(hipGetLastError());
   return 0;
@@ -965,12 +986,24 @@ static int launch_attention_bf16x3(const float* qkv, int64_t B, int64_t T, int64
   const int64_t kc = Tp < attn3_kc() ? Tp : attn3_kc();
   const int NT = (D + 31) / 32;
   const size_t smem = 2 * (size_t)kc * (attn3_dp(D) * 2 + 16) + 2 * (size_t)(NT * 32) * (kc * 2 + 16);
-  const int waves = (int)(Tp / 32 < 4 ? Tp / 32 : 4);
-  if (smem > 64 * 1024)
-    SL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_bf16x3_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  static const int max_waves = [] {
+    const char* e = getenv("SL_ATTN_WAVES");  // 4: the round-3 launch shape for every sequence length
+    return e ? atoi(e) : 8;
+  }();
   const float scale = (float)(1.0 / sqrt((double)D));
-  hipLaunchKernelGGL(attention_bf16x3_kernel<D>, dim3((unsigned)(B * H)), dim3(64 * waves), smem, st, qkv, (int)T, (int)H, causal,
-                     scale, out, osp);
+  if (Tp / 32 > 4 && max_waves >= 8 && D <= 96) {  // head_dim 104 / 128 would spill at 256 registers per wave
+    const int waves = (int)(Tp / 32 < 8 ? Tp / 32 : 8);
+    if (smem > 64 * 1024)
+      SL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_bf16x3_kernel<D, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL((attention_bf16x3_kernel<D, 8>), dim3((unsigned)(B * H)), dim3(64 * waves), smem, st, qkv, (int)T, (int)H, causal,
+                       scale, out, osp);
+  } else {
+    const int waves = (int)(Tp / 32 < 4 ? Tp / 32 : 4);
+    if (smem > 64 * 1024)
+      SL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_bf16x3_kernel<D, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL((attention_bf16x3_kernel<D, 4>), dim3((unsigned)(B * H)), dim3(64 * waves), smem, st, qkv, (int)T, (int)H, causal,
+                       scale, out, osp);
+  }
   SL_CHECK_HIP(hipGetLastError());
   return 0;
 }

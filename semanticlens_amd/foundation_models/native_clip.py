@@ -779,6 +779,28 @@ class NativeSigLipText:
         return _project(N.layernorm(picked, *self.ln_final), self.w_head, self.b_head, self.s_head)
 
 
+def friendly_batch(tokens: int, width: int, mlp: int, device=None, lo: int = 64, hi: int = 256) -> int:
+    """Images per encoder call (``embed_accumulate``) whose token rows fill whole rounds of 256 x 256 GEMM tiles on the part.
+
+    A GEMM of ``tm x tn`` tiles takes ``ceil(tm tn / CUs)`` rounds whatever its last round holds: SigLIP-so400m at 64 images
+    (16 384 rows) runs its out-projection and fc2 (N = 1152: 5 tile columns) as 320 tiles = 2 rounds for 1.25 rounds of work
+    (296 of the 411 TFLOP/s the same kernels reach at 256 images, where every GEMM is a whole number of rounds:
+    ``profiles/r04_siglip_b64_kernel_stats.csv`` / ``_b256_``).  An embedding does not depend on the batch it is computed in, so
+    the embed stage is free to pick the count: the one in ``[lo, hi]`` (multiples of 8) with the fewest tile rounds per image over the four
+    GEMMs of a block."""
+    cus = 256
+    if device is not None and torch.cuda.is_available():
+        cus = torch.cuda.get_device_properties(device).multi_processor_count or 256
+    tns = [-(-3 * width // 256), -(-width // 256), -(-mlp // 256), -(-width // 256)]
+    best, best_cost = hi, float("inf")
+    for b in range(lo, hi + 1, 8):
+        tm = -(-b * tokens // 256)
+        cost = sum(-(-tm * tn // cus) for tn in tns) / b
+        if cost < best_cost - 1e-12:
+            best, best_cost = b, cost
+    return best
+
+
 class NativeSigLip(AbstractVLM):
     """``AbstractVLM`` running the towers of a SigLIP-layout model on HIP kernels.
 
@@ -788,7 +810,7 @@ class NativeSigLip(AbstractVLM):
     (``vision_model`` / ``text_model``; the geometry of SigLIP-so400m — width 1152, head_dim 72 — is what BASELINE
     configs[3] names).  Tokenizer and host preprocessing stay ``base``'s; ``preprocess`` as for :class:`NativeClip`."""
 
-    embed_accumulate = 64  # see NativeClip; 64 images of a so400m-sized tower are 46 656 token rows already
+    embed_accumulate = 64  # see NativeClip; replaced per instance in __init__ (tile-friendly row count for the tower's geometry)
 
     def __init__(self, base, device=None, gemm: str = "bf16x3", preprocess=None):
         if gemm not in ("bf16x3", "f32"):
@@ -815,6 +837,7 @@ class NativeSigLip(AbstractVLM):
             self.text = NativeTextTower(text, text.transformer.resblocks, dev, split, pool=getattr(text, "pool_type", "argmax"),
                                         causal=getattr(text, "attn_mask", None) is not None)
         self.name = f"native-{gemm}-" + getattr(base, "name", type(base).__name__)
+        self.embed_accumulate = friendly_batch(self.vision.pos.shape[0], self.vision.width, self.vision.tower.blocks[0].w_fc.shape[0], dev)
         if preprocess == "device":
             from semanticlens_amd.foundation_models.preprocess import DevicePreprocess
 

@@ -289,6 +289,7 @@ def test_config4_full_geometry_convnext_l_collect_relevance_and_scores(monkeypat
             ref = oracle.ActMaxOracle(k, c, oracle.MODE_ATEN, init_value=-np.inf)
             for bi, (vals, ids) in enumerate(fed[id(am)]):
                 # K1 sum (+ abs-norm) against the oracle on the SAME tensors: fp32 summation order differs -> 1e-5 of the row scale
+                assert np.isfinite(captured[bi][name][idx]).all(), (name, idx, "the attribution produced inf / NaN")
                 want = oracle.agg_conv(captured[bi][name][idx], "sum")
                 if norm:
                     want = oracle.abs_norm_rows(want)

@@ -690,3 +690,18 @@ def test_embed_stage_writes_rows_in_dataset_order_when_preprocess_output_types_m
     stage.add(None, torch.tensor([[6.0]]))
     out = stage.finish()
     assert out[:, 0].tolist() == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0]
+
+
+def test_friendly_batch_fills_whole_tile_rounds():
+    """`NativeSigLip.embed_accumulate`: the image count whose token rows make every GEMM of a block a whole number of 256-tile rounds."""
+    from semanticlens_amd.foundation_models.native_clip import friendly_batch
+
+    def rounds_per_image(b, tokens, width, mlp, cus=256):
+        tm = -(-b * tokens // 256)
+        return sum(-(-tm * tn // cus) for tn in (-(-3 * width // 256), -(-width // 256), -(-mlp // 256), -(-width // 256))) / b
+
+    b = friendly_batch(256, 1152, 4304)  # SigLIP-so400m at 224 px
+    assert 64 <= b <= 256 and b % 8 == 0
+    assert rounds_per_image(b, 256, 1152, 4304) <= min(rounds_per_image(c, 256, 1152, 4304) for c in (64, 128, 192, 256)) + 1e-12
+    assert rounds_per_image(b, 256, 1152, 4304) < 0.85 * rounds_per_image(64, 256, 1152, 4304)  # what 64 images wasted
+    assert 64 <= friendly_batch(729, 1152, 4304) <= 256 and 64 <= friendly_batch(196, 768, 3072) <= 256

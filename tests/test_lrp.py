@@ -213,3 +213,26 @@ def test_first_layer_is_the_first_linear_module_in_module_order():
         (r_x,) = torch.autograd.grad(y, xx, grad_outputs=y.detach())
     # `early` runs the epsilon rule (relevance depends on x), it is not the flat one
     assert not torch.allclose(r_x[:, 0], r_x[:, 1])
+
+
+def test_layer_norm_passes_relevance_through():
+    """A ConvNeXt-style stack (depthwise conv -> LayerNorm -> Linear -> GELU -> Linear -> residual, BASELINE configs[4]'s probed
+    model): with LayerNorm left to autograd the relevance grew ~10x per block and overflowed on ConvNeXt-L; passed through,
+    it stays finite and of the scale of the target logit in every stage."""
+    import synth
+
+    torch.manual_seed(0)
+    m = synth.ConvNeXt(depths=(2, 2, 3, 2), dims=(16, 32, 64, 128), layer_scale=1.0).eval()
+    x = torch.randn(2, 3, 64, 64)
+    layers = {f"stages.{i}": m.stages[i] for i in range(4)}
+    out = lrp_epsilon_plus_flat(m, layers, x, None)
+    with torch.no_grad():
+        y = m(x)
+    top = y.max(1).values.abs().max().item()
+    for name, (act, rel) in out.items():
+        assert torch.isfinite(rel).all(), name
+        assert 0 < rel.abs().max().item() < 1e3 * max(top, 1.0), (name, rel.abs().max().item(), top)
+    # a LayerNorm alone: relevance in == relevance out
+    ln = nn.Sequential(nn.Linear(6, 6, bias=False), nn.LayerNorm(6), nn.Linear(6, 3, bias=False)).eval()
+    res = lrp_epsilon_plus_flat(ln, {"0": ln[0], "1": ln[1]}, torch.rand(4, 6) + 0.5, None)
+    assert torch.allclose(res["0"][1], res["1"][1])
