@@ -116,12 +116,19 @@ class RelevanceComponentVisualizer(ActivationComponentVisualizer):
     (default True), ``num_samples`` (default 100), ``composite`` (``"epsilon_plus_flat"`` — default —,
     ``"gradient_x_activation"``, or a callable) / ``attribution`` (a callable as :func:`gradient_x_activation`; wins),
     ``use_labels`` (take the targets from the dataset's labels instead of the model's prediction; crp conditions on the
-    label).
+    label), ``epsilon`` (stabiliser of the epsilon / z+ rules, zennit's default 1e-6).
+
+    The epsilon rule divides by pre-activations of either sign; behind LayerNorm / GELU (ConvNeXt, transformers) some pass
+    arbitrarily close to zero, and with the 1e-6 stabiliser relevance grows ~30x per block — inf / NaN from stage 2 of ConvNeXt-L
+    upwards (zennit behaves the same: its composite leaves that to the user).  A batch with non-finite relevance raises
+    ``FloatingPointError`` instead of filling the top-k states with NaN; ``epsilon=0.1`` keeps ConvNeXt-L conservative
+    (tests/test_gpu_configs.py), ``composite="gradient_x_activation"`` is the parameter-free alternative.
     """
 
     def __init__(self, model: nn.Module, dataset_model, dataset_fm, layer_names, num_samples: int = 100,
                  aggregation_fn: str = "sum", abs_norm: bool = True, attribution=None, use_labels: bool = False,
-                 device=None, cache_dir: str | None = None, tie_mode: str | None = None, composite="epsilon_plus_flat"):
+                 device=None, cache_dir: str | None = None, tie_mode: str | None = None, composite="epsilon_plus_flat",
+                 epsilon: float = 1e-6):
         if aggregation_fn not in _LABELS:  # crp's `max_target`: "sum" (the reference's default) or "max" over the spatial / token axis
             raise ValueError(f"aggregation_fn must be 'sum' or 'max' (crp's max_target), got {aggregation_fn!r}")
         layer_names = [layer_names] if not isinstance(layer_names, list) else layer_names
@@ -131,7 +138,12 @@ class RelevanceComponentVisualizer(ActivationComponentVisualizer):
             if callable(composite):
                 attribution = composite
             elif composite == "epsilon_plus_flat":
-                from semanticlens_amd.component_visualization.lrp import lrp_epsilon_plus_flat as attribution
+                from semanticlens_amd.component_visualization.lrp import lrp_epsilon_plus_flat
+
+                def attribution(model_, layers_, images_, targets_, _eps=float(epsilon)):
+                    return lrp_epsilon_plus_flat(model_, layers_, images_, targets_, epsilon=_eps)
+
+                attribution.__name__ = "lrp_epsilon_plus_flat" if epsilon == 1e-6 else f"lrp_epsilon_plus_flat_eps{epsilon:g}"
             elif composite == "gradient_x_activation":
                 attribution = gradient_x_activation
             else:
@@ -212,6 +224,12 @@ class RelevanceComponentVisualizer(ActivationComponentVisualizer):
             targets = torch.as_tensor(labels).to(self.device) if self.use_labels else None
             per_layer = self.attribution(self.model, self._modules, images, targets)
             ids = torch.arange(start, start + images.shape[0])
+            bad = [name for name in self.layer_names if not bool(torch.isfinite(per_layer[name][1]).all())]
+            if bad:
+                raise FloatingPointError(
+                    f"the attribution {self.composite!r} produced inf / NaN relevance at {bad} (samples {start}..{start + images.shape[0] - 1}): "
+                    "the epsilon rule is unstable on this architecture with its current stabiliser — pass a larger `epsilon` "
+                    "(e.g. 0.1) or composite='gradient_x_activation'")
             for name in self.layer_names:
                 act, rel = per_layer[name]
                 self.collect_relevance(name, act, rel, ids)
