@@ -1397,12 +1397,14 @@ bool launch_colreduce2(ProfScope& prof, const T* x, int64_t B, int T_, int64_t F
   if (all >= nt_min_bytes) tail_from = tail_bytes > 0 ? (all > tail_bytes ? (all - tail_bytes) / per_b * nchunk : 0) : INT64_MAX;
   // waves per task split the reduced axis; a wave instruction covers 64 / lpr rows, so short axes want few waves
   const int64_t inst_rows = rows * lpr / 64;  // wave instructions per task
-  // measured (profiles/r04_k2_lab.txt): fp32 (72 registers, 24+ waves per CU) gains 2-5 % from 8 waves up to 4 tasks per CU
-  // ((256, 197, 768): 6.09 -> 6.19 TB/s cold, 5.67 -> 5.96 behind a producer); the half-precision kernels (100 registers, 16
-  // waves per CU) LOSE 15 % with 8 once there are two tasks per CU ((256, 257, 1024) bf16: 6.07 -> 5.15)
+  // 8 waves per task only below two tasks per CU.  tools/k2_lab.py (an elementwise producer, then K2) showed the fp32 kernel
+  // 2-5 % faster with 8 waves up to four tasks per CU ((256, 197, 768): 6.09 -> 6.19 TB/s cold), but INSIDE the bench's leg
+  // (behind a ViT block's GEMMs, tools/k2_leg_probe.py) the same shape reads 0.717 of spec with four waves and 0.671 with
+  // eight; the half-precision kernels (100 registers, 16 waves per CU) lose 15 % with eight once there are two tasks per CU
+  // ((256, 257, 1024) bf16: 6.07 -> 5.15 TB/s).  profiles/r04_k2_lab.txt
   int nw = 4;
   if (tasks * 2 < cus && inst_rows >= 128 && lpr == 64) nw = 16;
-  else if (tasks < (sizeof(T) == 4 ? 4 : 1) * cus && inst_rows >= 64) nw = 8;
+  else if (tasks < (sizeof(T) == 4 ? 2 : 1) * cus && inst_rows >= 64) nw = 8;
   if (forced_nw == 4 || forced_nw == 8 || (forced_nw == 16 && lpr == 64)) nw = forced_nw;
 #define SL_COL2(NW_, LPR_) launch_colreduce2_as<T, OP, NW_, LPR_>(prof, x, B, T_, F, sb, st_, t0, t1, denom, tail_from, cand, outf, st)
 #define SL_COL2_NW(LPR_)                 \
