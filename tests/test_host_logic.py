@@ -705,3 +705,33 @@ def test_friendly_batch_fills_whole_tile_rounds():
     assert rounds_per_image(b, 256, 1152, 4304) <= min(rounds_per_image(c, 256, 1152, 4304) for c in (64, 128, 192, 256)) + 1e-12
     assert rounds_per_image(b, 256, 1152, 4304) < 0.85 * rounds_per_image(64, 256, 1152, 4304)  # what 64 images wasted
     assert 64 <= friendly_batch(729, 1152, 4304) <= 256 and 64 <= friendly_batch(196, 768, 3072) <= 256
+
+
+def test_text_chunks_are_tokenised_one_ahead_in_the_same_order(monkeypatch):
+    """`_encode_texts`: the tokenizer runs one chunk ahead on a helper thread; calls, order and results equal the serial loop's."""
+    from semanticlens_amd.lens import _encode_texts
+
+    class FM:
+        device = torch.device("cpu")
+
+        def __init__(self):
+            self.log = []
+
+        def tokenize(self, chunk):
+            self.log.append(("tok", tuple(chunk)))
+            return torch.tensor([[len(t), sum(map(ord, t)) % 97] for t in chunk], dtype=torch.int64)
+
+        def encode_text(self, tokens):
+            self.log.append(("enc", tokens.shape[0]))
+            return tokens.float() * 0.5
+
+    texts = [f"prompt {i}" * (1 + i % 3) for i in range(23)]
+    a, b = FM(), FM()
+    monkeypatch.setenv("SL_TEXT_PREFETCH", "1")
+    got = _encode_texts(a, texts, batch_size=5)
+    monkeypatch.setenv("SL_TEXT_PREFETCH", "0")
+    want = _encode_texts(b, texts, batch_size=5)
+    assert torch.equal(got, want) and got.shape == (23, 2)
+    assert [e for e in a.log if e[0] == "tok"] == [e for e in b.log if e[0] == "tok"]  # same chunks, same order
+    assert [e for e in a.log if e[0] == "enc"] == [("enc", 5)] * 4 + [("enc", 3)]
+    assert len(_encode_texts(FM(), texts, batch_size=None)) == 23  # one chunk: no thread
