@@ -485,6 +485,19 @@ __device__ inline int attn3_vpos(int kk) {
   return (2 * (r >> 3) + h) * 8 + (r & 7);
 }
 
+// e^x for the softmax of attention_bf16x3_kernel: 2^(x log2 e) on the hardware exp2 with the rounding error of the product and the
+// low half of the constant folded back in (2^(t + d) = 2^t (1 + d ln 2)): ~2e-7 relative — the library expf's accuracy class — in
+// 7 instructions instead of ~15.  Round 4: with two waves per SIMD the kernel's VALU work (17 exponentials and 48 rescales per
+// lane and key tile) outweighed its 33 MFMAs.  x <= 0 here; -inf (masked keys, the first tile's running maximum) gives 0.
+__device__ __forceinline__ float exp_neg(float x) {
+  x = fmaxf(x, -104.f);  // 2^-150 flushes to 0; keeps -inf out of the error term (inf - inf)
+  const float t = x * 1.44269502e+00f;
+  float d = __builtin_fmaf(x, 1.44269502e+00f, -t);
+  d = __builtin_fmaf(x, 1.92596299e-08f, d);
+  const float r = __builtin_amdgcn_exp2f(t);
+  return __builtin_fmaf(r, d * 6.93147182e-01f, r);
+}
+
 // MAXW waves per (image, head), one 32-query tile each per round.  MAXW = 8 (round 4) for sequences of more than four tiles:
 // SigLIP-so400m's 256 tokens ran as two rounds of four waves, which staged (converted, transposed) K and V twice per
 // workgroup and left each SIMD with ONE wave whose MFMAs and softmax VALU work serialise (253 us per layer at B = 64: 63 us per
@@ -643,21 +656,25 @@ __global__ __launch_bounds__(64 * MAXW) void attention_bf16x3_kernel(const float
         }
         mx = fmaxf(mx, xhalf(mx));
         const float mn = fmaxf(m, mx);
-        const float alpha = expf(m - mn);
+        const float alpha = exp_neg(m - mn);
         float ps = 0.f;
         float pv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          pv[r] = expf(st[r] - mn);
+          pv[r] = exp_neg(st[r] - mn);
           ps += pv[r];
         }
         ps += xhalf(ps);
         l = l * alpha + ps;
+        // once the running maxima have settled (after the first key tiles of most rows) alpha is exactly 1 in every lane and
+        // the 16 NT rescales of the output accumulators are skipped for the whole wave
+        if (!__all(mn == m)) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
+        }
         m = mn;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           abf16x8 ph, pl;

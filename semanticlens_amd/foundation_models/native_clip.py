@@ -351,7 +351,12 @@ class NativeResNetVision:
     @torch.no_grad()
     def __call__(self, img: torch.Tensor) -> torch.Tensor:
         img = N.to_device(img).to(next(self.visual.parameters()).dtype)
-        fmap = self.trunk(img).to(torch.float32).contiguous()
+        return self.head(self.trunk(img))
+
+    @torch.no_grad()
+    def head(self, fmap: torch.Tensor) -> torch.Tensor:
+        """The attention pool + projection of a ``(B, C, h, w)`` trunk output, on the kernels."""
+        fmap = N.to_device(fmap).to(torch.float32).contiguous()
         B, C = fmap.shape[:2]
         T = fmap[0, 0].numel() + 1
         if C != self.width or T != self.pos.shape[0]:

@@ -420,8 +420,10 @@ def test_clip_rn50_attention_pool_head_on_the_kernels(gemm):
     assert got_i.shape == (8, 1024) and got_t.shape == (4, 1024)
     want_i32 = fm.encode_image(x)
     assert rel_err(got_i, want_i32) < 1e-4
-    # the head alone, on the trunk's own output, against float64
+    # the head alone, on ONE trunk output (MIOpen's convolutions are not run-to-run deterministic at this batch size, so two
+    # calls of the trunk may differ in the last bits — amplified by the pool's large logits), against float64
     fmap = nat.vision.trunk(x)
+    got_i = nat.vision.head(fmap)
     assert fmap.shape == (8, 2048, 7, 7) and fm.model.visual.attnpool is not None and not isinstance(fm.model.visual.attnpool, torch.nn.Identity)
     import copy
 
