@@ -47,6 +47,19 @@ def test_argument_errors_are_reported_without_a_device():
     assert lib.sl_similarity(None, 3, 4, None, 5, 6, None, None, 0, None) == -1
     assert lib.sl_last_error() == b"x and y must have the same shape"  # the reference's ValueError text
     assert lib.sl_reduce_conv(None, 7, 1, 1, 1, 1, 1, 1, 0, None, None, None) == -1
+    # the communicator entry points validate before they touch RCCL or a device
+    assert lib.sl_comm_allgather(None, None, None, 16, None) == -1 and lib.sl_last_error() == b"sl_comm_allgather: null communicator"
+    assert lib.sl_comm_allreduce(None, None, 4, 0, 0, None) == -1
+    assert lib.sl_actmax_allgather_merge(None, 1, None, None, None, 5, None, 0, None) == -1
+    assert lib.sl_comm_init_from_unique_id(None, 2, 0, None) == -1
+    assert lib.sl_comm_destroy(None) == 0  # destroying nothing is fine
+    import ctypes
+
+    C = (ctypes.c_int64 * 3)(512, 1024, 2048)
+    per_rank = lib.sl_actmax_packed_bytes(3, C, 20)
+    assert per_rank == 3584 * 20 * 10 and lib.sl_actmax_allgather_merge_ws_bytes(3, C, 20, 8) == 9 * per_rank  # 717 KB per rank
+    assert lib.sl_actmax_packed_bytes(1, (ctypes.c_int64 * 1)(3), 5) == 160  # 150 bytes rounded up to 16
+    assert lib.sl_actmax_merge_packed(1, None, None, None, 5, None, 2, -1, None) == -1
 
 
 @pytest.mark.skipif(not NO_GPU, reason="checks the no-device behaviour")
