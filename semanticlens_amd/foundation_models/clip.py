@@ -80,14 +80,19 @@ class OpenClip(AbstractVLM):
         return self.tokenizer(txt, context_length=length).to(self.device)
 
     # ---- the package's own execution path --------------------------------------------------------------------------
-    def native(self, gemm: str = "bf16x3", device_preprocess: bool = True):
+    #: what ``native()`` does with an image tower the native classes do not read: "native" = raise ``TypeError``
+    NATIVE_IMAGE_TOWER = "native"
+
+    def native(self, gemm: str = "bf16x3", device_preprocess: bool = True, image_tower: str | None = None):
         """This model with its towers on the HIP kernels and, optionally, its inference transform on the device
         (``DevicePreprocess.from_transform(self.preprocessor)``).  The native class follows the module layout open_clip
-        built: ``NativeClip`` for its own ``VisionTransformer`` towers, ``NativeSigLip`` for a timm trunk with a MAP head
-        (``SigLipV2``); layouts neither implements (MobileCLIP's hybrid tower) raise ``TypeError``."""
+        built: ``NativeClip`` for its own ``VisionTransformer`` and ResNet towers, ``NativeSigLip`` for a timm trunk with a MAP
+        head (``SigLipV2``).  ``image_tower="auto"`` (``ClipMobile``'s default: MobileCLIP's FastViT hybrid is not read) keeps
+        such an image tower on PyTorch and moves the text tower only (``NativeTextClip``); ``"native"`` raises ``TypeError``."""
         from semanticlens_amd.foundation_models.native_clip import native_model
 
-        return native_model(self, gemm=gemm, preprocess="device" if device_preprocess else None)
+        return native_model(self, gemm=gemm, preprocess="device" if device_preprocess else None,
+                            image_tower=image_tower or self.NATIVE_IMAGE_TOWER)
 
 
 class SigLipV2(OpenClip):
@@ -105,6 +110,7 @@ class ClipMobile(OpenClip):
 
     SPECS = {"s1": _Spec("MobileCLIP-S1", "datacompdr"), "s2": _Spec("MobileCLIP-S2", "datacompdr")}
     URLs = {version: spec.model_name for version, spec in SPECS.items()}
+    NATIVE_IMAGE_TOWER = "auto"  # FastViT hybrid image tower: stays on PyTorch; `.native()` moves the text tower (NativeTextClip)
 
     def __init__(self, version: str = "s1", device="cpu", **kwargs):
         self._install(self.SPECS[version], device, kwargs)

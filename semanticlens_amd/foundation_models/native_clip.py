@@ -874,9 +874,82 @@ class NativeSigLip(AbstractVLM):
         return self.base.tokenize(txt, *args, **kwargs)
 
 
-def native_model(base, gemm: str = "bf16x3", preprocess=None):
-    """The native counterpart of a wrapped open_clip / transformers model, chosen by its module layout."""
+class NativeTextClip(AbstractVLM):
+    """The wrapped model with its TEXT tower on the kernels and its image tower left to PyTorch — for CLIP models whose image
+    tower the native classes do not read: MobileCLIP (``ClipMobile``, foundation_models/clip.py:214-247 — the reference
+    tutorial's foundation model: a FastViT hybrid of re-parameterised convolutions behind open_clip's ``TimmModel``) and any
+    other convolutional / hybrid tower.  ``base.model`` is open_clip's ``CustomTextCLIP`` (``text`` = ``TextTransformer``) or
+    ``CLIP`` (text members on the model).  Text probing — ``Lens.text_probing``'s 10 000-prompt sweeps — runs natively;
+    ``encode_image`` is ``base``'s own (the embed stage treats it like any user ``AbstractVLM``).  ``preprocess`` as for
+    :class:`NativeClip`."""
+
+    def __init__(self, base, device=None, gemm: str = "bf16x3", preprocess=None):
+        if gemm not in ("bf16x3", "f32"):
+            raise ValueError("gemm must be 'bf16x3' or 'f32'")
+        model = base.model
+        dev = torch.device(device) if device is not None else next(model.parameters()).device
+        if dev.type != "cuda":
+            dev = N.default_device()
+        self._device, self.base = dev, base
+        base.to(dev)
+        text = model.text if hasattr(getattr(model, "text", None), "transformer") else model
+        if not hasattr(getattr(text, "transformer", None), "resblocks") or not hasattr(text, "token_embedding"):
+            raise TypeError(f"NativeTextClip reads open_clip's TextTransformer layout (`token_embedding`, `transformer.resblocks`, "
+                            f"`ln_final`, `text_projection`); found {type(text).__name__}")
+        pool = getattr(text, "pool_type", None) or getattr(model, "text_pool_type", "argmax")
+        if pool not in ("argmax", "first", "last"):
+            raise TypeError(f"text pool_type={pool!r} (only 'argmax', 'first', 'last')")
+        self.text = NativeTextTower(text, text.transformer.resblocks, dev, gemm == "bf16x3", pool=pool,
+                                    causal=getattr(text, "attn_mask", None) is not None)
+        self.name = f"native-text-{gemm}-" + getattr(base, "name", type(base).__name__)
+        if preprocess == "device":
+            from semanticlens_amd.foundation_models.preprocess import DevicePreprocess
+
+            preprocess = DevicePreprocess.from_transform(base.preprocessor)
+        self._preprocess = preprocess.to(dev) if preprocess is not None else None
+
+    @property
+    def device(self):
+        return self._device
+
+    def to(self, device):
+        if torch.device(device).type != "cuda":
+            raise N.NativeLibraryError("NativeTextClip runs on a HIP device only")
+        return self
+
+    def encode_image(self, img):
+        return self.base.encode_image(img)
+
+    def encode_text(self, tokens):
+        return self.text(tokens)
+
+    def preprocess(self, img):
+        if self._preprocess is not None:
+            out = self._preprocess(img)
+            return out.unsqueeze(0) if out.ndim == 3 else out
+        return self.base.preprocess(img)
+
+    def tokenize(self, txt, *args, **kwargs):
+        return self.base.tokenize(txt, *args, **kwargs)
+
+
+def native_model(base, gemm: str = "bf16x3", preprocess=None, image_tower: str = "native"):
+    """The native counterpart of a wrapped open_clip / transformers model, chosen by its module layout.  ``image_tower``:
+    ``"native"`` (refuse a tower the native classes do not read), ``"auto"`` (fall back to :class:`NativeTextClip` — torch image
+    tower, native text tower — when only the image tower is refused), ``"torch"`` (always that)."""
+    if image_tower not in ("native", "auto", "torch"):
+        raise ValueError("image_tower must be 'native', 'auto' or 'torch'")
+    if image_tower == "torch":
+        return NativeTextClip(base, gemm=gemm, preprocess=preprocess)
     model = base.model
-    if hasattr(model, "vision_model") or hasattr(getattr(model, "visual", None), "trunk"):
-        return NativeSigLip(base, gemm=gemm, preprocess=preprocess)
-    return NativeClip(base, gemm=gemm, preprocess=preprocess)
+    try:
+        if hasattr(model, "vision_model") or hasattr(getattr(model, "visual", None), "trunk"):
+            return NativeSigLip(base, gemm=gemm, preprocess=preprocess)
+        return NativeClip(base, gemm=gemm, preprocess=preprocess)
+    except TypeError as err:
+        if image_tower != "auto":
+            raise
+        try:
+            return NativeTextClip(base, gemm=gemm, preprocess=preprocess)
+        except TypeError:
+            raise err from None

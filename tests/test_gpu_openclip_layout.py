@@ -238,3 +238,73 @@ def test_unsupported_open_clip_variants_are_refused_by_name():
         NativeClip(wrap(MobileLike()))
     with pytest.raises(TypeError, match="NativeSigLip expects"):
         NativeSigLip(wrap(MobileLike()))
+
+
+# ---- MobileCLIP-style models (`ClipMobile`, clip.py:214-247: the reference tutorial's foundation model) -----------------------
+class _ConvTower(torch.nn.Module):
+    """A convolutional image tower behind `visual` (stands for MobileCLIP's FastViT hybrid, which the native classes do not read)."""
+
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.body = torch.nn.Sequential(torch.nn.Conv2d(3, 16, 3, 2, 1), torch.nn.GELU(), torch.nn.Conv2d(16, 32, 3, 2, 1), torch.nn.GELU(),
+                                        torch.nn.AdaptiveAvgPool2d(1), torch.nn.Flatten(), torch.nn.Linear(32, embed_dim))
+
+    def forward(self, x):
+        return self.body(x)
+
+
+def _mobile_like(layout):
+    torch.manual_seed(7)
+    text = oc.TextTransformer(context_length=16, vocab_size=1000, width=128, heads=2, layers=2, output_dim=64)
+    if layout == "custom_text":  # open_clip.CustomTextCLIP: what MobileCLIP-S1/S2 are built as
+        model = oc.CustomTextCLIP(_ConvTower(64), text)
+    else:  # text members flattened onto the model, as open_clip.CLIP does
+        model = oc.build_clip_vit(**SMALL)
+        model.visual = _ConvTower(64)
+    oc._randomize(model, 7)
+    return Wrapped(model, 16, 1000, eot=999)
+
+
+@pytest.mark.parametrize("layout", ["custom_text", "clip"])
+@pytest.mark.parametrize("gemm", ["bf16x3", "f32"])
+def test_native_text_tower_beside_a_torch_image_tower(layout, gemm):
+    """`NativeTextClip`: the text tower on the kernels, the (unreadable) image tower left to PyTorch — `ClipMobile.native()`."""
+    from semanticlens_amd.foundation_models import NativeTextClip
+    from semanticlens_amd.foundation_models.native_clip import native_model
+
+    base = _mobile_like(layout)
+    base.encode_image = lambda img: base.model.encode_image(img)
+    with pytest.raises(TypeError):
+        native_model(base, gemm=gemm)  # image_tower="native": refused, as before
+    nat = native_model(base, gemm=gemm, image_tower="auto")
+    assert isinstance(nat, NativeTextClip) and nat.name.startswith(f"native-text-{gemm}-")
+    got_i, got_t = check_towers(base, nat, 64, 64, 3e-5 if gemm == "bf16x3" else 1e-5)
+    with torch.no_grad():
+        assert torch.equal(got_i, base.model.encode_image(torch.randn(6, 3, 64, 64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))))
+    # and it probes: Lens.text_probing through the native text tower
+    from semanticlens_amd import Lens
+
+    db = {"l": torch.randn(9, 64, device=DEV)}
+    out = Lens(nat, device=DEV).text_probing(PROMPTS, db)
+    want = torch.nn.functional.normalize(got_t, dim=-1) @ torch.nn.functional.normalize(db["l"], dim=-1).T
+    assert torch.allclose(out["l"], want, atol=1e-5)
+
+
+def test_clip_mobile_native_keeps_the_image_tower_on_torch(monkeypatch):
+    """`ClipMobile(...).native()` — the wrapper the reference's tutorial uses — no longer refuses: `NATIVE_IMAGE_TOWER = "auto"`."""
+    import sys
+
+    from semanticlens_amd.foundation_models import ClipMobile, NativeTextClip, OpenClip
+
+    base = _mobile_like("custom_text")
+    registry = {"MobileCLIP-S1": (lambda: base.model, 64, oc.HALF, oc.HALF, oc._tokenizer(1000, eot=999))}
+    monkeypatch.setitem(sys.modules, "open_clip", oc.fake_open_clip_module(registry))
+    fm = ClipMobile("s1", device=DEV)
+    nat = fm.native(device_preprocess=False)
+    assert isinstance(nat, NativeTextClip)
+    with pytest.raises(TypeError):
+        fm.native(image_tower="native")
+    assert OpenClip.NATIVE_IMAGE_TOWER == "native" and ClipMobile.NATIVE_IMAGE_TOWER == "auto"
+    tok = fm.tokenize(PROMPTS)
+    with torch.no_grad():
+        assert rel_err(nat.encode_text(tok), fm.model.encode_text(tok)) < 3e-5
