@@ -769,6 +769,60 @@ def cpu_baseline_scores(threads_best: int):
     return out
 
 
+@torch.no_grad()
+def sharded_check(dev, model, fm, args, rank, world):
+    """Multi-rank parity inside the measured run (never fatal: differences are REPORTED in the line).  Every rank collects one batch of
+    `--batch` images (ids rank*B .. rank*B + B - 1) and takes part in the cross-rank merge + sharded gather; rank 0 then replays all
+    world*B images on its own GPU under oracle taps (total order) and compares the merged top-k bits, ids and the concept_db it holds
+    with the oracle's — the check `self_check` performs at N = 1, across the wire."""
+    import numpy as np
+
+    B = args.batch
+    n = world * B
+    cv = make_cv(model, n, args.k, "total")
+    mine = [synth.synth_images_u8(torch.arange(rank * B, (rank + 1) * B, device=dev))]
+    emb = run_steps(cv, fm, mine, rank * B, B)
+    db = finish_job(cv, emb, rank * B, n, True)
+    torch.cuda.synchronize()
+    if rank != 0:
+        return None
+    import oracle  # the checker — rank 0 only, never on the product path
+
+    refs, seen = {}, {name: 0 for name in LAYERS}
+
+    def tap(name):
+        def fn(m, i, o):
+            a = oracle.agg_conv(o.detach().float().cpu().numpy(), "max")
+            if name not in refs:
+                refs[name] = oracle.ActMaxOracle(args.k, a.shape[1], oracle.MODE_TOTAL)
+            refs[name].update(a, np.arange(seen[name], seen[name] + a.shape[0]))
+            seen[name] += a.shape[0]
+
+        return fn
+
+    modules = dict(model.named_modules())
+    taps = [modules[name].register_forward_hook(tap(name)) for name in LAYERS]
+    embeds = []
+    try:
+        for r in range(world):
+            u8 = synth.synth_images_u8(torch.arange(r * B, (r + 1) * B, device=dev))
+            model(synth.normalize_u8(u8, synth.IMAGENET_MEAN, synth.IMAGENET_STD))
+            embeds.append(fm.encode_image(fm.preprocess(u8)).float().cpu().numpy())
+    finally:
+        for h in taps:
+            h.remove()
+    emb_all = np.concatenate(embeds)
+    out = {"images": n, "ranks": world, "topk_values_equal": True, "topk_ids_equal": True, "concept_db_equal": True}
+    for name in LAYERS:
+        am = cv.actmax_cache.cache[name]
+        out["topk_values_equal"] &= bool(np.array_equal(am.activations.view(torch.int16).numpy().view(np.uint16), refs[name].vals))
+        out["topk_ids_equal"] &= bool(np.array_equal(am.sample_ids.numpy(), refs[name].ids))
+        out["concept_db_equal"] &= bool(np.array_equal(db[name].cpu().numpy(), oracle.gather_rows(emb_all, refs[name].ids)))
+    out["note"] = ("rank 0 replays every rank's batch on its own GPU under oracle taps; a False here with `True` at one rank means the "
+                   "probed model's forward / the encoder is not bit-reproducible across devices, not that the merge is wrong")
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves — one process per GPU, backend
     nccl (= RCCL) — by re-executing this file under torch.distributed.run on a free local port.  Rank 0 prints the ONE JSON
@@ -956,6 +1010,9 @@ def main():
                   "workload": "the same job (collect + embed + merge + concept_db gather) over --strong-images samples in total, "
                               "contiguous shards of ceil(N / ranks) samples (distributed.shard_range), global sample ids"}
 
+    shard_chk = None
+    if sharded and not args.no_self_check:
+        shard_chk = sharded_check(dev, model, fm, args, rank, world)
     if rank != 0:
         if sharded:
             sld.destroy_native_comms()
@@ -1030,6 +1087,8 @@ def main():
         },
     }
     single = world == 1
+    if shard_chk is not None:
+        line["sharded_check"] = shard_chk
     if strong is not None:
         # the N = 1 figure the speed-up is taken against: measured by THIS command at --gpus 1 (its own `strong_scaling`
         # object; committed copy of the round's run: profiles/strong_scaling_n1.json)

@@ -311,6 +311,7 @@ def test_bench_distributed_path_over_rccl_on_one_gpu():
                                                         "--min-warmup-seconds", "0.3", "--quick"], 1)
     assert line["n_gpus"] == 1 and line["config"]["collectives"].startswith("libsemanticlens_hip.so (RCCL behind the C ABI)")
     assert line["config"]["rccl_world_size"] == 1 and line["config"]["tie_mode"] == "total"
+    assert all(line["sharded_check"][k_] for k_ in ("topk_values_equal", "topk_ids_equal", "concept_db_equal"))
     assert line["config"]["images_total"] == 2 * 2 * 64 and line["value"] > 0 and line["self_check"] == "ok"
     line = _bench_line({"SL_BENCH_FORCE_DIST": "1", "SL_COLLECTIVES": "torch"}, ["--steps", "1", "--batches-per-step", "2", "--warmup", "1",
                                                                                  "--batch", "64", "--min-warmup-seconds", "0", "--quick"], 1)
@@ -337,6 +338,8 @@ def test_bench_launches_its_own_ranks():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["images_total"] == 2 * 2 * 2 * 64
     assert line["config"]["tie_mode"] == "total" and line["config"]["process_group"] == {"backend": "gloo", "world_size": 2}
+    chk = line["sharded_check"]  # two ranks' batches merged across the (gloo) wire == the oracle's replay on rank 0
+    assert chk["ranks"] == 2 and chk["images"] == 128 and chk["topk_values_equal"] and chk["topk_ids_equal"] and chk["concept_db_equal"], chk
     st = line["strong_scaling"]
     assert st["images"] == 333 and st["n_gpus"] == 2 and st["images_per_gpu"] == 167 and st["seconds"] > 0
     # without the test switch a box with fewer GPUs than ranks is refused, loudly
