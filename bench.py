@@ -486,6 +486,17 @@ def probing_leg(dev):
     }
 
 
+def policy_report(cv):
+    """Per hooked layer: which cache policy its reduce settled on (N.ReducePolicyTuner: 'default' = inputs below 256 MiB and the last
+    240 MiB of larger ones with the default policy; 'nt>=96MiB,tail80MiB' = what outputs of residual adds want)."""
+    names = {None: "not tuned (input below 96 MiB, or policy set by the caller)", 0: "default", 1: "nt>=96MiB,tail80MiB"}
+    out = {}
+    for name in cv.layer_names:
+        t = cv.actmax_cache.cache[name]._policy_tuner
+        out[name] = names.get(getattr(t, "choice", None), "measuring") if t is not None and getattr(t, "_key", None) is not None else names[None]
+    return out
+
+
 def collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, cast=None, check_n=None, overlap=None, keep_db=None):
     """A short run of the same step on another probed model / aggregator / activation dtype, so that the reduce kernel that
     configuration selects gets its own driver-measured roofline object (algorithmic bytes / per-dispatch HIP-event time, as
@@ -501,9 +512,10 @@ def collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, c
 
 
 def _collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, cast, check_n, keep_db=None):
-    warm = [synth.synth_images_u8(torch.arange(10**7 + i * B, 10**7 + (i + 1) * B, device=dev)) for i in range(2)]
-    cv_w = make_cv(model, 2 * B, args.k, args.tie_mode, layers, agg)
-    finish_job(cv_w, run_steps(cv_w, fm, warm, 0, 2 * B, cast), 0, 2 * B, False)  # MIOpen / hipBLASLt pick their kernels
+    # MIOpen / hipBLASLt pick their kernels, and each hooked layer's reduce settles its cache policy (N.ReducePolicyTuner: 8 launches)
+    warm = [synth.synth_images_u8(torch.arange(10**7 + (i % 2) * B, 10**7 + (i % 2 + 1) * B, device=dev)) for i in range(2)] * 5
+    cv_w = make_cv(model, 10 * B, args.k, args.tie_mode, layers, agg)
+    finish_job(cv_w, run_steps(cv_w, fm, warm, 0, 10 * B, cast), 0, 10 * B, False)
     batches = [synth.synth_images_u8(torch.arange(s * B, (s + 1) * B, device=dev)) for s in range(steps)]
     n = steps * B
     cv = make_cv(model, n, args.k, args.tie_mode, layers, agg)
@@ -522,7 +534,7 @@ def _collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, 
     del db
     gbps = nbytes / ms / 1e6 if ms else None
     out = {
-        "workload": workload, "images_per_s": n / dt, "steps": steps, "batch": B,
+        "workload": workload, "images_per_s": n / dt, "steps": steps, "batch": B, "reduce_cache_policy": policy_report(cv),
         "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": gbps / HBM_PEAK_GBPS if gbps else None, "traffic": None, "kernel": kernel, "launches": launches,
                      "avg_launch_us": ms / max(launches, 1) * 1e3, "algorithmic_bytes_per_launch": nbytes / max(launches, 1),
@@ -964,9 +976,12 @@ def main():
 
     assert n_local > 0, "every rank needs at least one sample (--images >= --gpus)"
 
+    last_cv = [None]
+
     def timed_job(fm_used, batches, n_total, n_local, model_=None, id_start_=None, tie_mode=None, prof=True):
         """One complete job between barriers: collect + embed over `batches`, flush / cross-rank merge, concept_db gather."""
         cv_ = make_cv(model_ or model, n_total, args.k, tie_mode or args.tie_mode)
+        last_cv[0] = cv_
         ids0 = id_start if id_start_ is None else id_start_
         N.prof_enable(prof)
         N.prof_reset()
@@ -982,6 +997,7 @@ def main():
         return time.perf_counter() - t0_, db_
 
     elapsed, concept_db = timed_job(fm, batches, n_total, n_local)
+    headline_policy = policy_report(last_cv[0])
     red_ms, red_n, red_bytes = N.prof_read(N.SL_PROF_REDUCE)
     mrg_ms, mrg_n, _ = N.prof_read(N.SL_PROF_MERGE)
     gat_ms, gat_n, _ = N.prof_read(N.SL_PROF_GATHER)
@@ -1076,7 +1092,7 @@ def main():
             "traffic_source": "profiles/roofline_traffic.json (separate rocprofv3 --pmc passes of this command)" if traffic else None,
             "kernel": "rowreduce (K1, activation spatial-max -> bf16 candidates)",
             "launches": red_n, "avg_launch_us": red_ms / max(red_n, 1) * 1e3,
-            "algorithmic_bytes_per_launch": red_bytes / max(red_n, 1),
+            "algorithmic_bytes_per_launch": red_bytes / max(red_n, 1), "reduce_cache_policy": headline_policy,
             "condition": "in-pipeline: inputs written by the model's last kernel microseconds earlier, encoder running on "
                          "a second stream" if args.overlap else "in-pipeline, single stream",
         },

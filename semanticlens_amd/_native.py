@@ -475,11 +475,113 @@ def similarity(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def set_reduce_policy(nt_min_bytes: int | None = None, tail_bytes: int | None = None):
-    """Cache policy of K1's row streams (include/semanticlens_amd.h ``sl_set_reduce_policy``): ``(0, 0)`` reads everything
-    with the read-once policy (cold inputs), ``None`` restores the defaults (inputs just written by the previous kernel)."""
+_policy_explicit = False  # the caller chose a cache policy (set_reduce_policy or the environment): the tuner keeps out
+
+
+def _set_reduce_policy_raw(nt_min_bytes, tail_bytes):
     _check(lib().sl_set_reduce_policy(-1 if nt_min_bytes is None else int(nt_min_bytes),
                                       -1 if tail_bytes is None else int(tail_bytes)), "sl_set_reduce_policy")
+
+
+def set_reduce_policy(nt_min_bytes: int | None = None, tail_bytes: int | None = None):
+    """Cache policy of K1's row streams (include/semanticlens_amd.h ``sl_set_reduce_policy``): ``(0, 0)`` reads everything
+    with the read-once policy (cold inputs), ``None`` restores the defaults (inputs just written by the previous kernel).
+    An explicit choice also switches the per-layer :class:`ReducePolicyTuner` of the collect hooks off."""
+    global _policy_explicit
+    _policy_explicit = nt_min_bytes is not None or tail_bytes is not None
+    _set_reduce_policy_raw(nt_min_bytes, tail_bytes)
+
+
+def reduce_policy_is_explicit() -> bool:
+    return _policy_explicit or "SL_NT_MIN_BYTES" in os.environ or "SL_REDUCE_TAIL_MB" in os.environ
+
+
+class ReducePolicyTuner:
+    """Which cache policy a hooked layer's reduce should read its input with — measured, per layer, on the first batches.
+
+    The reduce kernels cannot know their producer.  The library default (inputs below 256 MiB and the last 240 MiB of larger
+    ones with the default policy, the head read-once) is what a layer ending in an IN-PLACE activation wants (torchvision's
+    Bottleneck: the whole output was just re-written, so the Infinity Cache holds its tail).  A layer whose output comes out of
+    a residual ADD of two other tensors (transformer blocks, ConvNeXt) streamed three times its size through that cache: only
+    ~80 MB of the output's tail are still there, and reading 240 MiB with the default policy thrashes (ConvNeXt-L's stage
+    outputs: 0.625 of spec with the default, 0.693 with an 80 MiB tail; ViT-B/16's 155 MB block outputs 0.718 -> 0.742 with
+    nt from 96 MiB: ``profiles/r04_reduce_policy_sweep.txt``).  So each layer tries both on its first launches (one untimed +
+    ``TRIALS`` timed each, HIP events read back only once they have completed: no synchronisation) and keeps the faster;
+    results do not depend on the policy.  Off when the caller chose a policy (``set_reduce_policy`` / ``SL_NT_MIN_BYTES`` /
+    ``SL_REDUCE_TAIL_MB``) or with ``SL_REDUCE_AUTOTUNE=0``; inputs below 96 MiB are never tuned."""
+
+    CANDIDATES = ((None, None), (96 << 20, 80 << 20))  # (nt_min_bytes, tail_bytes); None = the library default
+    MIN_BYTES = 96 << 20
+    TRIALS = 3
+
+    def __init__(self):
+        self.choice = None
+        self._key = None
+        self._calls = 0
+        self._samples = [[] for _ in self.CANDIDATES]
+        self._pending = []
+
+    @staticmethod
+    def enabled() -> bool:
+        return os.environ.get("SL_REDUCE_AUTOTUNE", "1") != "0" and not reduce_policy_is_explicit()
+
+    def run(self, launch, nbytes: int, batch: int):
+        """``launch()`` enqueues the reduce on the current stream; called under the candidate / chosen policy."""
+        if nbytes < self.MIN_BYTES or batch <= 0 or not self.enabled():
+            return launch()
+        key = nbytes // batch
+        if key != self._key:  # another layer shape behind the same hook: start over
+            self.__init__()
+            self._key = key
+        if self.choice is not None:
+            if self.choice == 0:
+                return launch()
+            _set_reduce_policy_raw(*self.CANDIDATES[self.choice])
+            try:
+                return launch()
+            finally:
+                _set_reduce_policy_raw(None, None)
+        idx = self._calls % len(self.CANDIDATES)
+        timed = self._calls >= len(self.CANDIDATES)  # the first launch of each candidate also pays first-use costs
+        self._calls += 1
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        _set_reduce_policy_raw(*self.CANDIDATES[idx])
+        try:
+            e0.record()
+            out = launch()
+            e1.record()
+        finally:
+            _set_reduce_policy_raw(None, None)
+        if timed:
+            self._pending.append((idx, e0, e1, nbytes))
+        self._harvest()
+        return out
+
+    _registry: dict = {}
+
+    @classmethod
+    def for_site(cls, key) -> "ReducePolicyTuner":
+        """The tuner of one call site (a hooked module): kept for the life of the process, so a second visualizer over the same
+        model does not measure again."""
+        t = cls._registry.get(key)
+        if t is None:
+            t = cls._registry[key] = cls()
+        return t
+
+    def _harvest(self):
+        keep = []
+        for idx, e0, e1, nbytes in self._pending:
+            if e1.query():
+                self._samples[idx].append(e0.elapsed_time(e1) / nbytes)
+            else:
+                keep.append((idx, e0, e1, nbytes))
+        self._pending = keep
+        if all(len(s_) >= self.TRIALS for s_ in self._samples):
+            med = [sorted(s_)[len(s_) // 2] for s_ in self._samples]
+            best = min(range(len(med)), key=med.__getitem__)
+            self.choice = best if med[best] < 0.98 * med[0] else 0  # the default unless another is clearly faster
+            self.medians_ns_per_mb = [m * 1e12 for m in med]  # ms per byte -> ns per MB
+            self._pending = []
 
 
 def set_gemm_mode(mode: str | None):

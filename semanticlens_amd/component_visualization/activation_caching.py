@@ -79,6 +79,7 @@ class ActMax:
         self._dev_ids: torch.Tensor | None = None  # (C,k) int64 in HBM
         self._dev_newer = False
         self._ring: torch.Tensor | None = None  # (slots, Bcap, C) bf16 candidate batches awaiting a merge
+        self._policy_tuner = None  # N.ReducePolicyTuner of this layer's reduce (created on the first fused collect)
         self._pending: list[tuple[int, int]] = []  # (id_base, rows) per queued slot
         self._ws: torch.Tensor | None = None
         if n_latents is not None:
@@ -167,8 +168,9 @@ class ActMax:
         N.actmax_update(vals, ids, cand, sid, 0, B, N.TIE_MODES[self.tie_mode], self._aten_ws(B, a.device))
         self._dev_newer = True
 
-    def collect(self, outs: torch.Tensor, native: tuple, id_base: int):
-        """Fused hook path: reduce ``outs`` on the device and merge; samples get ids id_base + b."""
+    def collect(self, outs: torch.Tensor, native: tuple, id_base: int, site=None):
+        """Fused hook path: reduce ``outs`` on the device and merge; samples get ids id_base + b.  ``site``: what identifies the
+        producer of ``outs`` (the hooked module), for the cache-policy tuner of its reduce."""
         kind, code, pos = native
         x = N.to_device(outs.detach())
         B = x.shape[0]
@@ -187,10 +189,12 @@ class ActMax:
             self._ring = torch.empty((slots, B, C), dtype=torch.bfloat16, device=x.device)
         slot = self._ring[len(self._pending)]
         cand = slot[:B]
+        if self._policy_tuner is None:
+            self._policy_tuner = N.ReducePolicyTuner.for_site(site) if site is not None else N.ReducePolicyTuner()
         if kind == "conv":
-            N.reduce_conv(x, code, cand, None)
+            self._policy_tuner.run(lambda: N.reduce_conv(x, code, cand, None), x.numel() * x.element_size(), B)
         else:
-            N.reduce_tokens(x, code, pos, cand, None)
+            self._policy_tuner.run(lambda: N.reduce_tokens(x, code, pos, cand, None), x.numel() * x.element_size(), B)
         if self.tie_mode == "aten":
             N.actmax_update(vals, ids, cand, None, id_base, B, N.SL_TIES_ATEN, self._aten_ws(B, x.device))
             self._dev_newer = True
@@ -337,7 +341,7 @@ class ActMaxCache(ActCache):
                     raise ValueError(f"Input tensor should be {want}D. \n" + aggregators._ERROR_MESSAGE)
                 batch_size = outs.shape[0]
                 self.sample_idx_counter[layer_name] += batch_size
-                self.cache[layer_name].collect(outs, native, start)
+                self.cache[layer_name].collect(outs, native, start, site=(id(module), layer_name))
                 return
             # user-defined aggregator: (B, C) tensor on any device, then K3 alone
             aggregated_acts = self.aggregation_fn(outs)

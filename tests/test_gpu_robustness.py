@@ -108,3 +108,45 @@ def test_tuple_outputs_raise_like_the_reference():
     cache = ActMaxCache(["0"], agg.aggregate_conv_max, n_collect=3)
     with pytest.raises(AttributeError), cache.hook_context(model):
         model(torch.randn(2, 3, 4, 4, device=DEV))
+
+
+def test_reduce_policy_tuner_settles_per_layer_and_changes_no_result(monkeypatch):
+    """The per-layer cache-policy tuner of the collect hooks (`N.ReducePolicyTuner`): a 155 MB token activation is reduced under
+    both candidate policies on its first launches, a choice is made without any host synchronisation, and the top-k state equals
+    the one collected with the tuner off, bit for bit."""
+    import numpy as np
+    import torch
+
+    from semanticlens_amd import _native as N
+    from semanticlens_amd.component_visualization import aggregators
+    from semanticlens_amd.component_visualization.activation_caching import ActMaxCache
+
+    class Add(torch.nn.Module):  # output = residual add of two other tensors, like a transformer block
+        def forward(self, x):
+            return x + 0.25 * x.flip(1)
+
+    def collect(autotune):
+        monkeypatch.setenv("SL_REDUCE_AUTOTUNE", "1" if autotune else "0")
+        N.ReducePolicyTuner._registry.clear()
+        model = torch.nn.Sequential(Add()).to("cuda:0")
+        cache = ActMaxCache(["0"], aggregators.aggregate_transformer_max, n_collect=7, tie_mode="aten")
+        g = torch.Generator(device="cuda:0").manual_seed(3)
+        with torch.no_grad(), cache.hook_context(model):
+            for _ in range(10):
+                model(torch.randn(256, 197, 768, device="cuda:0", generator=g))
+        torch.cuda.synchronize()
+        am = cache.cache["0"]
+        return am.activations.view(torch.int16).numpy().copy(), am.sample_ids.numpy().copy(), am._policy_tuner
+
+    v1, i1, t1 = collect(True)
+    assert t1.choice in (0, 1) and len(t1.medians_ns_per_mb) == 2 and all(m > 0 for m in t1.medians_ns_per_mb)
+    v0, i0, t0 = collect(False)
+    assert t0.choice is None
+    assert np.array_equal(v1, v0) and np.array_equal(i1, i0)
+    # an explicit policy keeps the tuner out
+    N.set_reduce_policy(0, 0)
+    try:
+        _, _, t2 = collect(True)
+        assert t2.choice is None
+    finally:
+        N.set_reduce_policy(None, None)
