@@ -20,4 +20,4 @@ model = synth.convnext_l().to(dev)
 bench.OVERLAP = len(sys.argv) > 1 and sys.argv[1] == "1"
 out = bench.collect_leg(dev, fm, args, model, [f"stages.{i}" for i in range(4)], aggregators.aggregate_conv_max, "colreduce2", "cfg4", steps=6, B=256)
 r = out["roofline"]
-print(f"overlap={bench.OVERLAP}: {out['images_per_s']:.0f} images/s, K1 avg {r['avg_launch_us']:.1f} us = {r['frac']:.3f} ({r['launches']} launches)", flush=True)
+print(f"overlap={bench.OVERLAP}: {out['images_per_s']:.0f} images/s, K1 avg {r['avg_launch_us']:.1f} us = {r['frac']:.3f} ({r['launches']} launches) policy {sorted(set(out.get('reduce_cache_policy', {}).values()))}", flush=True)

@@ -22,4 +22,4 @@ for overlap in ([True, False] if len(sys.argv) < 2 else [sys.argv[1] == "1"]):
     out = bench.collect_leg(dev, fm, args, vit, [f"blocks.{i}" for i in range(12)], aggregators.aggregate_transformer_max,
                             "colreduce", "tokens", steps=8, B=256)
     r = out["roofline"]
-    print(f"overlap={overlap}: {out['images_per_s']:.0f} images/s, K2 avg {r['avg_launch_us']:.1f} us = {r['frac']:.3f} ({r['launches']} launches)", flush=True)
+    print(f"overlap={overlap}: {out['images_per_s']:.0f} images/s, K2 avg {r['avg_launch_us']:.1f} us = {r['frac']:.3f} ({r['launches']} launches) policy {sorted(set(out.get('reduce_cache_policy', {}).values()))}", flush=True)
