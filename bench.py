@@ -784,23 +784,19 @@ def cpu_baseline_scores(threads_best: int):
 @torch.no_grad()
 def sharded_check(dev, model, fm, args, rank, world):
     """Multi-rank parity inside the measured run (never fatal: differences are REPORTED in the line).  Every rank collects one batch of
-    `--batch` images (ids rank*B .. rank*B + B - 1) and takes part in the cross-rank merge + sharded gather; rank 0 then replays all
-    world*B images on its own GPU under oracle taps (total order) and compares the merged top-k bits, ids and the concept_db it holds
-    with the oracle's — the check `self_check` performs at N = 1, across the wire."""
+    `--batch` images (ids rank*B .. rank*B + B - 1) with oracle taps on its own forward pass (what `self_check` does at N = 1: the same
+    device activations go through the product's hooks and through the oracle's aggregate + ActMax), then takes part in the cross-rank merge
+    and the sharded gather.  The per-rank ORACLE states and embeddings travel to rank 0 as host objects; rank 0 merges them with the oracle's
+    own `merge_states` / `gather_rows` and compares with the merged top-k bits, ids and concept_db the product holds — the merge and the
+    gather across the wire against the CPU restatement, with no forward pass replayed (MIOpen is not run-to-run deterministic at every batch size)."""
     import numpy as np
+
+    import oracle  # the checker — never on the product path
 
     B = args.batch
     n = world * B
     cv = make_cv(model, n, args.k, "total")
-    mine = [synth.synth_images_u8(torch.arange(rank * B, (rank + 1) * B, device=dev))]
-    emb = run_steps(cv, fm, mine, rank * B, B)
-    db = finish_job(cv, emb, rank * B, n, True)
-    torch.cuda.synchronize()
-    if rank != 0:
-        return None
-    import oracle  # the checker — rank 0 only, never on the product path
-
-    refs, seen = {}, {name: 0 for name in LAYERS}
+    refs, seen = {}, {name: rank * B for name in LAYERS}
 
     def tap(name):
         def fn(m, i, o):
@@ -814,24 +810,31 @@ def sharded_check(dev, model, fm, args, rank, world):
 
     modules = dict(model.named_modules())
     taps = [modules[name].register_forward_hook(tap(name)) for name in LAYERS]
-    embeds = []
     try:
-        for r in range(world):
-            u8 = synth.synth_images_u8(torch.arange(r * B, (r + 1) * B, device=dev))
-            model(synth.normalize_u8(u8, synth.IMAGENET_MEAN, synth.IMAGENET_STD))
-            embeds.append(fm.encode_image(fm.preprocess(u8)).float().cpu().numpy())
+        mine = [synth.synth_images_u8(torch.arange(rank * B, (rank + 1) * B, device=dev))]
+        emb = run_steps(cv, fm, mine, rank * B, B)
     finally:
         for h in taps:
             h.remove()
-    emb_all = np.concatenate(embeds)
+    db = finish_job(cv, emb, rank * B, n, True)
+    torch.cuda.synchronize()
+    payload = ({name: (refs[name].vals.copy(), refs[name].ids.copy()) for name in LAYERS}, emb.float().cpu().numpy())
+    gathered = [None] * world
+    dist.all_gather_object(gathered, payload)
+    if rank != 0:
+        return None
+    emb_all = np.concatenate([g[1] for g in gathered])
     out = {"images": n, "ranks": world, "topk_values_equal": True, "topk_ids_equal": True, "concept_db_equal": True}
     for name in LAYERS:
+        ref = refs[name]
+        if world > 1:
+            ref.merge_states(np.stack([gathered[r][0][name][0] for r in range(1, world)]), np.stack([gathered[r][0][name][1] for r in range(1, world)]))
         am = cv.actmax_cache.cache[name]
-        out["topk_values_equal"] &= bool(np.array_equal(am.activations.view(torch.int16).numpy().view(np.uint16), refs[name].vals))
-        out["topk_ids_equal"] &= bool(np.array_equal(am.sample_ids.numpy(), refs[name].ids))
-        out["concept_db_equal"] &= bool(np.array_equal(db[name].cpu().numpy(), oracle.gather_rows(emb_all, refs[name].ids)))
-    out["note"] = ("rank 0 replays every rank's batch on its own GPU under oracle taps; a False here with `True` at one rank means the "
-                   "probed model's forward / the encoder is not bit-reproducible across devices, not that the merge is wrong")
+        out["topk_values_equal"] &= bool(np.array_equal(am.activations.view(torch.int16).numpy().view(np.uint16), ref.vals))
+        out["topk_ids_equal"] &= bool(np.array_equal(am.sample_ids.numpy(), ref.ids))
+        out["concept_db_equal"] &= bool(np.array_equal(db[name].cpu().numpy(), oracle.gather_rows(emb_all, ref.ids)))
+    out["note"] = ("per-rank oracle states (taps on each rank's own forward) merged by the oracle on rank 0 against the product's "
+                   "all-gathered + K4-merged states and its sharded gather")
     return out
 
 
@@ -878,6 +881,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sharded = world > 1 or os.environ.get("SL_BENCH_FORCE_DIST") == "1"
+    if sharded and "RANK" not in os.environ:  # SL_BENCH_FORCE_DIST without a launcher: a one-rank group on a free local port
+        import socket
+
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if sharded:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
