@@ -838,6 +838,28 @@ def sharded_check(dev, model, fm, args, rank, world):
     return out
 
 
+class _quiet_stdout:
+    """File descriptor 1 points at stderr while this is active (and C stdio is flushed on both sides): RCCL prints a version banner
+    with printf when a communicator comes up, and the contract is ONE JSON line on stdout."""
+
+    def __enter__(self):
+        import ctypes
+
+        self._libc = ctypes.CDLL(None)
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def self_launch(args):
     """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves — one process per GPU, backend
     nccl (= RCCL) — by re-executing this file under torch.distributed.run on a free local port.  Rank 0 prints the ONE JSON
@@ -889,10 +911,11 @@ def main():
             port = sock.getsockname()[1]
         os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if sharded:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        with _quiet_stdout():
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if args.tie_mode is None:
         # one GPU: the reference's own tie order, so that "top-k indices bit-exact vs the reference" and the throughput figure
@@ -900,7 +923,13 @@ def main():
         args.tie_mode = "total" if (world > 1 or sharded) else "aten"
     if sharded and args.tie_mode != "total":
         raise SystemExit("a sharded build needs --tie-mode total (distributed.run_sharded)")
-    comm = sld.native_comm(None, dev) if sharded else None  # the library's own RCCL communicator (None under gloo / SL_COLLECTIVES=torch)
+    comm = None  # the library's own RCCL communicator (None under gloo / SL_COLLECTIVES=torch)
+    if sharded:
+        with _quiet_stdout():
+            comm = sld.native_comm(None, dev)
+            if comm is not None:  # bring the communicator all the way up here (RCCL prints its banner on first use)
+                comm.allreduce(torch.zeros(1, dtype=torch.float64, device=dev), "max")
+                torch.cuda.synchronize()
 
     def all_max(x: float) -> float:
         """max over ranks of one host double (timing, warm-up decision)"""
@@ -1041,8 +1070,9 @@ def main():
         shard_chk = sharded_check(dev, model, fm, args, rank, world)
     if rank != 0:
         if sharded:
-            sld.destroy_native_comms()
-            dist.destroy_process_group()
+            with _quiet_stdout():
+                sld.destroy_native_comms()
+                dist.destroy_process_group()
         return
 
     traffic = None
@@ -1214,10 +1244,12 @@ def main():
         torch.manual_seed(0)
         line["cpu_baseline"] = cpu_baseline(args, synth.resnet50(), synth.SyntheticClip(device="cpu"))
         line["cpu_baseline"]["scores_and_probing"] = cpu_baseline_scores(line["cpu_baseline"]["threads"])
+    if sharded:  # everything that may print comes down BEFORE the line: the JSON is the last thing on stdout
+        with _quiet_stdout():
+            sld.destroy_native_comms()
+            dist.destroy_process_group()
     print(json.dumps(line), flush=True)
-    if sharded:
-        sld.destroy_native_comms()
-        dist.destroy_process_group()
+    os.dup2(2, 1)  # whatever a library prints at exit goes to stderr
 
 
 if __name__ == "__main__":
