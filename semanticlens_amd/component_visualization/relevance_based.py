@@ -211,14 +211,18 @@ class RelevanceComponentVisualizer(ActivationComponentVisualizer):
         return self._run(batch_size=batch_size, num_workers=num_workers)
 
     def _run(self, batch_size: int = 32, num_workers: int = 0, sample_range=None):
-        if sample_range is not None:
-            raise NotImplementedError("the relevance visualizer collects the whole dataset in one process")
+        """One forward + attribution backward per batch over the dataset, or — ``sample_range = (start, stop)``, what
+        ``distributed.run_sharded`` passes — over one rank's contiguous shard with GLOBAL sample ids (no cache files are written
+        for a shard; rank 0 stores the merged states)."""
         for cache in (self.actmax_cache, self.activation_cache):  # fresh states, whatever the constructor loaded
             for name in self.layer_names:
                 old = cache.cache[name]
                 cache.cache[name] = type(old)(n_collect=old.n_collect, tie_mode=old.tie_mode, init_value=old.init_value)
-        loader = torch.utils.data.DataLoader(self.dataset, batch_size=batch_size, shuffle=False, num_workers=num_workers)
-        start = 0
+        dataset, start = self.dataset, 0
+        if sample_range is not None:
+            start, stop = sample_range
+            dataset = torch.utils.data.Subset(self.dataset, range(start, stop))
+        loader = torch.utils.data.DataLoader(dataset, batch_size=batch_size, shuffle=False, num_workers=num_workers)
         for images, labels in tqdm(loader, total=len(loader), desc="Collecting relevance"):
             images = images.to(self.device, non_blocking=True)
             targets = torch.as_tensor(labels).to(self.device) if self.use_labels else None
@@ -234,7 +238,7 @@ class RelevanceComponentVisualizer(ActivationComponentVisualizer):
                 act, rel = per_layer[name]
                 self.collect_relevance(name, act, rel, ids)
             start += images.shape[0]
-        if self._cache_root:
+        if self._cache_root and sample_range is None:
             self.actmax_cache.store(self.storage_dir)
             self.activation_cache.store(self.storage_dir)
         return self.actmax_cache.cache

@@ -201,22 +201,28 @@ def run_sharded(cv, batch_size: int = 64, num_workers: int = 0, group=None):
     if cv.actmax_cache.tie_mode != "total":
         raise ValueError("sharded collection requires tie_mode='total'")
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    # a RelevanceComponentVisualizer keeps a second set of states (crp's activation mode): collected, merged and stored alike
+    caches = [cv.actmax_cache] + ([cv.activation_cache] if hasattr(cv, "activation_cache") else [])
     if cv.caching:
         try:
-            cv.actmax_cache.load(cv.storage_dir)
+            for cache in caches:
+                cache.load(cv.storage_dir)
             hit = 1
         except FileNotFoundError:
             hit = 0
         if _all_reduce_host_ints([hit], dist.ReduceOp.MIN, group, cv.device)[0]:
             return cv.actmax_cache.cache
-    for name in cv.layer_names:  # fresh states, whatever the constructor loaded
-        old = cv.actmax_cache.cache[name]
-        cv.actmax_cache.cache[name] = type(old)(n_collect=old.n_collect, tie_mode=old.tie_mode, init_value=old.init_value)
+    for cache in caches:
+        for name in cv.layer_names:  # fresh states, whatever the constructor loaded
+            old = cache.cache[name]
+            cache.cache[name] = type(old)(n_collect=old.n_collect, tie_mode=old.tie_mode, init_value=old.init_value)
     cv._run(batch_size=batch_size, num_workers=num_workers, sample_range=shard_range(len(cv.dataset), rank, world))
-    merge_actmax_cache(cv.actmax_cache, group, cv.device)
+    for cache in caches:
+        merge_actmax_cache(cache, group, cv.device)
     if cv.caching:
         if rank == 0:
-            cv.actmax_cache.store(cv.storage_dir)
+            for cache in caches:
+                cache.store(cv.storage_dir)
         dist.barrier(group=group)
     return cv.actmax_cache.cache
 

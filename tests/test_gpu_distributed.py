@@ -483,3 +483,53 @@ def test_torch_collectives_remain_selectable(tmp_path, monkeypatch):
     got = np.load(tmp_path / "nccl1.npz")
     for k in ("0", "2"):
         assert np.array_equal(got[f"db_{k}"], want[k].numpy()), k
+
+
+# ---- configs[4] names 8 GPUs: the relevance visualizer sharded (both crp states merged across ranks) -------------------------------
+def _relevance_cv(device="cuda:0", cache_dir=None):
+    from helpers import FakeVLM, TensorPairDataset
+    from semanticlens_amd.component_visualization import RelevanceComponentVisualizer
+    from test_gpu_relevance import _IntNet, _small_images
+
+    ds = TensorPairDataset(_small_images(29), name="int29")  # 29: shards of unequal size
+    cv = RelevanceComponentVisualizer(_IntNet().to(device), ds, ds, ["relu1", "relu2"], num_samples=4, tie_mode="total", cache_dir=cache_dir,
+                                      composite="gradient_x_activation", device=device)
+    return cv, FakeVLM().to(device)
+
+
+def _relevance_worker(rank, world, port, out_dir):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(__file__))
+    from semanticlens_amd import distributed as sld
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cv, fm = _relevance_cv()
+        db = sld.compute_concept_db_sharded(cv, fm, batch_size=4)
+        np.savez(os.path.join(out_dir, f"rel_w{world}_r{rank}.npz"), **{f"db_{k}": v.cpu().numpy() for k, v in db.items()},
+                 **{f"rel_{k}": cv.get_max_reference(k).numpy() for k in db}, **{f"act_{k}": cv.get_act_max_sample_ids(k).numpy() for k in db},
+                 **{f"relv_{k}": cv.actmax_cache.cache[k].activations.view(torch.int16).numpy() for k in db})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_relevance_build_equals_single_process(world, tmp_path):
+    """`RelevanceComponentVisualizer` under `distributed.compute_concept_db_sharded`: each rank attributes its shard (global ids), both
+    states of every layer — relevance mode and activation mode — are merged across ranks, the concept_db is gathered sharded."""
+    sys_path = os.path.dirname(__file__)
+    import sys
+
+    sys.path.insert(0, sys_path)
+    cv, fm = _relevance_cv()
+    want = cv._compute_concept_db(fm, batch_size=4)
+    mp.spawn(_relevance_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        got = np.load(tmp_path / f"rel_w{world}_r{r}.npz")
+        for k in ("relu1", "relu2"):
+            assert np.array_equal(got[f"rel_{k}"], cv.get_max_reference(k).numpy()), (world, r, k)
+            assert np.array_equal(got[f"act_{k}"], cv.get_act_max_sample_ids(k).numpy()), (world, r, k)
+            assert np.array_equal(got[f"relv_{k}"], cv.actmax_cache.cache[k].activations.view(torch.int16).numpy()), (world, r, k)
+            assert np.array_equal(got[f"db_{k}"], want[k].numpy()), (world, r, k)
