@@ -487,12 +487,13 @@ def test_torch_collectives_remain_selectable(tmp_path, monkeypatch):
 
 # ---- configs[4] names 8 GPUs: the relevance visualizer sharded (both crp states merged across ranks) -------------------------------
 def _relevance_cv(device="cuda:0", cache_dir=None):
-    from helpers import FakeVLM, TensorPairDataset
+    from helpers import FakeVLM, TensorPairDataset, make_int_images
     from semanticlens_amd.component_visualization import RelevanceComponentVisualizer
     from test_gpu_relevance import _IntNet, _small_images
 
     ds = TensorPairDataset(_small_images(29), name="int29")  # 29: shards of unequal size
-    cv = RelevanceComponentVisualizer(_IntNet().to(device), ds, ds, ["relu1", "relu2"], num_samples=4, tie_mode="total", cache_dir=cache_dir,
+    ds_fm = TensorPairDataset(make_int_images(29), name="int29-fm")  # what the foundation model embeds (FakeVLM: 3 x 16 x 16)
+    cv = RelevanceComponentVisualizer(_IntNet().to(device), ds, ds_fm, ["relu1", "relu2"], num_samples=4, tie_mode="total", cache_dir=cache_dir,
                                       composite="gradient_x_activation", device=device)
     return cv, FakeVLM().to(device)
 
