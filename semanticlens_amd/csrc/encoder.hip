@@ -502,6 +502,13 @@ __device__ __forceinline__ float exp_neg(float x) {
 // SigLIP-so400m's 256 tokens ran as two rounds of four waves, which staged (converted, transposed) K and V twice per
 // workgroup and left each SIMD with ONE wave whose MFMAs and softmax VALU work serialise (253 us per layer at B = 64: 63 us per
 // workgroup, one workgroup per CU by its 97 KB of LDS); eight waves stage once and pair two waves per SIMD.
+#ifndef SL_ATTN_EXP
+#define SL_ATTN_EXP 0  // lab only (garbage results): 1 = no key-tile loop (staging + output only), 2 = no K / V global loads (compute only)
+#endif
+// Where a workgroup's life goes (so400m shape, B = 256, `tools/attn_exp_probe.py`, profiles/r04_attention_ablation.txt): 592 us per
+// layer as shipped, 251 with the key-tile loop compiled out (staging + output), 417 with the K / V global loads compiled out.
+// Staging and MFMAs do not overlap: the 97 KB of LDS and 216 registers keep ONE workgroup per CU.  Tried and dropped: pulling the
+// next chunk's (and the next workgroup's first chunk's) lines into L2 with LDS-DMA touches into a dummy area — 605 -> 648 us.
 template <int D, int MAXW>
 __global__ __launch_bounds__(64 * MAXW) void attention_bf16x3_kernel(const float* __restrict__ qkv, int T, int H, int causal, float scale,
                                                                 float* __restrict__ out, uint16_t* __restrict__ osp) {
@@ -580,7 +587,7 @@ __global__ __launch_bounds__(64 * MAXW) void attention_bf16x3_kernel(const float
             const int t = kc0 * 32 + tl0 + i;
             kv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             vv[i] = kv[i];
-            if (t < T && c * 4 < D) {
+            if (SL_ATTN_EXP != 2 && t < T && c * 4 < D) {
               kv[i] = *reinterpret_cast<const float4*>(base + t * ld + (int64_t)H * kDh + c * 4);
               vv[i] = *reinterpret_cast<const float4*>(base + t * ld + 2ll * H * kDh + c * 4);
             }
@@ -630,7 +637,7 @@ __global__ __launch_bounds__(64 * MAXW) void attention_bf16x3_kernel(const float
         }
         q_ready = true;
       }
-      const int kt_end = kc0 + kct < nkt ? kc0 + kct : nkt;
+      const int kt_end = SL_ATTN_EXP == 1 ? kc0 : (kc0 + kct < nkt ? kc0 + kct : nkt);
       for (int kt = kc0; kt < kt_end; ++kt) {
         const int kl = (kt - kc0) * 32;
         afloatx16 st;
