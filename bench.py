@@ -646,7 +646,7 @@ def config4_leg(dev, fm, args):
     def tapped(model_, modules, images, targets):
         from semanticlens_amd.component_visualization.lrp import lrp_epsilon_plus_flat
 
-        res = lrp_epsilon_plus_flat(model_, modules, images, targets, epsilon=0.1)  # 1e-6 overflows on ConvNeXt-L (relevance_based.py)
+        res = lrp_epsilon_plus_flat(model_, modules, images, targets, epsilon=0.1, norm_pass=True)  # 1e-6 overflows on ConvNeXt-L (relevance_based.py)
         if not first:
             first.update({k_: (a.detach().clone(), r.detach().clone()) for k_, (a, r) in res.items()})
         return res

@@ -142,6 +142,17 @@ def default_device() -> torch.device:
     return torch.device("cuda", torch.cuda.current_device())
 
 
+def resolve_device(device=None) -> torch.device:
+    """``device`` with its index filled in: ``"cuda"`` means the CURRENT device (the usual pattern after
+    ``torch.cuda.set_device(rank)``), so that ``tensor.device == resolve_device(...)`` holds for tensors living there."""
+    if device is None:
+        return default_device()
+    dev = torch.device(device)
+    if dev.type == "cuda" and dev.index is None:
+        return default_device()
+    return dev
+
+
 def to_device(t: torch.Tensor, device: torch.device | None = None) -> torch.Tensor:
     """Place ``t`` on a HIP device (host->device copies are plumbing, not compute)."""
     if t.is_cuda:
@@ -343,7 +354,7 @@ class Comm:
     def __init__(self, unique_id: bytes, world: int, rank: int, device=None):
         if len(unique_id) != SL_COMM_ID_BYTES:
             raise ValueError(f"an RCCL unique id is {SL_COMM_ID_BYTES} bytes, got {len(unique_id)}")
-        self.device = torch.device(device) if device is not None else default_device()
+        self.device = resolve_device(device)
         self.world, self.rank = int(world), int(rank)
         handle = _vp()
         buf = ctypes.create_string_buffer(bytes(unique_id), SL_COMM_ID_BYTES)

@@ -21,7 +21,8 @@ only gradient x activation:
   z+         ``(a+, w+, b+)`` and ``(a-, w-, 0)``                            ``nn.Conv*``
   flat       ``(1, 1)``: ``R_out`` spread evenly over the receptive field    the first linear module (module order)
   norm       ``(a,)`` through the module itself                              average pooling
-  pass       ``R_in = R_out``                                                activations, batch / layer / group norm, dropout
+  pass       ``R_in = R_out``                                                activations, batch norm, dropout (layer / group
+                                                                             norm only with ``norm_pass=True``)
   =========  ==============================================================  ==================================
 
   Max pooling and tensor additions keep PyTorch's own gradient (winner-takes-all; an un-canonised residual ``x + f(x)``
@@ -40,12 +41,15 @@ import torch
 from torch import nn
 
 _CONVS = (nn.Conv1d, nn.Conv2d, nn.Conv3d)
-# Layer / group normalisation pass relevance through like batch norm.  zennit's EpsilonPlusFlat maps only BatchNorm to `Pass` and
-# leaves nn.LayerNorm to plain autograd, whose Jacobian scales the incoming "gradient" (here: relevance) by gamma / sigma per
-# block: on ConvNeXt-L (36 LayerNorm blocks, BASELINE configs[4]) the relevance of the early stages overflows to inf / NaN
-# (tests/test_lrp.py::test_layer_norm_passes_relevance_through).  Pass-through keeps the rule set conservative and finite there.
+# zennit's EpsilonPlusFlat maps only BatchNorm to `Pass` and leaves nn.LayerNorm / nn.GroupNorm to plain autograd: that is the
+# DEFAULT here too (zennit parity; changing it changes the relevance top-k ids of every ViT / ConvNeXt).  Autograd's LayerNorm
+# Jacobian scales the incoming relevance by gamma / sigma per block, and on ConvNeXt-L (36 LayerNorm blocks, BASELINE
+# configs[4]) the relevance of the early stages overflows to inf / NaN (tests/test_lrp.py).  `norm_pass=True` is the explicit
+# opt-in that passes relevance through layer / group norm like batch norm and stays finite there; the visualizer names it in
+# its composite ("..._normpass") so cache directories of the two variants never mix.
 _PASS = (nn.ReLU, nn.ReLU6, nn.LeakyReLU, nn.ELU, nn.GELU, nn.SiLU, nn.Sigmoid, nn.Tanh, nn.Hardswish, nn.Hardtanh, nn.Softplus,
-         nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d, nn.LayerNorm, nn.GroupNorm, nn.Dropout, nn.Dropout2d, nn.Identity)
+         nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d, nn.Dropout, nn.Dropout2d, nn.Identity)
+_NORM_PASS = (nn.LayerNorm, nn.GroupNorm)
 _AVGPOOL = (nn.AvgPool1d, nn.AvgPool2d, nn.AvgPool3d, nn.AdaptiveAvgPool1d, nn.AdaptiveAvgPool2d, nn.AdaptiveAvgPool3d)
 
 
@@ -146,8 +150,9 @@ class _PassRule(torch.autograd.Function):
 
 
 @contextmanager
-def epsilon_plus_flat(model: nn.Module, epsilon: float = 1e-6, first_layer_flat: bool = True):
+def epsilon_plus_flat(model: nn.Module, epsilon: float = 1e-6, first_layer_flat: bool = True, norm_pass: bool = False):
     """While active, the backward pass of ``model`` propagates EpsilonPlusFlat relevance instead of gradients.
+    ``norm_pass=True`` (not zennit's behaviour, opt-in) also passes relevance through ``nn.LayerNorm`` / ``nn.GroupNorm``.
 
     Rules attach to leaf modules by type (table in the module docstring).  In-place activations are switched to
     out-of-place for the duration (their input is needed by the rule of the module in front of them)."""
@@ -187,7 +192,7 @@ def epsilon_plus_flat(model: nn.Module, epsilon: float = 1e-6, first_layer_flat:
             handles.append(module.register_forward_hook(hook_for("linear")))
         elif isinstance(module, _AVGPOOL):
             handles.append(module.register_forward_hook(hook_for("norm")))
-        elif isinstance(module, _PASS):
+        elif isinstance(module, _PASS) or (norm_pass and isinstance(module, _NORM_PASS)):
             handles.append(module.register_forward_hook(hook_for("pass")))
     try:
         yield
@@ -199,9 +204,10 @@ def epsilon_plus_flat(model: nn.Module, epsilon: float = 1e-6, first_layer_flat:
 
 
 def lrp_epsilon_plus_flat(model: nn.Module, layers: dict[str, nn.Module], images: torch.Tensor, targets: torch.Tensor | None,
-                          epsilon: float = 1e-6):
+                          epsilon: float = 1e-6, norm_pass: bool = False):
     """``{layer: (activation, relevance)}`` for one batch under the EpsilonPlusFlat rules, relevance started from the target
-    logit (``targets`` None = the model's own prediction).  Same contract as ``gradient_x_activation``."""
+    logit (``targets`` None = the model's own prediction).  Same contract as ``gradient_x_activation``.  ``norm_pass``: see
+    :func:`epsilon_plus_flat` (default False = zennit's rule set)."""
     kept: dict[str, torch.Tensor] = {}
 
     def keep(name):
@@ -210,7 +216,7 @@ def lrp_epsilon_plus_flat(model: nn.Module, layers: dict[str, nn.Module], images
 
         return hook
 
-    with epsilon_plus_flat(model, epsilon):
+    with epsilon_plus_flat(model, epsilon, norm_pass=norm_pass):
         # registered AFTER the rule hooks, so `out` is the tensor the rule's autograd node produced
         handles = [m.register_forward_hook(keep(n)) for n, m in layers.items()]
         try:

@@ -113,16 +113,18 @@ class RelevanceComponentVisualizer(ActivationComponentVisualizer):
 
     Parameters follow ``ActivationComponentVisualizer`` (model, the two datasets, layer names, cache directory) and the
     reference's relevance class: ``aggregation_fn`` (``"sum"``, the reference's default, or ``"max"``: crp's ``max_target``), ``abs_norm``
-    (default True), ``num_samples`` (default 100), ``composite`` (``"epsilon_plus_flat"`` — default —,
-    ``"gradient_x_activation"``, or a callable) / ``attribution`` (a callable as :func:`gradient_x_activation`; wins),
+    (default True), ``num_samples`` (default 100), ``composite`` (``"epsilon_plus_flat"`` — default, zennit's rule set —,
+    ``"epsilon_plus_flat_normpass"`` — the same with LayerNorm / GroupNorm passing relevance through, an explicit opt-in
+    that is part of the cache key —, ``"gradient_x_activation"``, or a callable) / ``attribution`` (a callable as :func:`gradient_x_activation`; wins),
     ``use_labels`` (take the targets from the dataset's labels instead of the model's prediction; crp conditions on the
     label), ``epsilon`` (stabiliser of the epsilon / z+ rules, zennit's default 1e-6).
 
     The epsilon rule divides by pre-activations of either sign; behind LayerNorm / GELU (ConvNeXt, transformers) some pass
     arbitrarily close to zero, and with the 1e-6 stabiliser relevance grows ~30x per block — inf / NaN from stage 2 of ConvNeXt-L
     upwards (zennit behaves the same: its composite leaves that to the user).  A batch with non-finite relevance raises
-    ``FloatingPointError`` instead of filling the top-k states with NaN; ``epsilon=0.1`` keeps ConvNeXt-L conservative
-    (tests/test_gpu_configs.py), ``composite="gradient_x_activation"`` is the parameter-free alternative.
+    ``FloatingPointError`` instead of filling the top-k states with NaN; ``composite="epsilon_plus_flat_normpass"`` with
+    ``epsilon=0.1`` keeps ConvNeXt-L finite (tests/test_gpu_configs.py), ``composite="gradient_x_activation"`` is the
+    parameter-free alternative.
     """
 
     def __init__(self, model: nn.Module, dataset_model, dataset_fm, layer_names, num_samples: int = 100,
@@ -137,17 +139,20 @@ class RelevanceComponentVisualizer(ActivationComponentVisualizer):
         if attribution is None:
             if callable(composite):
                 attribution = composite
-            elif composite == "epsilon_plus_flat":
+            elif composite in ("epsilon_plus_flat", "epsilon_plus_flat_normpass"):
                 from semanticlens_amd.component_visualization.lrp import lrp_epsilon_plus_flat
 
-                def attribution(model_, layers_, images_, targets_, _eps=float(epsilon)):
-                    return lrp_epsilon_plus_flat(model_, layers_, images_, targets_, epsilon=_eps)
+                normpass = composite.endswith("_normpass")  # opt-in: LayerNorm / GroupNorm pass relevance through (lrp.py)
 
-                attribution.__name__ = "lrp_epsilon_plus_flat" if epsilon == 1e-6 else f"lrp_epsilon_plus_flat_eps{epsilon:g}"
+                def attribution(model_, layers_, images_, targets_, _eps=float(epsilon), _np=normpass):
+                    return lrp_epsilon_plus_flat(model_, layers_, images_, targets_, epsilon=_eps, norm_pass=_np)
+
+                attribution.__name__ = ("lrp_" + composite) + ("" if epsilon == 1e-6 else f"_eps{epsilon:g}")
             elif composite == "gradient_x_activation":
                 attribution = gradient_x_activation
             else:
-                raise ValueError(f"composite must be 'epsilon_plus_flat', 'gradient_x_activation' or a callable, got {composite!r}")
+                raise ValueError("composite must be 'epsilon_plus_flat', 'epsilon_plus_flat_normpass', 'gradient_x_activation' "
+                                 f"or a callable, got {composite!r}")
         self.composite = getattr(attribution, "__name__", type(attribution).__name__)
         self.attribution = attribution
         self.use_labels = use_labels
@@ -233,7 +238,8 @@ class RelevanceComponentVisualizer(ActivationComponentVisualizer):
                 raise FloatingPointError(
                     f"the attribution {self.composite!r} produced inf / NaN relevance at {bad} (samples {start}..{start + images.shape[0] - 1}): "
                     "the epsilon rule is unstable on this architecture with its current stabiliser — pass a larger `epsilon` "
-                    "(e.g. 0.1) or composite='gradient_x_activation'")
+                    "(e.g. 0.1), composite='epsilon_plus_flat_normpass' (LayerNorm / GroupNorm models) or "
+                    "composite='gradient_x_activation'")
             for name in self.layer_names:
                 act, rel = per_layer[name]
                 self.collect_relevance(name, act, rel, ids)

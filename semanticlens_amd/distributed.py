@@ -35,30 +35,72 @@ import os
 from semanticlens_amd import _native as N
 
 COLLECTIVES = os.environ.get("SL_COLLECTIVES", "native")  # "native": RCCL through the C ABI; "torch": torch.distributed
-_COMMS: dict = {}
+_COMMS: list = []  # [(weakref to the ProcessGroup | None for the default group, world, rank, Comm)]
+
+
+def _group_of(entry):
+    ref = entry[0]
+    return None if ref is None else ref()
+
+
+def _prune_comms():
+    """Drop communicators whose process group is gone (``destroy_process_group`` + re-init, a freed subgroup whose id()
+    a new one could reuse): a stale RCCL communicator with the wrong world / rank would hang or give wrong results."""
+    alive = dist.is_available() and dist.is_initialized()
+    keep = []
+    for entry in _COMMS:
+        ref, world, rank, comm = entry[:4]
+        ok = alive and (ref is None or ref() is not None)
+        if ok:
+            g = _group_of(entry)
+            try:
+                ok = dist.get_world_size(g) == world and dist.get_rank(g) == rank and (g is not None or _default_pg() is entry[4])
+            except Exception:
+                ok = False
+        if ok:
+            keep.append(entry)
+        else:
+            try:
+                comm.destroy()
+            except Exception:
+                pass
+    _COMMS[:] = keep
+
+
+def _default_pg():
+    try:
+        return dist.distributed_c10d._get_default_group()
+    except Exception:
+        return None
 
 
 def native_comm(group=None, device=None):
     """The library's own RCCL communicator for ``group`` (created collectively on first use, then cached), or None when
-    the collectives go through torch.distributed (``COLLECTIVES == "torch"``, or a backend other than nccl)."""
+    the collectives go through torch.distributed (``COLLECTIVES == "torch"``, or a backend other than nccl).  The cache is
+    keyed on the group OBJECT (weak reference) and checked against its world size / rank on every lookup; an index-less
+    ``device`` ("cuda") means the current device."""
     if COLLECTIVES != "native" or dist.get_backend(group) != "nccl":
         return None
-    key = id(group) if group is not None else None
-    comm = _COMMS.get(key)
-    if comm is None:
-        rank, world = dist.get_rank(group), dist.get_world_size(group)
-        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
-        box = [N.Comm.unique_id() if rank == 0 else None]
-        src = dist.get_global_rank(group, 0) if group is not None else 0
-        dist.broadcast_object_list(box, src=src, group=group, device=dev)
-        comm = _COMMS[key] = N.Comm(box[0], world, rank, dev)
+    _prune_comms()
+    for entry in _COMMS:
+        if _group_of(entry) is group and (group is not None or entry[0] is None):
+            return entry[3]
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = N.resolve_device(device)
+    box = [N.Comm.unique_id() if rank == 0 else None]
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    dist.broadcast_object_list(box, src=src, group=group, device=dev)
+    comm = N.Comm(box[0], world, rank, dev)
+    import weakref
+
+    _COMMS.append((weakref.ref(group) if group is not None else None, world, rank, comm, _default_pg() if group is None else None))
     return comm
 
 
 def destroy_native_comms():
     """Tear down the cached communicators (before ``dist.destroy_process_group``)."""
     while _COMMS:
-        _COMMS.popitem()[1].destroy()
+        _COMMS.pop()[3].destroy()
 
 
 def shard_range(n_samples: int, rank: int, world_size: int) -> tuple[int, int]:
@@ -159,6 +201,8 @@ def merge_actmax_cache(actmax_cache, group=None, device=None):
         elif am.n_latents != width:
             raise RuntimeError(f"layer {name!r}: this rank has {am.n_latents} components, another rank {width}")
         layers.append(name)
+    if not layers:  # no rank collected anything (all widths agreed to be 0): nothing to exchange, on any rank
+        return
     states = [actmax_cache.cache[name].device_state(device) for name in layers]
     comm = native_comm(group, device)
     if comm is not None:  # pack + ncclAllGather + K4 inside the library, states updated in place
@@ -329,10 +373,12 @@ def encode_text_sharded(fm, texts: list[str], batch_size: int | None = None, gro
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     lo, hi = shard_range(len(texts), rank, world)
     local = _encode_texts(fm, texts[lo:hi], batch_size) if hi > lo else None
-    dim = torch.tensor([local.shape[1] if local is not None else 0], dtype=torch.int64, device=fm.device)
-    dist.all_reduce(dim, op=dist.ReduceOp.MAX, group=group)
+    # the width agreement goes where every other collective of this module goes: the library's own communicator under
+    # nccl (no second, torch-owned RCCL communicator), torch.distributed under gloo
+    dim = _all_reduce_host_ints([local.shape[1] if local is not None else 0], dist.ReduceOp.MAX, group,
+                                fm.device if torch.device(fm.device).type == "cuda" else None)[0]
     if local is None:
-        local = torch.empty((0, int(dim.item())), dtype=torch.float32, device=fm.device)
+        local = torch.empty((0, dim), dtype=torch.float32, device=fm.device)
     return all_gather_rows(local.to(torch.float32), len(texts), group)
 
 

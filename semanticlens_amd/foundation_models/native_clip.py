@@ -330,13 +330,15 @@ class NativeResNetVision:
         self.b_kv = torch.cat([_bias(pool.k_proj, device), _bias(pool.v_proj, device)]).contiguous()
         self.w_q, self.b_q = _f32(pool.q_proj.weight, device), _bias(pool.q_proj, device)
         self.w_c, self.b_c = _f32(pool.c_proj.weight, device), _bias(pool.c_proj, device)
-        self.split = split
-        if split:
-            self.s_kv, self.s_q, self.s_c = N.Split.of(self.w_kv), N.Split.of(self.w_q), N.Split.of(self.w_c)
+        # The head's four projections run on the fp32-MFMA GEMM (`N.linear`) in EVERY `gemm` mode.  A trunk hands the pool
+        # tokens of magnitude ~20, its softmax logits are in the hundreds, and a 3-product bf16 split (per-product relative
+        # error 2^-16..2^-17) then moves the attention weights by ~0.5 %: 1.1e-3 absolute on features of scale 22, 6x torch's
+        # own fp32 distance from float64 (round-4 driver run).  The GEMMs are (B*50) x 4096 x 2048 at most: microseconds
+        # beside the convolutional trunk, so the split buys nothing here.
+        self.split = False
+        del split
 
-    def _linear(self, x, w, sw, b):
-        if self.split:
-            return N.linear3(N.Split.of(x), sw, b)
+    def _linear(self, x, w, b):
         return N.linear(x, w, b)
 
     def trunk(self, img: torch.Tensor) -> torch.Tensor:
@@ -363,10 +365,10 @@ class NativeResNetVision:
             raise ValueError(f"trunk output {tuple(fmap.shape)} does not match the attention pool ({self.pos.shape[0] - 1} positions of width {self.width})")
         tokens = N.tokens_from_map(fmap, self.pos)  # (B, T, W), row 0 = mean token
         rows = tokens.reshape(B * T, C)
-        kv = self._linear(rows, self.w_kv, getattr(self, "s_kv", None), self.b_kv)  # (B*T, 2W)
-        q = self._linear(tokens[:, 0].contiguous(), self.w_q, getattr(self, "s_q", None), self.b_q)  # (B, W)
+        kv = self._linear(rows, self.w_kv, self.b_kv)  # (B*T, 2W)
+        q = self._linear(tokens[:, 0].contiguous(), self.w_q, self.b_q)  # (B, W)
         pooled = N.attention_pool_q(q, kv, B, T, self.heads, self.head_dim)
-        return self._linear(pooled, self.w_c, getattr(self, "s_c", None), self.b_c)
+        return self._linear(pooled, self.w_c, self.b_c)
 
 
 class NativeVisionTower:

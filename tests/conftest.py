@@ -23,3 +23,23 @@ def golden():
         return np.load(GOLDEN / f"{name}.npz", allow_pickle=False)
 
     return load
+
+
+# The driver runs `pytest tests -x -q -m gpu`: one failing assert ends the run.  The golden-fixture / oracle checks of the
+# kernels (the parity gate) therefore go FIRST and the long model-level tower / layout / relevance files last, so that a
+# tolerance assert on an encoder tower can never again keep the kernel parity suite from running (round 4: 280 tests unreached).
+_GPU_FILE_ORDER = (
+    "test_gpu_parity", "test_gpu_pipeline", "test_gpu_preprocess", "test_gpu_properties", "test_gpu_fullsize",
+    "test_gpu_config1", "test_gpu_configs", "test_gpu_robustness", "test_gpu_distributed",
+    "test_gpu_native_clip", "test_gpu_openclip_layout", "test_gpu_relevance",
+)
+
+
+def pytest_collection_modifyitems(config, items):
+    rank = {name: i for i, name in enumerate(_GPU_FILE_ORDER)}
+
+    def key(item):
+        stem = Path(str(item.fspath)).stem
+        return rank.get(stem, len(rank) if stem.startswith("test_gpu") else -1)
+
+    items.sort(key=key)  # stable: the order inside a file is kept; CPU files keep their place in front

@@ -265,7 +265,7 @@ def test_config4_full_geometry_convnext_l_collect_relevance_and_scores(monkeypat
     captured = []  # per batch: {layer: (activation, relevance)} as produced on the device
 
     def tapped(model_, modules, images, targets):
-        res = lrp.lrp_epsilon_plus_flat(model_, modules, images, targets, epsilon=0.1)  # zennit's 1e-6 overflows here, see below
+        res = lrp.lrp_epsilon_plus_flat(model_, modules, images, targets, epsilon=0.1, norm_pass=True)  # zennit's 1e-6 overflows here, see below
         captured.append({k_: (a.detach().float().cpu().numpy(), r.detach().float().cpu().numpy()) for k_, (a, r) in res.items()})
         return res
 
@@ -305,9 +305,10 @@ def test_config4_full_geometry_convnext_l_collect_relevance_and_scores(monkeypat
     with pytest.raises(FloatingPointError, match="epsilon"):
         cv_bad.run(batch_size=16)
     # ... and `epsilon=` on the visualizer is the way around it
-    cv_ok = RelevanceComponentVisualizer(model, _DeviceImages(16, "model"), _DeviceImages(16, "fm"), layers, num_samples=k, device=DEV, epsilon=0.1)
+    cv_ok = RelevanceComponentVisualizer(model, _DeviceImages(16, "model"), _DeviceImages(16, "fm"), layers, num_samples=k, device=DEV, epsilon=0.1,
+                                         composite="epsilon_plus_flat_normpass")
     cv_ok.run(batch_size=16)
-    assert cv_ok.composite == "lrp_epsilon_plus_flat_eps0.1" and all(int(cv_ok.get_max_reference(n).max()) < 16 for n in layers)
+    assert cv_ok.composite == "lrp_epsilon_plus_flat_normpass_eps0.1" and all(int(cv_ok.get_max_reference(n).max()) < 16 for n in layers)
     # (iii) scores over the whole concept_db
     dev_db = {name: v.to(DEV) for name, v in db.items()}
     cl, po = lens.eval_clarity(dev_db), lens.eval_polysemanticity(dev_db)

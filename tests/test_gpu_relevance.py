@@ -344,13 +344,15 @@ def test_epsilon_plus_flat_on_a_convnext_style_network_configs4():
     x = torch.randn(n, 3, 32, 32)
     layers = ["stage1", "stage2"]
     ds = TensorPairDataset(x, name="cnx29")
-    cv = RelevanceComponentVisualizer(model.to(DEV), ds, ds, layers, num_samples=k, tie_mode="total")
+    # LayerNorm models: the opt-in variant that passes relevance through the norms (lrp.py; the default is zennit's rule set)
+    cv = RelevanceComponentVisualizer(model.to(DEV), ds, ds, layers, num_samples=k, tie_mode="total", composite="epsilon_plus_flat_normpass")
+    assert cv.composite == "lrp_epsilon_plus_flat_normpass"
     cv.run(batch_size=bs)
     mods = {nme: m for nme, m in ref_model.named_modules() if nme in layers}
     widths = {"stage1": 8, "stage2": 16}
     want = {name: oracle.ActMaxOracle(k, widths[name], oracle.MODE_TOTAL, init_value=-np.inf) for name in layers}
     for s0 in range(0, n, bs):
-        per = lrp_epsilon_plus_flat(ref_model, mods, x[s0:s0 + bs], None)
+        per = lrp_epsilon_plus_flat(ref_model, mods, x[s0:s0 + bs], None, norm_pass=True)
         for name in layers:
             want[name].update(oracle.abs_norm_rows(oracle.agg_conv(per[name][1].numpy(), "sum")), np.arange(s0, min(n, s0 + bs)))
     for name in layers:

@@ -226,7 +226,7 @@ def test_layer_norm_passes_relevance_through():
     m = synth.ConvNeXt(depths=(2, 2, 3, 2), dims=(16, 32, 64, 128), layer_scale=1.0).eval()
     x = torch.randn(2, 3, 64, 64)
     layers = {f"stages.{i}": m.stages[i] for i in range(4)}
-    out = lrp_epsilon_plus_flat(m, layers, x, None)
+    out = lrp_epsilon_plus_flat(m, layers, x, None, norm_pass=True)
     with torch.no_grad():
         y = m(x)
     top = y.max(1).values.abs().max().item()
@@ -235,5 +235,13 @@ def test_layer_norm_passes_relevance_through():
         assert 0 < rel.abs().max().item() < 1e8 * max(top, 1.0), (name, rel.abs().max().item(), top)
     # a LayerNorm alone: relevance in == relevance out
     ln = nn.Sequential(nn.Linear(6, 6, bias=False), nn.LayerNorm(6), nn.Linear(6, 3, bias=False)).eval()
-    res = lrp_epsilon_plus_flat(ln, {"0": ln[0], "1": ln[1]}, torch.rand(4, 6) + 0.5, None)
+    xin = torch.rand(4, 6) + 0.5
+    res = lrp_epsilon_plus_flat(ln, {"0": ln[0], "1": ln[1]}, xin, None, norm_pass=True)
     assert torch.allclose(res["0"][1], res["1"][1])
+    # the DEFAULT is zennit's EpsilonPlusFlat: LayerNorm is left to autograd, so the relevance at its input is the relevance at
+    # its output pushed through the LayerNorm Jacobian (and differs from the pass-through variant)
+    res0 = lrp_epsilon_plus_flat(ln, {"0": ln[0], "1": ln[1]}, xin, None)
+    assert torch.allclose(res0["1"][1], res["1"][1])  # downstream of the norm nothing changes
+    h = ln[0](xin).detach().requires_grad_(True)
+    (want,) = torch.autograd.grad(ln[1](h), h, grad_outputs=res0["1"][1])
+    assert torch.allclose(res0["0"][1], want, atol=1e-6) and not torch.allclose(res0["0"][1], res["0"][1])
