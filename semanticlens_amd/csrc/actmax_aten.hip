@@ -1,13 +1,21 @@
 // K3, SL_TIES_ATEN — ActMax.update with torch.topk's exact CPU tie order
-// (activation_caching.py:137-141; selection order restated in aten_topk_order.hpp).
+// (activation_caching.py:137-141; selection order restated in aten_topk_order.hpp / aten_topk_wave.hpp).
 //
-// One lane per component runs the (inherently sequential) libstdc++ selection on the row
-// [state | batch] of n = k + B packed (order-key, position) words held in LDS, element j of the
-// lane's row at lds[j * rows_per_block + r].  Work is O(n) per row and data dependent; lanes of
-// a wave diverge, so few rows share a wave and the rows are spread over many waves.  This mode
-// exists for bit-identity with the reference; SL_TIES_TOTAL is the fast path.
+// Round 5: ONE WAVEFRONT PER COMPONENT.  The row [state | batch] of n = k + B packed (order-key, position) words lives in
+// LDS; libstdc++'s introselect / introsort are followed step by step, but each Hoare partition is evaluated by the whole
+// wave at once from its closed form (ballots give every lane's rank in the left-stop / right-stop lists, the swaps are
+// independent) and every insertion sort is a stable rank sort (aten_topk_wave.hpp has the derivation and the host check
+// against libstdc++).  A partition step costs a handful of LDS round trips instead of one dependent LDS access per element:
+// C = 2048, B = 256, k = 20 went from 169 us (one lane per row, round 4) to the figure in profiles/r05_k3_*.  The heap
+// fallbacks (depth limit, torch's `k * 64 <= n` partial_sort branch) run sequentially on lane 0 over the same LDS row; rows
+// too long for the LDS take the round-4 kernel (one lane per row, kept below).  This mode exists for bit-identity with the
+// reference; SL_TIES_TOTAL is the shard-invariant path.
 #include "aten_topk_order.hpp"
+#include "aten_topk_wave.hpp"
 #include "common.hpp"
+
+#include <cstdlib>
+#include <cstring>
 
 namespace sl {
 namespace {
@@ -57,7 +65,221 @@ __global__ __launch_bounds__(64) void actmax_update_aten_kernel(uint16_t* __rest
   }
 }
 
+
+// ---- one wavefront per row -----------------------------------------------------------------------------------------------
+__device__ inline void wave_sync() {  // LDS traffic of ONE wave executes in order; this only stops the compiler reordering it
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// move_median_to_first(result, x, y, z): every lane evaluates it, lane 0 writes the swap
+__device__ inline void wave_median_to_first(uint32_t* A, int result, int x, int y, int z, int lane) {
+  using aten_order::cmp;
+  const uint32_t ax = A[x], ay = A[y], az = A[z], ar = A[result];
+  int sel;
+  if (cmp(ax, ay)) sel = cmp(ay, az) ? y : (cmp(ax, az) ? z : x);
+  else sel = cmp(ax, az) ? x : (cmp(ay, az) ? z : y);
+  const uint32_t vs = sel == x ? ax : (sel == y ? ay : az);
+  wave_sync();
+  if (lane == 0) {
+    A[result] = vs;
+    A[sel] = ar;
+  }
+  wave_sync();
+}
+
+// aten_order::lists::partition with the lists built by ballots: tL / tR hold the left-stop / right-stop positions ascending
+__device__ inline int wave_partition(uint32_t* A, uint16_t* tL, uint16_t* tR, int lo, int hi, uint32_t pv, int lane) {
+  const uint32_t pk = pv >> 16;
+  const uint64_t below = (1ull << lane) - 1ull;
+  int nL = 0, nR = 0;
+  for (int p0 = lo; p0 < hi; p0 += 64) {
+    const int p = p0 + lane;
+    const bool valid = p < hi;
+    const uint32_t key = valid ? (A[p] >> 16) : 0u;
+    const bool inL = valid && key <= pk, inR = valid && key >= pk;
+    const uint64_t bL = __ballot(inL), bR = __ballot(inR);
+    if (inL) tL[nL + __popcll(bL & below)] = (uint16_t)p;
+    if (inR) tR[nR + __popcll(bR & below)] = (uint16_t)p;
+    nL += __popcll(bL);
+    nR += __popcll(bR);
+  }
+  wave_sync();
+  const int mn = nL < nR ? nL : nR;
+  int m = 0;  // swaps: L[j] < R[j] is monotone in j
+  for (int j0 = 0; j0 < mn; j0 += 64) {
+    const int j = j0 + lane;
+    const bool ok = j < mn && tL[j < mn ? j : 0] < tR[j < mn ? nR - 1 - j : 0];
+    const uint64_t bb = __ballot(ok);
+    m += __popcll(bb);
+    if (bb != ~0ull) break;
+  }
+  for (int j0 = 0; j0 < m; j0 += 64) {
+    const int j = j0 + lane;
+    if (j < m) {
+      const int pl = tL[j], pr = tR[nR - 1 - j];
+      const uint32_t x = A[pl], y = A[pr];
+      A[pl] = y;
+      A[pr] = x;
+    }
+  }
+  const int big = 0x7FFFFFFF;
+  const int cutL = m < nL ? (int)tL[m] : big;
+  const int cutR = m > 0 ? (int)tR[nR - m] : big;
+  wave_sync();
+  return uni(cutL < cutR ? cutL : cutR);
+}
+
+// stable descending rank sort of A[first, last) through T (>= last - first words)
+__device__ inline void wave_stable_sort(uint32_t* A, uint32_t* T, int first, int last, int lane) {
+  if (last - first < 2) return;
+  for (int i0 = first; i0 < last; i0 += 64) {
+    const int i = i0 + lane;
+    const bool valid = i < last;
+    const uint32_t vi = A[valid ? i : first];
+    const uint32_t ki = vi >> 16;
+    int rank = 0;
+    for (int j = first; j < last; ++j) {
+      const uint32_t kj = A[j] >> 16;  // one address for the whole wave: an LDS broadcast
+      rank += (kj > ki) || (kj == ki && j < i);
+    }
+    if (valid) T[rank] = vi;
+  }
+  wave_sync();
+  for (int i0 = first; i0 < last; i0 += 64) {
+    const int i = i0 + lane;
+    if (i < last) A[i] = T[i - first];
+  }
+  wave_sync();
+}
+
+// aten_order::topk_order on the LDS row A[0, n); T: n words of scratch, stk: 96 words
+__device__ inline void wave_topk_row(uint32_t* A, uint32_t* T, uint32_t* stk, int n, int k, int lane) {
+  using namespace aten_order;
+  uint16_t* tL = reinterpret_cast<uint16_t*>(T);
+  uint16_t* tR = tL + n;
+  if ((int64_t)k * 64 <= (int64_t)n) {  // torch's partial_sort branch: heaps, sequential
+    if (lane == 0) partial_sort(A, 0, k, n);
+    wave_sync();
+    return;
+  }
+  // std::nth_element(A, A + k - 1, A + n)
+  int first = 0, last = n;
+  const int nth = k - 1;
+  int depth = floor_log2(n) * 2;
+  bool done = false;
+  while (last - first > 3) {
+    if (depth == 0) {
+      if (lane == 0) {
+        heap_select(A, first, nth + 1, last);
+        swap_at(A, first, nth);
+      }
+      wave_sync();
+      done = true;
+      break;
+    }
+    --depth;
+    wave_median_to_first(A, first, first + 1, first + (last - first) / 2, last - 1, lane);
+    const int cut = wave_partition(A, tL, tR, first + 1, last, A[first], lane);
+    if (cut <= nth) first = cut;
+    else last = cut;
+  }
+  if (!done) wave_stable_sort(A, T, first, last, lane);  // __insertion_sort of <= 3 elements
+  // std::sort(A, A + k - 1): introsort loop over an explicit stack (disjoint sub-ranges: their order does not matter)
+  const int s_last = k - 1;
+  if (s_last <= 0) return;
+  constexpr int kThreshold = 16;
+  int sp = 0;
+  if (lane == 0) stk[0] = 0u, stk[1] = (uint32_t)s_last | ((uint32_t)(floor_log2(s_last) * 2) << 16);
+  wave_sync();
+  sp = 1;
+  while (sp > 0) {
+    --sp;
+    int f = uni((int)stk[2 * sp]);
+    const uint32_t ld = stk[2 * sp + 1];
+    int l = uni((int)(ld & 0xFFFFu)), d = uni((int)(ld >> 16));
+    while (l - f > kThreshold) {
+      if (d == 0) {
+        if (lane == 0) partial_sort(A, f, l, l);
+        wave_sync();
+        break;
+      }
+      --d;
+      wave_median_to_first(A, f, f + 1, f + (l - f) / 2, l - 1, lane);
+      const int cut = wave_partition(A, tL, tR, f + 1, l, A[f], lane);
+      if (sp < 48) {
+        if (lane == 0) stk[2 * sp] = (uint32_t)cut, stk[2 * sp + 1] = (uint32_t)l | ((uint32_t)d << 16);
+        wave_sync();
+        ++sp;
+      }
+      l = cut;
+    }
+  }
+  wave_stable_sort(A, T, 0, s_last, lane);  // __final_insertion_sort
+}
+
+// LDS bytes of one row: A and T (n words each), the original bf16 bits (n halves), the old ids (k), the stack
+__host__ __device__ inline size_t wave_row_bytes(int n, int k) {
+  return (size_t)n * 8 + (((size_t)n * 2 + 7) & ~(size_t)7) + (size_t)k * 8 + 96 * 4;
+}
+
+template <int ROWS>
+__global__ __launch_bounds__(64 * ROWS) void actmax_update_aten_wave_kernel(uint16_t* __restrict__ vals, int64_t* __restrict__ ids,
+                                                                            int64_t C, int k, const uint16_t* __restrict__ cand,
+                                                                            const int64_t* __restrict__ sample_ids,
+                                                                            int64_t id_base, int B) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int n = k + B;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t c0 = (int64_t)blockIdx.x * ROWS;
+  const size_t rb = wave_row_bytes(n, k);
+  auto rowA = [&](int r) { return reinterpret_cast<uint32_t*>(smem + r * rb); };
+  auto rowT = [&](int r) { return rowA(r) + n; };
+  auto rowIds = [&](int r) { return reinterpret_cast<int64_t*>(smem + r * rb + (size_t)n * 8); };
+  auto rowStk = [&](int r) { return reinterpret_cast<uint32_t*>(rowIds(r) + k); };
+  auto rowRaw = [&](int r) { return reinterpret_cast<uint16_t*>(rowStk(r) + 96); };
+  // all_acts = cat([state, batch_acts]) — activation_caching.py:137.  The (B, C) candidates are transposed on the way in:
+  // consecutive threads take the ROWS adjacent components of one sample (ROWS x 2 contiguous bytes)
+  for (int idx = threadIdx.x; idx < B * ROWS; idx += 64 * ROWS) {
+    const int b = idx / ROWS, r = idx % ROWS;
+    if (c0 + r < C) {
+      const uint16_t h = cand[(int64_t)b * C + c0 + r];
+      rowA(r)[k + b] = (bf16_order_key(h) << 16) | (uint32_t)(k + b);
+      rowRaw(r)[k + b] = h;
+    }
+  }
+  for (int idx = threadIdx.x; idx < k * ROWS; idx += 64 * ROWS) {
+    const int r = idx / k, j = idx % k;
+    if (c0 + r < C) {
+      const int64_t so = (c0 + r) * k + j;
+      const uint16_t h = vals[so];
+      rowA(r)[j] = (bf16_order_key(h) << 16) | (uint32_t)j;
+      rowRaw(r)[j] = h;
+      rowIds(r)[j] = ids[so];
+    }
+  }
+  __syncthreads();  // the only workgroup barrier: from here on every wave owns its row
+  if (c0 + w >= C) return;
+  uint32_t* A = rowA(w);
+  wave_topk_row(A, rowT(w), rowStk(w), n, k, lane);  // :140
+  // gather values / ids through the selected positions — :140-141 (the old state was copied to LDS above: in place is safe)
+  const uint16_t* raw = rowRaw(w);
+  const int64_t* old_ids = rowIds(w);
+  const int64_t so = (c0 + w) * k;
+  for (int j0 = 0; j0 < k; j0 += 64) {
+    const int j = j0 + lane;
+    if (j < k) {
+      const int pos = (int)(A[j] & 0xFFFFu);
+      vals[so + j] = raw[pos];
+      ids[so + j] = pos < k ? old_ids[pos] : (sample_ids ? sample_ids[pos - k] : id_base + (pos - k));
+    }
+  }
+}
+
 constexpr size_t kLdsBudget = 64 * 1024;
+constexpr size_t kLdsMax = 160 * 1024;
 
 }  // namespace
 
@@ -69,6 +291,30 @@ int actmax_update_aten(ProfScope& prof, uint16_t* d_vals, int64_t* d_ids, int64_
   SL_REQUIRE(d_ws && ws_bytes >= sl_actmax_aten_ws_bytes(C, k, B),
              "sl_actmax_update(SL_TIES_ATEN): workspace too small (%zu < %zu)", ws_bytes,
              sl_actmax_aten_ws_bytes(C, k, B));
+  static const int impl = [] {  // SL_K3_ATEN_IMPL = wave (default) | lane (round 4: one lane per row)
+    const char* e = getenv("SL_K3_ATEN_IMPL");
+    return (e && strcmp(e, "lane") == 0) ? 0 : 1;
+  }();
+  const size_t rb = wave_row_bytes((int)n, (int)k);
+  if (impl == 1 && n <= 65535 && rb <= kLdsMax) {
+#define SL_K3_WAVE(ROWS_)                                                                                                        \
+  do {                                                                                                                           \
+    const size_t lds = rb * ROWS_;                                                                                               \
+    if (lds > kLdsBudget)                                                                                                        \
+      SL_CHECK_HIP(hipFuncSetAttribute((const void*)actmax_update_aten_wave_kernel<ROWS_>,                                        \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                    \
+    SL_LAUNCH(prof, actmax_update_aten_wave_kernel<ROWS_>, dim3((unsigned)((C + ROWS_ - 1) / ROWS_)), dim3(64 * ROWS_), lds, st,   \
+              d_vals, d_ids, C, (int)k, d_cand, d_sample_ids, id_base, (int)B);                                                    \
+  } while (0)
+    // eight rows per workgroup (16 contiguous candidate bytes per sample) while the rows fit; fewer for long rows or few components
+    if (rb * 8 <= kLdsBudget && C >= 1024) SL_K3_WAVE(8);
+    else if (rb * 4 <= kLdsBudget && C >= 256) SL_K3_WAVE(4);
+    else if (rb * 2 <= kLdsMax && C >= 2) SL_K3_WAVE(2);
+    else SL_K3_WAVE(1);
+#undef SL_K3_WAVE
+    SL_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   int rpb = (int)((C + 511) / 512);  // spread rows over >= 512 waves when C allows
   const int lds_cap = (int)(kLdsBudget / ((size_t)n * 4));
   if (rpb > lds_cap) rpb = lds_cap;

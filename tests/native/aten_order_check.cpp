@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../semanticlens_amd/csrc/aten_topk_order.hpp"
+#include "../../semanticlens_amd/csrc/aten_topk_wave.hpp"
 
 static uint32_t key_of(float f) {  // same map as common.hpp bf16_order_key, on the bf16 bits of f
   uint32_t u;
@@ -45,6 +46,17 @@ static bool run_case(const std::vector<float>& vals, int k, long& n_partial, lon
   sl::aten_order::topk_order(p, n, k);
   for (int j = 0; j < k; ++j)
     if ((int64_t)(a[j] & 0xFFFF) != q[j].second) return false;
+  // the data-parallel restatement (aten_topk_wave.hpp: Hoare partition by its L / R lists, insertion sorts as stable rank
+  // sorts) must leave the SAME first k elements — it is what actmax_aten.hip evaluates with one wavefront per row
+  if (k > 0 && (int64_t)k * 64 > n) {
+    std::vector<uint32_t> b(n), tmp(n);
+    std::vector<int> tab(2 * n + 2);
+    for (int j = 0; j < n; ++j) b[j] = (key_of(vals[j]) << 16) | (uint32_t)j;
+    uint32_t* pb = b.data();
+    sl::aten_order::lists::topk_order_nth(pb, n, k, tab.data(), tmp.data());
+    for (int j = 0; j < k; ++j)
+      if ((b[j] & 0xFFFF) != (a[j] & 0xFFFF)) return false;
+  }
   return true;
 }
 

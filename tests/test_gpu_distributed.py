@@ -279,25 +279,28 @@ def _nccl_single_worker(rank, world, port, out_dir):
         np.savez(os.path.join(out_dir, "nccl1.npz"), **{f"db_{k}": v.cpu().numpy() for k, v in db.items()},
                  **{f"dbref_{k}": v.cpu().numpy() for k, v in db_ref.items()},
                  **{f"ids_{k}": cv.get_max_reference(k).numpy() for k in db}, **out)
-        # an index-less device ("cuda" after torch.cuda.set_device(rank), the usual pattern) names the current device: the
-        # library's communicator must accept tensors living on cuda:0 (round-4 advisor finding)
-        sld.destroy_native_comms()
-        comm = sld.native_comm(None, "cuda")
-        assert comm is not None and comm.device == dev and sld.native_comm(None, dev) is comm
-        assert sld._all_reduce_host_ints([3, -5], dist.ReduceOp.MAX, None, "cuda") == [3, -5]
-        assert torch.equal(sld.all_gather_rows(rows, 7), rows)
-        from semanticlens_amd.component_visualization import ActivationComponentVisualizer, aggregators
-        from helpers import TensorPairDataset, make_int_conv_model, make_int_images
+        if sld.COLLECTIVES == "native":
+            # an index-less device ("cuda" after torch.cuda.set_device(rank), the usual pattern) names the current device: the
+            # library's communicator must accept tensors living on cuda:0 (round-4 advisor finding)
+            sld.destroy_native_comms()
+            comm = sld.native_comm(None, "cuda")
+            assert comm is not None and comm.device == dev and sld.native_comm(None, dev) is comm
+            assert sld._all_reduce_host_ints([3, -5], dist.ReduceOp.MAX, None, "cuda") == [3, -5]
+            assert torch.equal(sld.all_gather_rows(rows, 7), rows)
+            from semanticlens_amd.component_visualization import ActivationComponentVisualizer, aggregators
+            from helpers import TensorPairDataset, make_int_conv_model, make_int_images
 
-        ds = TensorPairDataset(make_int_images(47))
-        cv3 = ActivationComponentVisualizer(make_int_conv_model().to(dev), ds, ds, ["0", "2"], num_samples=6, device="cuda",
-                                            aggregate_fn=aggregators.aggregate_conv_max, tie_mode="total")
-        sld.run_sharded(cv3, batch_size=8)
-        for k in ("0", "2"):
-            assert torch.equal(cv3.get_max_reference(k), cv.get_max_reference(k))
+            ds = TensorPairDataset(make_int_images(47))
+            cv3 = ActivationComponentVisualizer(make_int_conv_model().to(dev), ds, ds, ["0", "2"], num_samples=6, device="cuda",
+                                                aggregate_fn=aggregators.aggregate_conv_max, tie_mode="total")
+            sld.run_sharded(cv3, batch_size=8)
+            for k in ("0", "2"):
+                assert torch.equal(cv3.get_max_reference(k), cv.get_max_reference(k))
     finally:
         dist.destroy_process_group()
     # a re-initialised process group must not be handed the communicator of the destroyed one
+    if sld.COLLECTIVES != "native":
+        return
     stale = comm
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, init_method=f"tcp://127.0.0.1:{_free_port()}")  # one rank: no port to agree on
     try:
