@@ -823,13 +823,18 @@ __global__ __launch_bounds__(64) void attention_pool_kernel(const float* __restr
   for (int t = lane; t < T; t += 64) {
     const float* kr = kv + (b * T + t) * ld + h * hd;
     const float* vr = kr + voff;
-    float s = 0.f;
+    // The score is accumulated in double and the exponentials are the library's (1 ulp): behind a CLIP-ResNet trunk the
+    // logits are in the hundreds, where the hardware exp2 path (`__expf`: the product x * log2(e) rounded to fp32) is off by
+    // |x| * 6e-8 in the exponent, i.e. ~1e-5 relative in the weights — 3x torch's own fp32 distance from float64 on the seeded
+    // head test (round 5).  hd MACs and two exps per key beside 2 * hd * 4 bytes of K / V: free for this HBM-bound kernel.
+    double sd = 0.0;
     for (int d = 0; d < hd; d += 4) {
       const float4 k4 = *reinterpret_cast<const float4*>(kr + d);
-      s += s_q[d] * k4.x + s_q[d + 1] * k4.y + s_q[d + 2] * k4.z + s_q[d + 3] * k4.w;
+      sd += (double)s_q[d] * k4.x + (double)s_q[d + 1] * k4.y + (double)s_q[d + 2] * k4.z + (double)s_q[d + 3] * k4.w;
     }
+    const float s = (float)sd;
     const float mn = fmaxf(m, s);
-    const float corr = __expf(m - mn), p = __expf(s - mn);  // first key: m = -inf -> corr = 0
+    const float corr = expf(m - mn), p = expf(s - mn);  // first key: m = -inf -> corr = 0
     l = l * corr + p;
 #pragma unroll
     for (int d = 0; d < kPoolMaxHd; d += 4) {
@@ -845,7 +850,7 @@ __global__ __launch_bounds__(64) void attention_pool_kernel(const float* __restr
   }
   float M = m;
   for (int off = 32; off > 0; off >>= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
-  const float f = (m == -__builtin_huge_valf()) ? 0.f : __expf(m - M);  // lanes without a key contribute nothing
+  const float f = (m == -__builtin_huge_valf()) ? 0.f : expf(m - M);  // lanes without a key contribute nothing
   l *= f;
   for (int off = 32; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
   const float inv = 1.f / l;
@@ -1063,6 +1068,7 @@ static int attention_pool_impl(const char* fn, const float* d_q, int64_t q_batch
   SL_REQUIRE(d_q && d_kv && d_out, "%s: null pointer", fn);
   SL_REQUIRE(kv_row_stride % 4 == 0 && v_offset % 4 == 0 && (((uintptr_t)d_kv) & 15) == 0, "%s: rows must be 16-byte aligned", fn);
   SL_REQUIRE(B * H < (1ll << 31) && q_batch_stride >= 0, "%s: too many heads", fn);
+  SL_REQUIRE(T < (1ll << 31), "%s: T=%lld exceeds the 32-bit key index", fn, (long long)T);
   hipLaunchKernelGGL(attention_pool_kernel, dim3((unsigned)(B * H)), dim3(64), 0, (hipStream_t)stream, d_q, q_batch_stride, d_kv,
                      kv_row_stride, v_offset, (int)T, (int)H, (int)head_dim, 1.f / sqrtf((float)head_dim), d_out);
   SL_CHECK_HIP(hipGetLastError());
@@ -1084,8 +1090,10 @@ SL_API int sl_tokens_from_map(const float* d_map, int64_t B, int64_t C, int64_t 
   SL_REQUIRE(B >= 0 && C >= 1 && S >= 1, "sl_tokens_from_map: bad shape");
   if (B == 0) return 0;
   SL_REQUIRE(d_map && d_pos && d_out, "sl_tokens_from_map: null pointer");
-  SL_REQUIRE(B < 65536 && S <= 1024, "sl_tokens_from_map: B=%lld S=%lld (limits 65535 / 1024)", (long long)B, (long long)S);
   const size_t lds = (size_t)64 * (S + 1) * sizeof(float);
+  // the (64 channels x S positions) tile lives in LDS: S is bounded by the 160 KiB a gfx950 workgroup may declare (S <= 639)
+  SL_REQUIRE(B < 65536 && lds <= 160 * 1024, "sl_tokens_from_map: B=%lld S=%lld (limits 65535 / %d: the 64 x (S + 1) fp32 tile must fit the LDS)",
+             (long long)B, (long long)S, (int)(160 * 1024 / (64 * sizeof(float)) - 1));
   if (lds > 64 * 1024)
     SL_CHECK_HIP(hipFuncSetAttribute((const void*)tokens_from_map_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(tokens_from_map_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)B), dim3(256), lds, (hipStream_t)stream, d_map, d_pos,

@@ -488,7 +488,9 @@ def test_clip_rn50_attention_pool_head_on_the_kernels(gemm):
     # (ii) trunk-scale map (entries up to 20, logits in the hundreds): every fp32 implementation, torch's included, sits
     #      ~1e-4 from float64 here.  Bars: 5e-4 absolute on features of scale ~20 (2.5e-5 of the scale) AND at most twice
     #      the distance of torch's own fp32 attention pool on the same map.
-    for scale, bar in ((1.0, 1e-4), (20.0, 5e-4)):
+    # (iii) scale 120: features of scale ~20 as on the round-4 driver box; no absolute bar is meaningful there (torch's own fp32
+    #      pool is ~1e-4 from float64), only the one relative to torch
+    for scale, bar in ((1.0, 1e-4), (20.0, 5e-4), (120.0, None)):
         fmap = _seeded_trunk_map(scale)
         got = nat.vision.head(fmap)
         assert torch.equal(got, nat.vision.head(fmap)), "the head is not run-to-run deterministic"
@@ -497,8 +499,8 @@ def test_clip_rn50_attention_pool_head_on_the_kernels(gemm):
             d_torch = (pool(fmap).double() - want).abs().max().item()
         d = (got.double() - want).abs().max().item()
         print(f"rn50 head [{gemm}] scale {scale}: native {d:.3e}  torch-fp32 {d_torch:.3e}  |features| {want.abs().max().item():.2f}")
-        assert d < bar, (gemm, scale, d, d_torch)
-        assert d < max(2 * d_torch, 0.2 * bar), (gemm, scale, d, d_torch)
+        assert bar is None or d < bar, (gemm, scale, d, d_torch)
+        assert d < max(2 * d_torch, 2e-5 if bar is None else 0.2 * bar), (gemm, scale, d, d_torch)
     # end to end behind the real trunk: `trunk()` must be the model's forward minus the pool.  MIOpen's convolutions are not
     # run-to-run deterministic at this batch size, so two calls of the trunk may differ in their last bits (amplified by the
     # pool's large logits): a 1e-3 relative smoke bar here, the arithmetic bars are the seeded ones above
