@@ -203,6 +203,10 @@ size_t sl_similarity_multi_ws_bytes(int64_t Q, int64_t K, const int64_t* h_Cs, i
 
 /* ---- K7: clarity_score (scores.py:18-47): V (C,n,D) -> out (C) ---------------------------- */
 int sl_clarity(const float* d_V, int64_t C, int64_t n, int64_t D, float* d_out, void* stream);
+/* The per-layer loop of `Lens.eval_clarity` over a concept_db dict (lens.py:391-419) as ONE launch: L layers with the same
+ * (n, D) and their own component counts.  h_d_Vs / h_d_outs: host arrays of L device pointers ((C_l,n,D) inputs, (C_l) outputs). */
+int sl_clarity_multi(const float* const* h_d_Vs, const int64_t* h_Cs, int L, int64_t n, int64_t D, float* const* h_d_outs,
+                     void* stream);
 
 /* ---- K8: redundancy_score (scores.py:50-81): V (Bt,C,D) -> out (Bt) ----------------------- */
 int sl_redundancy(const float* d_V, int64_t Bt, int64_t C, int64_t D, float* d_out, void* d_ws, size_t ws_bytes,

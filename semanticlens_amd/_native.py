@@ -69,6 +69,7 @@ SIGNATURES = {
     "sl_similarity_multi": (_int, [_vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _sz, _vp]),
     "sl_similarity_multi_ws_bytes": (_sz, [_i64, _i64, _vp, _int]),
     "sl_clarity": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "sl_clarity_multi": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _vp]),
     "sl_redundancy": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "sl_redundancy_ws_bytes": (_sz, [_i64, _i64, _i64]),
     "sl_template_mean": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
@@ -632,6 +633,24 @@ def clarity(V: torch.Tensor) -> torch.Tensor:
     with _on(Vd.device):
         _check(lib().sl_clarity(_ptr(Vd), C, n, D, _ptr(out), _stream(Vd)), "sl_clarity")
     return out.reshape(lead)
+
+
+def clarity_multi(Vs: list[torch.Tensor]) -> list[torch.Tensor] | None:
+    """``[clarity(V) for V in Vs]`` as ONE launch when every ``V`` is ``(C_l, n, D)`` with the same ``(n, D)``; None otherwise
+    (the caller then goes layer by layer)."""
+    if not Vs or any(V.ndim != 3 for V in Vs) or len({tuple(V.shape[1:]) for V in Vs}) != 1:
+        return None
+    vds = [_f32c(Vs[0])]
+    vds += [_f32c(V, vds[0].device) for V in Vs[1:]]
+    n, D = vds[0].shape[1:]
+    outs = [torch.empty((V.shape[0],), dtype=torch.float32, device=vds[0].device) for V in vds]
+    L = len(vds)
+    cs = (_i64 * L)(*[V.shape[0] for V in vds])
+    vp = (_vp * L)(*[V.data_ptr() if V.numel() else None for V in vds])
+    op = (_vp * L)(*[o.data_ptr() if o.numel() else None for o in outs])
+    with _on(vds[0].device):
+        _check(lib().sl_clarity_multi(vp, cs, L, n, D, op, _stream(vds[0])), "sl_clarity_multi")
+    return outs
 
 
 def redundancy(V: torch.Tensor) -> torch.Tensor:

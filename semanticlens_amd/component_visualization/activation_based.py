@@ -279,12 +279,27 @@ class ActivationComponentVisualizer(AbstractComponentVisualizer):
             if referenced_only:
                 return self._concept_db_from_referenced(fm, batch_size, keep_on_device, **kwargs)
             embeds = self._embed_vision_dataset(fm, batch_size, **kwargs)
-        concept_db = dict()
-        for layer_name in self.layer_names:
-            ids = self.get_max_reference(layer_name)
-            gathered = N.gather_rows(embeds, ids)
-            concept_db[layer_name] = gathered if keep_on_device else gathered.cpu()
-        return concept_db
+        return self._gather_layers(embeds, {name: self.get_max_reference(name) for name in self.layer_names}, keep_on_device)
+
+    @staticmethod
+    def _gather_layers(table: torch.Tensor, refs: dict, keep_on_device: bool) -> dict:
+        """``{layer: table[ids]}`` (activation_based.py:387-390) with K5 launched ONCE over the ids of all layers — a layer alone
+        is ``C * k * D * 4`` bytes (2-20 MB: launch-latency-sized; one range check and one host synchronisation instead of one
+        per layer).  The per-layer results are views of one buffer on the device, separate host tensors otherwise."""
+        if not refs:
+            return {}
+        shapes = [tuple(ids.shape) for ids in refs.values()]
+        flat = torch.cat([ids.reshape(-1).to(torch.int64) for ids in refs.values()])
+        gathered = N.gather_rows(table, flat)  # (sum C*k, D)
+        out, row = {}, 0
+        for name, shape in zip(refs, shapes):
+            rows = 1
+            for d in shape:
+                rows *= d
+            part = gathered[row : row + rows].reshape(shape + (gathered.shape[1],))
+            out[name] = part if keep_on_device else part.cpu()
+            row += rows
+        return out
 
     def _collect_and_embed_single_pass(self, fm, batch_size, num_workers: int = 0, **kwargs):
         """Hot loops 1 and 2 fused over one walk of the data, on two HIP streams.  Returns the ``(N, D)`` table."""
@@ -334,13 +349,11 @@ class ActivationComponentVisualizer(AbstractComponentVisualizer):
             raise IndexError(f"index out of range in embeds[sample_ids] (dataset size {n_total})")
         uniq = torch.unique(flat)  # sorted
         table = self._embed_vision_dataset(fm, batch_size, subset=uniq.tolist(), **kwargs)
-        concept_db = dict()
+        pos = {}
         for name, ids in refs.items():
             ids = ids.to(torch.int64)
-            pos = torch.searchsorted(uniq, torch.where(ids < 0, ids + n_total, ids))
-            gathered = N.gather_rows(table, pos)
-            concept_db[name] = gathered if keep_on_device else gathered.cpu()
-        return concept_db
+            pos[name] = torch.searchsorted(uniq, torch.where(ids < 0, ids + n_total, ids))
+        return self._gather_layers(table, pos, keep_on_device)
 
     def _embed_vision_dataset(self, fm, batch_size, subset=None, **kwargs):
         """Embed every ``dataset_fm`` sample (or the samples listed in ``subset``, in that order) with ``fm``; returns

@@ -172,6 +172,14 @@ class Lens:
 
     def eval_clarity(self, concept_db):
         """``clarity_score`` of a ``(C, n, D)`` tensor or of each layer of a dict (lens.py:391-419)."""
+        if isinstance(concept_db, dict) and len(concept_db) > 1:
+            # the per-layer loop of lens.py:391-419 as one launch over all layers (K7 reads C*n*D*4 bytes once; a layer alone is
+            # a few MB — launch-latency-sized); same values as layer by layer
+            keys = list(concept_db)
+            if all(isinstance(concept_db[k_], torch.Tensor) for k_ in keys):
+                outs = N.clarity_multi([concept_db[k_] for k_ in keys])
+                if outs is not None:
+                    return {k_: o.to(concept_db[k_].device) for k_, o in zip(keys, outs)}
         return self._per_layer(clarity_score, concept_db)
 
     def eval_redundancy(self, aggregated_concept_db):

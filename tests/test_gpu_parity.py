@@ -668,6 +668,35 @@ def test_cosine_gemm_detects_transposes():
     np.testing.assert_allclose(got, oracle.similarity(x, y), rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("n,D", [(20, 512), (20, 1152), (100, 512), (7, 36), (2, 2048), (5, 2052), (9, 30), (33, 260)])
+def test_clarity_all_layers_in_one_launch_vs_oracle(n, D):
+    """`Lens.eval_clarity` over a concept_db dict (lens.py:391-419) = ONE `sl_clarity_multi` launch: layers with their own
+    component counts (one of them empty, one a zero-norm slab) against the oracle layer by layer; odd / wide D take the two-pass
+    kernel behind the same entry point."""
+    from semanticlens_amd import Lens
+    from helpers import FakeVLM
+
+    rng = np.random.RandomState(n * 7 + D)
+    layers = {f"l{i}": (rng.randn(c, n, D) * rng.rand(c, 1, 1) * 3).astype(np.float32) for i, c in enumerate((37, 1, 0, 300, 64))}
+    layers["l1"][:] = 0.0  # F.normalize's eps path: every row has norm 0
+    db = {k: torch.from_numpy(v).to(DEV) for k, v in layers.items()}
+    got = Lens(FakeVLM(), device=DEV).eval_clarity(db)
+    assert list(got) == list(db)
+    with np.errstate(all="ignore"):
+        for k, v in layers.items():
+            want = oracle.clarity(v) if v.shape[0] else np.zeros((0,), np.float32)
+            assert got[k].shape == (v.shape[0],) and got[k].is_cuda
+            np.testing.assert_allclose(got[k].cpu().numpy(), want, rtol=0, atol=1e-5, equal_nan=True)
+    # layer by layer through the public function: the same values to the last bit or two (another summation order inside a wave)
+    for k, v in db.items():
+        if v.shape[0] and n > 1:
+            np.testing.assert_allclose(scores.clarity_score(v).cpu().numpy(), got[k].cpu().numpy(), rtol=0, atol=2e-6)
+    # mixed (n, D) across layers cannot share a launch: the per-layer loop still answers
+    mixed = {"a": db["l0"], "b": torch.randn(5, n + 1, D, device=DEV)}
+    out = Lens(FakeVLM(), device=DEV).eval_clarity(mixed)
+    np.testing.assert_allclose(out["b"].cpu().numpy(), oracle.clarity(mixed["b"].cpu().numpy()), rtol=0, atol=1e-5)
+
+
 def test_clarity_redundancy_vs_oracle_larger():
     rng = np.random.RandomState(9)
     V = rng.randn(300, 20, 512).astype(np.float32)
