@@ -327,7 +327,7 @@ def cpu_baseline(args, model_cpu, fm_cpu):
     except AttributeError:
         all_cores = os.cpu_count() or torch.get_num_threads()
     best_t, best_dt = torch.get_num_threads(), float("inf")
-    cands = sorted({t for t in (8, 16, 32, 64, 128, all_cores) if t <= all_cores})
+    cands = sorted({t for t in (2, 4, 8, 16, 32, 64, 128, all_cores) if t <= all_cores})  # 2 and 4: the grid must bracket its best (round 4: best = its smallest, 8)
     thread_probe = {}
     with torch.no_grad():
         for t in cands:
@@ -391,7 +391,7 @@ def cpu_baseline(args, model_cpu, fm_cpu):
     except AttributeError:
         affinity = None
     return {
-        # `cores` = the threads the run USED (the fastest of 8/16/32/64/all on this box for the torch-CPU forward);
+        # `cores` = the threads the run USED (the fastest of 2/4/8/16/32/64/128/all on this box for the torch-CPU forward);
         # `host_cores` = what the box has (logical CPUs / CPUs this process may run on)
         "value": n / dt, "unit": "images/s", "cores": threads, "threads": threads, "host_cores": os.cpu_count(),
         "host_cores_affinity": affinity, "kind": "port",

@@ -70,12 +70,26 @@ def _encode_texts(fm, texts: list[str], batch_size: int | None = None, progress:
     if len(starts) > 1 and os.environ.get("SL_TEXT_PREFETCH", "1") != "0":
         from concurrent.futures import ThreadPoolExecutor
 
+        # A new thread's current HIP device is 0 and its current stream the default one.  A wrapper's `tokenize` may end in
+        # `.to(self.device)`: with an index-less device ("cuda") that copy would land on GPU 0 on every rank, issued on a stream
+        # the encoder does not run on.  The helper therefore tokenises under the CALLER's device and stream; `.to(fm.device)` on
+        # the main thread is then a no-op for tensors already there.
+        dev = torch.device(fm.device)
+        if dev.type == "cuda":
+            cur_dev = torch.cuda.current_device() if dev.index is None else dev.index
+            cur_stream = torch.cuda.current_stream(cur_dev)
+
+            def tokenize(chunk):
+                with torch.cuda.device(cur_dev), torch.cuda.stream(cur_stream):
+                    return fm.tokenize(chunk)
+        else:
+            tokenize = fm.tokenize
         with ThreadPoolExecutor(max_workers=1) as pool:
-            nxt = pool.submit(fm.tokenize, texts[starts[0] : starts[0] + batch_size])
+            nxt = pool.submit(tokenize, texts[starts[0] : starts[0] + batch_size])
             for i, _ in enumerate(bar):
                 tokens = nxt.result()
                 if i + 1 < len(starts):
-                    nxt = pool.submit(fm.tokenize, texts[starts[i + 1] : starts[i + 1] + batch_size])
+                    nxt = pool.submit(tokenize, texts[starts[i + 1] : starts[i + 1] + batch_size])
                 chunks.append(fm.encode_text(tokens.to(fm.device)))
     else:
         for start in bar:
