@@ -97,6 +97,14 @@ int sl_abs_norm_rows(float* d_x, int64_t B, int64_t C, float eps, void* stream);
 int sl_reduce_tokens(const void* d_act, int dtype, int64_t B, int64_t T, int64_t F, int64_t sb, int64_t st,
                      int64_t sf, int agg, int64_t pos, uint16_t* d_cand_bf16, float* d_out_f32, void* stream);
 
+/* The same reductions over L activations of ONE shape (the hooked outputs of L identical blocks, activation_caching.py:388-418
+ * fires once per hooked layer and batch) in one launch where the component axis is contiguous, tensor by tensor otherwise.
+ * h_d_acts: host array of L device pointers; d_cand_bf16: (L, B, C) contiguous. */
+int sl_reduce_conv_multi(const void* const* h_d_acts, int L, int dtype, int64_t B, int64_t C, int64_t S, int64_t sb, int64_t sc,
+                         int64_t ss, int agg, uint16_t* d_cand_bf16, void* stream);
+int sl_reduce_tokens_multi(const void* const* h_d_acts, int L, int dtype, int64_t B, int64_t T, int64_t F, int64_t sb, int64_t st,
+                           int64_t sf, int agg, int64_t pos, uint16_t* d_cand_bf16, void* stream);
+
 /* ---- K3: streaming top-k state (ActMax) --------------------------------------------------
  * State = d_vals (C,k) bf16 bit patterns + d_ids (C,k) int64, sorted best-first per row.
  * sl_actmax_init: activation_caching.py:101-110 (values -0.0, ids -1). */
@@ -119,6 +127,12 @@ int sl_actmax_update(uint16_t* d_vals, int64_t* d_ids, int64_t C, int64_t k, con
                      const int64_t* d_sample_ids, int64_t id_base, int64_t B, int ties, void* d_ws, size_t ws_bytes,
                      void* stream);
 size_t sl_actmax_aten_ws_bytes(int64_t C, int64_t k, int64_t B);
+/* SL_TIES_ATEN update of L states of one (C, k) from one (L, B, C) candidate buffer (sl_reduce_*_multi's output) in one launch;
+ * h_id_bases: the sample id of each layer's first candidate row (the reference's per-layer counter, activation_caching.py:410-413).
+ * `_supported`: 1 when (k + B) rows fit the one-wavefront-per-row kernel, else update layer by layer. */
+int sl_actmax_update_multi(uint16_t* const* h_d_vals, int64_t* const* h_d_ids, const int64_t* h_id_bases, int L, int64_t C,
+                           int64_t k, const uint16_t* d_cand, int64_t B, void* stream);
+int sl_actmax_update_multi_supported(int64_t C, int64_t k, int64_t B);
 
 /* ---- K4: merge R other states (e.g. all-gathered per-rank states) into this one ----------
  * No reference counterpart (the reference is single-process); semantics = SL_TIES_TOTAL

@@ -47,6 +47,10 @@ SIGNATURES = {
     "sl_actmax_merge": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _int, _vp]),
     "sl_actmax_update": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _int, _vp, _sz, _vp]),
     "sl_actmax_aten_ws_bytes": (_sz, [_i64, _i64, _i64]),
+    "sl_actmax_update_multi": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _vp, _i64, _vp]),
+    "sl_actmax_update_multi_supported": (_int, [_i64, _i64, _i64]),
+    "sl_reduce_conv_multi": (_int, [_vp, _int, _int, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp]),
+    "sl_reduce_tokens_multi": (_int, [_vp, _int, _int, _i64, _i64, _i64, _i64, _i64, _i64, _int, _i64, _vp, _vp]),
     "sl_actmax_merge_states": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),
     "sl_comm_unique_id": (_int, [_vp]),
     "sl_comm_init_from_unique_id": (_int, [_vp, _int, _int, ctypes.POINTER(_vp)]),
@@ -256,9 +260,51 @@ def reduce_tokens(x: torch.Tensor, agg: int, pos: int, cand: torch.Tensor | None
     _check(rc, "sl_reduce_tokens")
 
 
+def reduce_multi(kind: str, xs: list[torch.Tensor], agg: int, pos: int, cand: torch.Tensor):
+    """K1 / K2 over ``L`` device tensors of ONE shape, strides and dtype into ``cand`` ``(L, B, C)`` bf16: one launch when the
+    component axis is contiguous (``sl_reduce_*_multi``)."""
+    x0 = xs[0]
+    L = len(xs)
+    assert all(x.is_cuda and x.shape == x0.shape and x.stride() == x0.stride() and x.dtype == x0.dtype for x in xs)
+    assert cand.is_contiguous() and cand.dtype == torch.bfloat16 and cand.shape[0] == L
+    if kind == "conv":
+        flat = [_flatten_spatial(x) for x in xs]  # identical strides: the same answer (view or copy) for every tensor
+        xs = [f[0] for f in flat]
+        sb, sc, ss = flat[0][1:]
+    ptrs = (_vp * L)(*[x.data_ptr() for x in xs])
+    with _on(x0.device):
+        if kind == "conv":
+            B, C = x0.shape[:2]
+            S = x0.shape[2] * x0.shape[3]
+            rc = lib().sl_reduce_conv_multi(ptrs, L, _dtype_code(x0), B, C, S, sb, sc, ss, agg, _ptr(cand), _stream(x0))
+            _check(rc, "sl_reduce_conv_multi")
+        else:
+            B, T, F = x0.shape
+            sb, st, sf = x0.stride()
+            rc = lib().sl_reduce_tokens_multi(ptrs, L, _dtype_code(x0), B, T, F, sb, st, sf, agg, pos, _ptr(cand), _stream(x0))
+            _check(rc, "sl_reduce_tokens_multi")
+
+
 # ------------------------------------------------------------------------------------------------
 # K3 / K4
 # ------------------------------------------------------------------------------------------------
+def actmax_update_multi_supported(C: int, k: int, B: int) -> bool:
+    return bool(lib().sl_actmax_update_multi_supported(C, k, B))
+
+
+def actmax_update_multi(states: list[tuple[torch.Tensor, torch.Tensor]], cand: torch.Tensor, id_bases: list[int], B: int):
+    """``SL_TIES_ATEN`` update of ``L`` states ``(C, k)`` from ``cand`` ``(L, B, C)`` in one launch."""
+    L = len(states)
+    C, k = states[0][0].shape
+    assert cand.is_contiguous() and tuple(cand.shape) == (L, B, C)
+    vp = (_vp * L)(*[v.data_ptr() for v, _ in states])
+    ip = (_vp * L)(*[i.data_ptr() for _, i in states])
+    hb = (_i64 * L)(*id_bases)
+    with _on(cand.device):
+        rc = lib().sl_actmax_update_multi(vp, ip, hb, L, C, k, _ptr(cand), B, _stream(cand))
+    _check(rc, "sl_actmax_update_multi")
+
+
 def actmax_init(vals: torch.Tensor, ids: torch.Tensor):
     C, k = vals.shape
     with _on(vals.device):

@@ -82,6 +82,7 @@ class ActMax:
         self._policy_tuner = None  # N.ReducePolicyTuner of this layer's reduce (created on the first fused collect)
         self._pending: list[tuple[int, int]] = []  # (id_base, rows) per queued slot
         self._ws: torch.Tensor | None = None
+        self._before_flush = None  # set by ActMaxCache for layers collected in groups: runs the group's queued work first
         if n_latents is not None:
             self._setup_tensors()
 
@@ -204,7 +205,10 @@ class ActMax:
                 self.flush()
 
     def flush(self):
-        """Merge every queued candidate batch into the state (total-order mode)."""
+        """Merge every queued candidate batch into the state (total-order mode); a layer collected as part of a group of
+        identical layers (``ActMaxCache``) first has its group's stashed activations reduced and merged."""
+        if self._before_flush is not None:
+            self._before_flush()
         if self._pending:
             ring = self._ring
             N.actmax_merge(
@@ -322,6 +326,20 @@ class ActMaxCache(ActCache):
         self.cache: dict[str, ActMax] = {
             name: ActMax(n_collect=n_collect, tie_mode=self.tie_mode, init_value=self.init_value) for name in layer_names
         }
+        # ---- groups of identical layers (round 5) ----
+        # Hooking "all encoder blocks" of a transformer means L outputs of ONE shape per batch, each a launch of ~150 MB for K2
+        # and a 17 us K3 launch: both sit on their fixed costs.  Layers whose outputs agree in shape, strides, dtype and aggregator
+        # are therefore collected TOGETHER: the hook only stashes a reference, and when the last member of the group has fired
+        # one `sl_reduce_*_multi` launch reads all L tensors (1.9 GB for ViT-B/16's twelve blocks at B = 256) and one
+        # `sl_actmax_update_multi` launch merges all L states.  Costs L - 1 activations kept alive a little longer (HBM is 288 GB).
+        # Safety: a stashed tensor must not change between its hook and the group's launch.  The first batch runs ungrouped and
+        # records every hooked output's `_version`; only layers whose output was still unmodified when the next batch began are
+        # grouped, and every later launch re-checks the versions (an in-place edit raises instead of collecting wrong values).
+        # The reference's tie order only (`tie_mode="aten"`); SEMANTICLENS_AMD_GROUP_LAYERS=0 switches it off.
+        self._grouping = self.tie_mode == "aten" and os.environ.get("SEMANTICLENS_AMD_GROUP_LAYERS", "1") != "0"
+        self._probe: dict[str, tuple] | None = {}  # first batch: layer -> (signature, tensor, version); None once planned
+        self._group_of: dict[str, int] = {}
+        self._groups: list[dict] = []
 
     def __getitem__(self, layer_name: str) -> ActMax:
         return self.cache[layer_name]
@@ -341,6 +359,8 @@ class ActMaxCache(ActCache):
                     raise ValueError(f"Input tensor should be {want}D. \n" + aggregators._ERROR_MESSAGE)
                 batch_size = outs.shape[0]
                 self.sample_idx_counter[layer_name] += batch_size
+                if self._grouping and self._collect_grouped(layer_name, module, outs, native, start):
+                    return
                 self.cache[layer_name].collect(outs, native, start, site=(id(module), layer_name))
                 return
             # user-defined aggregator: (B, C) tensor on any device, then K3 alone
@@ -353,7 +373,125 @@ class ActMaxCache(ActCache):
 
         return hook_fn
 
+    # ---- groups of identical layers --------------------------------------------------------------------------------------
+    @staticmethod
+    def _signature(outs: torch.Tensor, native) -> tuple:
+        return (native, outs.dtype, tuple(outs.shape[1:]), tuple(outs.stride()), outs.device)
+
+    @staticmethod
+    def _version(tensor: torch.Tensor):
+        try:
+            return tensor._version
+        except RuntimeError:  # inference tensors keep no version counter: an in-place edit could not be noticed
+            return None
+
+    def _plan_groups(self):
+        """End of the first pass over the hooked layers: group the layers with identical outputs that nobody modified in place."""
+        by_sig: dict[tuple, list[str]] = {}
+        for name, (sig, tensor, version) in self._probe.items():
+            if version is not None and self._version(tensor) == version:
+                by_sig.setdefault(sig[:3] + sig[4:], []).append(name)  # strides are re-checked per batch (they scale with B)
+        self._probe = None
+        for names in by_sig.values():
+            if len(names) >= 2:
+                gid = len(self._groups)
+                self._groups.append({"layers": names, "stash": {}, "cand": {}})
+                for name in names:
+                    self._group_of[name] = gid
+                    self.cache[name]._before_flush = (lambda g=gid: self._flush_group(g))
+
+    def _collect_grouped(self, layer_name, module, outs, native, start) -> bool:
+        """True when ``outs`` was taken over (stashed, or collected with its group); False = collect it now, alone."""
+        if self._probe is not None:
+            if layer_name not in self._probe:
+                if outs.is_cuda:
+                    self._probe[layer_name] = (self._signature(outs, native), outs.detach(), self._version(outs))
+                return False
+            self._plan_groups()  # a layer fires for the second time: the first batch is over
+        gid = self._group_of.get(layer_name)
+        version = self._version(outs) if gid is not None else None
+        if version is None:
+            return False
+        group = self._groups[gid]
+        self.cache[layer_name]._before_flush = (lambda g=gid: self._flush_group(g))  # the ActMax may have been replaced (load)
+        stash = group["stash"]
+        if layer_name in stash:  # the previous forward did not reach every member: finish it layer by layer
+            self._flush_group(gid)
+        if stash:
+            first = next(iter(stash.values()))
+            if self._signature(first[0], first[3]) != self._signature(outs, native) or first[0].shape[0] != outs.shape[0]:
+                self._flush_group(gid)
+                return False
+        stash[layer_name] = (outs.detach(), version, start, native, module)
+        if len(stash) == len(group["layers"]):
+            self._run_group(gid)
+        return True
+
+    @classmethod
+    def _check_unmodified(cls, layer_name, tensor, version):
+        if cls._version(tensor) != version:
+            raise RuntimeError(
+                f"the output of hooked layer {layer_name!r} was modified in place after its forward hook ran; layers with identical "
+                "outputs are collected together once the last of them has fired, which needs the earlier outputs intact. "
+                "Set SEMANTICLENS_AMD_GROUP_LAYERS=0 to collect every layer inside its own hook.")
+
+    def _run_group(self, gid: int):
+        """All members have fired: one multi-tensor reduce, one multi-state top-k update."""
+        group = self._groups[gid]
+        stash, names = group["stash"], group["layers"]
+        entries = [stash[name] for name in names]
+        group["stash"] = {}
+        for name, (tensor, version, _, _, _) in zip(names, entries):
+            self._check_unmodified(name, tensor, version)
+        x0, _, _, native, _ = entries[0]
+        kind, code, pos = native
+        B = x0.shape[0]
+        C = x0.shape[1] if kind == "conv" else x0.shape[2]
+        states = []
+        for name in names:
+            am = self.cache[name]
+            if not am.is_setup:
+                am.n_latents = C
+                am._setup_tensors()
+            if C != am.n_latents:
+                raise RuntimeError(f"layer output has {C} components, ActMax was set up for {am.n_latents}")
+            hook, am._before_flush = am._before_flush, None  # _device_state flushes: nothing of this group is pending any more
+            try:
+                states.append(am._device_state(x0.device))
+            finally:
+                am._before_flush = hook
+        if self.n_collect == 0 or B == 0:
+            return
+        if not N.actmax_update_multi_supported(C, self.n_collect, B):
+            for name, (tensor, _, start, nat, module) in zip(names, entries):
+                self.cache[name].collect(tensor, nat, start, site=(id(module), name))
+            return
+        cand = group["cand"].get(B)
+        if cand is None or cand.device != x0.device:
+            cand = group["cand"][B] = torch.empty((len(names), B, C), dtype=torch.bfloat16, device=x0.device)
+        N.reduce_multi(kind, [e[0] for e in entries], code, pos, cand)
+        N.actmax_update_multi(states, cand, [e[2] for e in entries], B)
+        for name in names:
+            self.cache[name]._dev_newer = True
+
+    def _flush_group(self, gid: int):
+        """Collect whatever the group has stashed, layer by layer (a forward that did not reach every member, or a state read)."""
+        group = self._groups[gid]
+        stash, group["stash"] = group["stash"], {}
+        for name, (tensor, version, start, native, module) in stash.items():
+            self._check_unmodified(name, tensor, version)
+            am = self.cache[name]
+            hook, am._before_flush = am._before_flush, None
+            try:
+                am.collect(tensor, native, start, site=(id(module), name))
+            finally:
+                am._before_flush = hook
+
     def _finalize(self):
+        for gid in range(len(self._groups)):
+            self._flush_group(gid)
+        if self._probe is not None:  # hooks removed before a second batch came: no tensor reference outlives the context
+            self._probe = {}
         for act_max in self.cache.values():
             act_max.flush()
 

@@ -225,11 +225,20 @@ __host__ __device__ inline size_t wave_row_bytes(int n, int k) {
   return (size_t)n * 8 + (((size_t)n * 2 + 7) & ~(size_t)7) + (size_t)k * 8 + 96 * 4;
 }
 
+// The states of up to kMaxK3Layers layers with the same (C, k), fed from one (L, B, C) candidate buffer (round 5: the hooks of L
+// identical transformer blocks merged by ONE launch; a single layer is a table of one).  "Virtual" component v of the L * C
+// belongs to layer v / C.
+constexpr int kMaxK3Layers = 32;
+struct K3States {
+  uint16_t* vals[kMaxK3Layers];
+  int64_t* ids[kMaxK3Layers];
+  int64_t id_base[kMaxK3Layers];
+};
+
 template <int ROWS>
-__global__ __launch_bounds__(64 * ROWS) void actmax_update_aten_wave_kernel(uint16_t* __restrict__ vals, int64_t* __restrict__ ids,
-                                                                            int64_t C, int k, const uint16_t* __restrict__ cand,
-                                                                            const int64_t* __restrict__ sample_ids,
-                                                                            int64_t id_base, int B) {
+__global__ __launch_bounds__(64 * ROWS) void actmax_update_aten_wave_kernel(K3States tab, int64_t C, int64_t Ctot, int k,
+                                                                            const uint16_t* __restrict__ cand,
+                                                                            const int64_t* __restrict__ sample_ids, int B) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int n = k + B;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -244,30 +253,36 @@ __global__ __launch_bounds__(64 * ROWS) void actmax_update_aten_wave_kernel(uint
   // consecutive threads take the ROWS adjacent components of one sample (ROWS x 2 contiguous bytes)
   for (int idx = threadIdx.x; idx < B * ROWS; idx += 64 * ROWS) {
     const int b = idx / ROWS, r = idx % ROWS;
-    if (c0 + r < C) {
-      const uint16_t h = cand[(int64_t)b * C + c0 + r];
+    const int64_t v = c0 + r;
+    if (v < Ctot) {
+      const int64_t l = v / C, c = v - l * C;
+      const uint16_t h = cand[(l * B + b) * C + c];
       rowA(r)[k + b] = (bf16_order_key(h) << 16) | (uint32_t)(k + b);
       rowRaw(r)[k + b] = h;
     }
   }
   for (int idx = threadIdx.x; idx < k * ROWS; idx += 64 * ROWS) {
     const int r = idx / k, j = idx % k;
-    if (c0 + r < C) {
-      const int64_t so = (c0 + r) * k + j;
-      const uint16_t h = vals[so];
+    const int64_t v = c0 + r;
+    if (v < Ctot) {
+      const int64_t l = v / C, so = (v - l * C) * k + j;
+      const uint16_t h = tab.vals[l][so];
       rowA(r)[j] = (bf16_order_key(h) << 16) | (uint32_t)j;
       rowRaw(r)[j] = h;
-      rowIds(r)[j] = ids[so];
+      rowIds(r)[j] = tab.ids[l][so];
     }
   }
   __syncthreads();  // the only workgroup barrier: from here on every wave owns its row
-  if (c0 + w >= C) return;
+  if (c0 + w >= Ctot) return;
   uint32_t* A = rowA(w);
   wave_topk_row(A, rowT(w), rowStk(w), n, k, lane);  // :140
   // gather values / ids through the selected positions — :140-141 (the old state was copied to LDS above: in place is safe)
   const uint16_t* raw = rowRaw(w);
   const int64_t* old_ids = rowIds(w);
-  const int64_t so = (c0 + w) * k;
+  const int64_t l = (c0 + w) / C, so = (c0 + w - l * C) * k;
+  uint16_t* vals = tab.vals[l];
+  int64_t* ids = tab.ids[l];
+  const int64_t id_base = tab.id_base[l];
   for (int j0 = 0; j0 < k; j0 += 64) {
     const int j = j0 + lane;
     if (j < k) {
@@ -281,6 +296,37 @@ __global__ __launch_bounds__(64 * ROWS) void actmax_update_aten_wave_kernel(uint
 constexpr size_t kLdsBudget = 64 * 1024;
 constexpr size_t kLdsMax = 160 * 1024;
 
+bool wave_impl() {  // SL_K3_ATEN_IMPL = wave (default) | lane (round 4: one lane per row)
+  static const int impl = [] {
+    const char* e = getenv("SL_K3_ATEN_IMPL");
+    return (e && strcmp(e, "lane") == 0) ? 0 : 1;
+  }();
+  return impl == 1;
+}
+
+int launch_wave(ProfScope& prof, const K3States& tab, int L, int64_t C, int64_t k, const uint16_t* d_cand, const int64_t* d_sample_ids,
+                int64_t B, hipStream_t st) {
+  const int64_t n = k + B, Ctot = (int64_t)L * C;
+  const size_t rb = wave_row_bytes((int)n, (int)k);
+#define SL_K3_WAVE(ROWS_)                                                                                                        \
+  do {                                                                                                                           \
+    const size_t lds = rb * ROWS_;                                                                                               \
+    if (lds > kLdsBudget)                                                                                                        \
+      SL_CHECK_HIP(hipFuncSetAttribute((const void*)actmax_update_aten_wave_kernel<ROWS_>,                                        \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                    \
+    SL_LAUNCH(prof, actmax_update_aten_wave_kernel<ROWS_>, dim3((unsigned)((Ctot + ROWS_ - 1) / ROWS_)), dim3(64 * ROWS_), lds,    \
+              st, tab, C, Ctot, (int)k, d_cand, d_sample_ids, (int)B);                                                             \
+  } while (0)
+  // eight rows per workgroup (16 contiguous candidate bytes per sample) while the rows fit; fewer for long rows or few components
+  if (rb * 8 <= kLdsBudget && Ctot >= 1024) SL_K3_WAVE(8);
+  else if (rb * 4 <= kLdsBudget && Ctot >= 256) SL_K3_WAVE(4);
+  else if (rb * 2 <= kLdsMax && Ctot >= 2) SL_K3_WAVE(2);
+  else SL_K3_WAVE(1);
+#undef SL_K3_WAVE
+  SL_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace
 
 int actmax_update_aten(ProfScope& prof, uint16_t* d_vals, int64_t* d_ids, int64_t C, int64_t k, const uint16_t* d_cand,
@@ -291,29 +337,10 @@ int actmax_update_aten(ProfScope& prof, uint16_t* d_vals, int64_t* d_ids, int64_
   SL_REQUIRE(d_ws && ws_bytes >= sl_actmax_aten_ws_bytes(C, k, B),
              "sl_actmax_update(SL_TIES_ATEN): workspace too small (%zu < %zu)", ws_bytes,
              sl_actmax_aten_ws_bytes(C, k, B));
-  static const int impl = [] {  // SL_K3_ATEN_IMPL = wave (default) | lane (round 4: one lane per row)
-    const char* e = getenv("SL_K3_ATEN_IMPL");
-    return (e && strcmp(e, "lane") == 0) ? 0 : 1;
-  }();
-  const size_t rb = wave_row_bytes((int)n, (int)k);
-  if (impl == 1 && n <= 65535 && rb <= kLdsMax) {
-#define SL_K3_WAVE(ROWS_)                                                                                                        \
-  do {                                                                                                                           \
-    const size_t lds = rb * ROWS_;                                                                                               \
-    if (lds > kLdsBudget)                                                                                                        \
-      SL_CHECK_HIP(hipFuncSetAttribute((const void*)actmax_update_aten_wave_kernel<ROWS_>,                                        \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                    \
-    SL_LAUNCH(prof, actmax_update_aten_wave_kernel<ROWS_>, dim3((unsigned)((C + ROWS_ - 1) / ROWS_)), dim3(64 * ROWS_), lds, st,   \
-              d_vals, d_ids, C, (int)k, d_cand, d_sample_ids, id_base, (int)B);                                                    \
-  } while (0)
-    // eight rows per workgroup (16 contiguous candidate bytes per sample) while the rows fit; fewer for long rows or few components
-    if (rb * 8 <= kLdsBudget && C >= 1024) SL_K3_WAVE(8);
-    else if (rb * 4 <= kLdsBudget && C >= 256) SL_K3_WAVE(4);
-    else if (rb * 2 <= kLdsMax && C >= 2) SL_K3_WAVE(2);
-    else SL_K3_WAVE(1);
-#undef SL_K3_WAVE
-    SL_CHECK_HIP(hipGetLastError());
-    return 0;
+  if (wave_impl() && n <= 65535 && wave_row_bytes((int)n, (int)k) <= kLdsMax) {
+    K3States tab;
+    tab.vals[0] = d_vals, tab.ids[0] = d_ids, tab.id_base[0] = id_base;
+    return launch_wave(prof, tab, 1, C, k, d_cand, d_sample_ids, B, st);
   }
   int rpb = (int)((C + 511) / 512);  // spread rows over >= 512 waves when C allows
   const int lds_cap = (int)(kLdsBudget / ((size_t)n * 4));
@@ -330,6 +357,34 @@ int actmax_update_aten(ProfScope& prof, uint16_t* d_vals, int64_t* d_ids, int64_
 }
 
 }  // namespace sl
+
+SL_API int sl_actmax_update_multi_supported(int64_t C, int64_t k, int64_t B) {
+  const int64_t n = k + B;
+  return (C >= 1 && k >= 1 && B >= 1 && sl::wave_impl() && n <= 16384 && sl::wave_row_bytes((int)n, (int)k) <= sl::kLdsMax) ? 1 : 0;
+}
+
+SL_API int sl_actmax_update_multi(uint16_t* const* h_d_vals, int64_t* const* h_d_ids, const int64_t* h_id_bases, int L, int64_t C,
+                                  int64_t k, const uint16_t* d_cand, int64_t B, void* stream) {
+  using namespace sl;
+  SL_REQUIRE(L >= 0 && C >= 0 && k >= 0 && B >= 0, "sl_actmax_update_multi: negative shape");
+  if (L == 0 || C * k == 0 || B == 0) return 0;
+  SL_REQUIRE(h_d_vals && h_d_ids && h_id_bases && d_cand, "sl_actmax_update_multi: null pointer");
+  SL_REQUIRE(sl_actmax_update_multi_supported(C, k, B), "sl_actmax_update_multi: k + B = %lld rows do not fit the one-wave-per-row kernel "
+             "(update the layers one by one with sl_actmax_update)", (long long)(k + B));
+  hipStream_t st = (hipStream_t)stream;
+  for (int l0 = 0; l0 < L; l0 += kMaxK3Layers) {
+    const int n = L - l0 < kMaxK3Layers ? L - l0 : kMaxK3Layers;
+    K3States tab;
+    for (int i = 0; i < n; ++i) {
+      SL_REQUIRE(h_d_vals[l0 + i] && h_d_ids[l0 + i], "sl_actmax_update_multi: null state");
+      tab.vals[i] = h_d_vals[l0 + i], tab.ids[i] = h_d_ids[l0 + i], tab.id_base[i] = h_id_bases[l0 + i];
+    }
+    ProfScope prof(SL_PROF_MERGE, st, (double)n * ((double)B * C * 2 + (double)C * k * 10));
+    const int rc = launch_wave(prof, tab, n, C, k, d_cand + (int64_t)l0 * B * C, nullptr, B, st);
+    if (rc) return rc;
+  }
+  return 0;
+}
 
 SL_API size_t sl_actmax_aten_ws_bytes(int64_t C, int64_t k, int64_t B) {
   (void)B;

@@ -901,8 +901,18 @@ __global__ __launch_bounds__(64 * NW) void colreduce_kernel(const E* __restrict_
 // sets, ping-pong), so 8-16 loads per lane are in flight from the first block to the last.  No predicated loads: a row past the
 // end is clamped to the last row (a cache hit) and its values are discarded by the accumulator's `valid` flag, so the last
 // block costs one round trip like any other.
+// Round 5: the input is a TABLE of up to kMaxReduceSources same-shape tensors (the outputs of L identical transformer blocks,
+// kept alive until the last one exists): "virtual" batch b of the B = L * per batches lives in tensor b / per at batch b % per,
+// and the (L, per, F) outputs are one contiguous buffer, so nothing else in the kernel changes.  One 1.9 GB launch instead of
+// twelve 155 MB ones: the ~2.5 us a launch costs beyond bytes / 6.45 TB/s is paid once (a single tensor is a table of one).
+constexpr int kMaxReduceSources = 32;
+struct MultiSrc {
+  const void* ptr[kMaxReduceSources];
+  int64_t per;  // batches per tensor
+};
+
 template <typename E, int OP, int NW, int LPR, int INFL>
-__global__ __launch_bounds__(64 * NW) void colreduce2_kernel(const E* __restrict__ x, int64_t B, int T, int64_t F, int64_t sb,
+__global__ __launch_bounds__(64 * NW) void colreduce2_kernel(MultiSrc src, int64_t B, int T, int64_t F, int64_t sb,
                                                               int64_t st, int t_begin, int t_end, float denom, int64_t tail_from,
                                                               uint16_t* __restrict__ cand, float* __restrict__ outf) {
   constexpr int EPP = 16 / (int)sizeof(E);
@@ -943,7 +953,8 @@ __global__ __launch_bounds__(64 * NW) void colreduce2_kernel(const E* __restrict
     const int64_t b = task / nchunk;
     const int64_t f0 = (task % nchunk) * CW + (int64_t)pl * EPP;
     const bool in = f0 < F;  // F % EPP == 0 on this path; lanes past the row re-read its first piece and are never stored
-    const u32x4* base = reinterpret_cast<const u32x4*>(x + b * sb + (in ? f0 : 0));
+    const E* x = static_cast<const E*>(src.ptr[b / src.per]);
+    const u32x4* base = reinterpret_cast<const u32x4*>(x + (b % src.per) * sb + (in ? f0 : 0));
     // max ops: v_max_f32 drops NaN, torch.amax propagates it.  As in K1 a running SUM rides along (v_pk_add_f32: NaN in => NaN
     // out) and only columns whose sum is NaN (a NaN, or +inf with -inf) are looked at again, exactly.  Rows past the end are
     // CLAMPED to the last row: a duplicate changes neither a max nor the detector's verdict; sums mask them instead.
@@ -1351,7 +1362,7 @@ void dispatch_rowreduce(ProfScope& prof, const float* x, int64_t R, int S, float
 // per SIMD); with 8 the half-precision kernels need 140 registers and fall from 5.3 to 4.0 TB/s, fp32 gains nothing
 constexpr int kCol2Infl = 4;
 template <typename T, int OP, int NW, int LPR>
-void launch_colreduce2_as(ProfScope& prof, const T* x, int64_t B, int T_, int64_t F, int64_t sb, int64_t st_, int t0, int t1,
+void launch_colreduce2_as(ProfScope& prof, const MultiSrc& x, int64_t B, int T_, int64_t F, int64_t sb, int64_t st_, int t0, int t1,
                           float denom, int64_t tail_from, uint16_t* cand, float* outf, hipStream_t st) {
   constexpr int CW = LPR * (16 / (int)sizeof(T));
   int64_t blocks = B * ((F + CW - 1) / CW);
@@ -1361,8 +1372,9 @@ void launch_colreduce2_as(ProfScope& prof, const T* x, int64_t B, int T_, int64_
             t1, denom, tail_from, cand, outf);
 }
 
+// `x`: a table of L = B / x.per tensors of x.per batches each (L = 1: one tensor); B counts the batches of all of them
 template <typename T, int OP>
-bool launch_colreduce2(ProfScope& prof, const T* x, int64_t B, int T_, int64_t F, int64_t sb, int64_t st_, int t0, int t1,
+bool launch_colreduce2(ProfScope& prof, const MultiSrc& x, int64_t B, int T_, int64_t F, int64_t sb, int64_t st_, int t0, int t1,
                        float denom, uint16_t* cand, float* outf, hipStream_t st) {
   static const int impl = [] {  // SL_COLREDUCE_IMPL = v2 (default) | vgpr (rounds 1-3) | dma (LDS-DMA rings; -DSL_K2_DMA_LAB builds only)
     const char* e = getenv("SL_COLREDUCE_IMPL");
@@ -1378,7 +1390,10 @@ bool launch_colreduce2(ProfScope& prof, const T* x, int64_t B, int T_, int64_t F
   }();
   constexpr int EPP = 16 / (int)sizeof(T);
   const int64_t rows = t1 - t0;
-  if (impl != 1 || ((uintptr_t)x & 15) != 0 || (F % EPP) != 0 || ((st_ * (int64_t)sizeof(T)) & 15) != 0 ||
+  const int64_t L = B / x.per;
+  bool aligned = true;
+  for (int64_t l = 0; l < L; ++l) aligned = aligned && ((uintptr_t)x.ptr[l] & 15) == 0;
+  if (impl != 1 || !aligned || (F % EPP) != 0 || ((st_ * (int64_t)sizeof(T)) & 15) != 0 ||
       ((sb * (int64_t)sizeof(T)) & 15) != 0 || rows < 1)
     return false;
   // lanes per row: the widest chunk that wastes no lane, else the one that wastes least (ties: wider = fewer tasks)
@@ -1391,8 +1406,10 @@ bool launch_colreduce2(ProfScope& prof, const T* x, int64_t B, int T_, int64_t F
   }
   if (forced_lpr == 64 || forced_lpr == 32 || forced_lpr == 16) lpr = forced_lpr;
   const int64_t cw = (int64_t)lpr * EPP, nchunk = (F + cw - 1) / cw, tasks = B * nchunk, cus = num_cus();
-  const int64_t nt_min_bytes = nt_min_bytes_(), tail_bytes = tail_bytes_();
+  const int64_t nt_min_bytes = nt_min_bytes_();
   const int64_t per_b = (int64_t)T_ * F * (int64_t)sizeof(T), all = B * per_b;
+  // of a table of tensors only the LAST one was written a moment ago: the default-policy tail never reaches into the others
+  const int64_t tail_bytes = (L > 1 && tail_bytes_() > x.per * per_b) ? x.per * per_b : tail_bytes_();
   int64_t tail_from = 0;
   if (all >= nt_min_bytes) tail_from = tail_bytes > 0 ? (all > tail_bytes ? (all - tail_bytes) / per_b * nchunk : 0) : INT64_MAX;
   // waves per task split the reduced axis; a wave instruction covers 64 / lpr rows, so short axes want few waves
@@ -1434,7 +1451,10 @@ bool launch_colreduce2(ProfScope& prof, const T* x, int64_t B, int T_, int64_t F
 template <typename T, int OP>
 void launch_colreduce(ProfScope& prof, const T* x, int64_t B, int T_, int64_t F, int64_t sb, int64_t st_, int t0, int t1,
                       float denom, uint16_t* cand, float* outf, hipStream_t st) {
-  if (launch_colreduce2<T, OP>(prof, x, B, T_, F, sb, st_, t0, t1, denom, cand, outf, st)) return;
+  MultiSrc one;
+  one.ptr[0] = x;
+  one.per = B;
+  if (launch_colreduce2<T, OP>(prof, one, B, T_, F, sb, st_, t0, t1, denom, cand, outf, st)) return;
 #ifdef SL_K2_DMA_LAB
   if (launch_colreduce_dma<T, OP>(prof, x, B, T_, F, sb, st_, t0, t1, denom, cand, outf, st)) return;
 #endif
@@ -1582,6 +1602,44 @@ int reduce_dispatch(ProfScope& prof, const void* x, int dtype, int64_t B, int64_
 
 int dtype_size(int dtype) { return dtype == SL_F32 ? 4 : 2; }
 
+// L same-shape (B, C, S) activations -> (L, B, C) candidates.  ONE launch when the component axis is contiguous (tokens,
+// channels_last: colreduce2 over a table of tensors), tensor by tensor otherwise — the same values either way.
+template <int OP>
+int reduce_dispatch_multi(const void* const* xs, int L, int dtype, int64_t B, int64_t C, int64_t S, int64_t sb, int64_t sc, int64_t ss,
+                          int64_t s0, int64_t s1, uint16_t* cand, hipStream_t st, bool plain_sum = false) {
+  const float denom = plain_sum ? 1.f : (float)(s1 - s0);
+  const double work = (double)B * C * (s1 - s0) * dtype_size(dtype);
+  for (int l0 = 0; l0 < L; l0 += kMaxReduceSources) {
+    const int n = L - l0 < kMaxReduceSources ? L - l0 : kMaxReduceSources;
+    uint16_t* out = cand + (int64_t)l0 * B * C;
+    bool done = false;
+    if (n > 1 && sc == 1 && S < (1 << 30) && (ss % 4) == 0 && (sb % 4) == 0 && (C % 4) == 0) {
+      MultiSrc src;
+      for (int i = 0; i < n; ++i) src.ptr[i] = xs[l0 + i];
+      src.per = B;
+      ProfScope prof(SL_PROF_REDUCE, st, work * n);
+      if (dtype == SL_F32)
+        done = launch_colreduce2<float, OP>(prof, src, n * B, (int)S, C, sb, ss, (int)s0, (int)s1, denom, out, nullptr, st);
+      else if (dtype == SL_F16)
+        done = launch_colreduce2<_Float16, OP>(prof, src, n * B, (int)S, C, sb, ss, (int)s0, (int)s1, denom, out, nullptr, st);
+      else
+        done = launch_colreduce2<uint16_t, OP>(prof, src, n * B, (int)S, C, sb, ss, (int)s0, (int)s1, denom, out, nullptr, st);
+      if (done) {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "reduce kernel launch");
+      }
+    }
+    if (!done) {
+      for (int i = 0; i < n; ++i) {
+        ProfScope prof(SL_PROF_REDUCE, st, work);
+        const int rc = reduce_dispatch<OP>(prof, xs[l0 + i], dtype, B, C, S, sb, sc, ss, s0, s1, out + (int64_t)i * B * C, nullptr, st, plain_sum);
+        if (rc) return rc;
+      }
+    }
+  }
+  return 0;
+}
+
 void set_reduce_policy(int64_t nt_min_bytes, int64_t tail_bytes) {
   g_nt_min_bytes = nt_min_bytes;
   g_tail_bytes = tail_bytes;
@@ -1604,6 +1662,47 @@ SL_API int sl_reduce_conv(const void* d_act, int dtype, int64_t B, int64_t C, in
   ProfScope prof(SL_PROF_REDUCE, st, (double)B * C * S * dtype_size(dtype));
   if (agg == SL_CONV_MAX) return reduce_dispatch<OP_MAX>(prof, d_act, dtype, B, C, S, sb, sc, ss, 0, S, d_cand_bf16, d_out_f32, st);
   return reduce_dispatch<OP_SUM>(prof, d_act, dtype, B, C, S, sb, sc, ss, 0, S, d_cand_bf16, d_out_f32, st, agg == SL_CONV_SUM);
+}
+
+SL_API int sl_reduce_conv_multi(const void* const* h_d_acts, int L, int dtype, int64_t B, int64_t C, int64_t S, int64_t sb, int64_t sc,
+                                int64_t ss, int agg, uint16_t* d_cand_bf16, void* stream) {
+  SL_REQUIRE(L >= 0 && B >= 0 && C >= 0 && S >= 0, "sl_reduce_conv_multi: negative shape");
+  SL_REQUIRE(dtype >= SL_F32 && dtype <= SL_BF16, "sl_reduce_conv_multi: bad dtype %d", dtype);
+  SL_REQUIRE(agg == SL_CONV_MAX || agg == SL_CONV_MEAN || agg == SL_CONV_SUM, "sl_reduce_conv_multi: bad agg %d", agg);
+  if (L == 0 || B * C == 0) return 0;
+  SL_REQUIRE(h_d_acts && d_cand_bf16, "sl_reduce_conv_multi: null pointer");
+  for (int l = 0; l < L; ++l) SL_REQUIRE(h_d_acts[l] || S == 0, "sl_reduce_conv_multi: null activation");
+  hipStream_t st = (hipStream_t)stream;
+  if (agg == SL_CONV_MAX) return reduce_dispatch_multi<OP_MAX>(h_d_acts, L, dtype, B, C, S, sb, sc, ss, 0, S, d_cand_bf16, st);
+  return reduce_dispatch_multi<OP_SUM>(h_d_acts, L, dtype, B, C, S, sb, sc, ss, 0, S, d_cand_bf16, st, agg == SL_CONV_SUM);
+}
+
+SL_API int sl_reduce_tokens_multi(const void* const* h_d_acts, int L, int dtype, int64_t B, int64_t T, int64_t F, int64_t sb, int64_t st_,
+                                  int64_t sf, int agg, int64_t pos, uint16_t* d_cand_bf16, void* stream) {
+  SL_REQUIRE(L >= 0 && B >= 0 && T >= 0 && F >= 0, "sl_reduce_tokens_multi: negative shape");
+  SL_REQUIRE(dtype >= SL_F32 && dtype <= SL_BF16, "sl_reduce_tokens_multi: bad dtype %d", dtype);
+  SL_REQUIRE(agg >= SL_TOK_MEAN && agg <= SL_TOK_TOKEN, "sl_reduce_tokens_multi: bad agg %d", agg);
+  if (L == 0 || B * F == 0) return 0;
+  SL_REQUIRE(h_d_acts && d_cand_bf16, "sl_reduce_tokens_multi: null pointer");
+  for (int l = 0; l < L; ++l) SL_REQUIRE(h_d_acts[l] || T == 0, "sl_reduce_tokens_multi: null activation");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t t0 = 0, t1 = T;
+  if (agg == SL_TOK_TOKEN) {
+    int64_t p = pos < 0 ? pos + T : pos;
+    SL_REQUIRE(p >= 0 && p < T, "sl_reduce_tokens: token position %lld out of range for T=%lld", (long long)pos, (long long)T);
+    t0 = p;
+    t1 = p + 1;
+  }
+  switch (agg) {
+    case SL_TOK_MEAN:
+      return reduce_dispatch_multi<OP_SUM>(h_d_acts, L, dtype, B, F, T, sb, sf, st_, t0, t1, d_cand_bf16, st);
+    case SL_TOK_ABSMEAN:
+      return reduce_dispatch_multi<OP_ABSSUM>(h_d_acts, L, dtype, B, F, T, sb, sf, st_, t0, t1, d_cand_bf16, st);
+    case SL_TOK_ABSMAX:
+      return reduce_dispatch_multi<OP_ABSMAX>(h_d_acts, L, dtype, B, F, T, sb, sf, st_, t0, t1, d_cand_bf16, st);
+    default:
+      return reduce_dispatch_multi<OP_MAX>(h_d_acts, L, dtype, B, F, T, sb, sf, st_, t0, t1, d_cand_bf16, st);
+  }
 }
 
 // x (B,C) fp32 in place: x[b][:] /= (sum_c |x[b][c]| + eps)   (crp ChannelConcept.reference_sampling, abs_norm)

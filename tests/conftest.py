@@ -30,7 +30,7 @@ def golden():
 # tolerance assert on an encoder tower can never again keep the kernel parity suite from running (round 4: 280 tests unreached).
 _GPU_FILE_ORDER = (
     "test_gpu_parity", "test_gpu_pipeline", "test_gpu_preprocess", "test_gpu_properties", "test_gpu_fullsize",
-    "test_gpu_config1", "test_gpu_configs", "test_gpu_robustness", "test_gpu_distributed",
+    "test_gpu_config1", "test_gpu_configs", "test_gpu_robustness", "test_gpu_groups", "test_gpu_distributed",
     "test_gpu_native_clip", "test_gpu_openclip_layout", "test_gpu_relevance",
 )
 
