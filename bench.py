@@ -574,10 +574,12 @@ def config3_leg(dev, args):
     db = {}
     out = collect_leg(
         dev, fm, args, vit, layers, aggregators.aggregate_transformer_max,
-        "colreduce2 (K2, (B, 197, 768) token activations, component axis contiguous)",
+        "colreduce2 (K2, (B, 197, 768) token activations, component axis contiguous; the 12 identical block outputs of a batch "
+        "are reduced by ONE launch over a table of tensors once the last block has fired — 1.86 GB at B = 256 — and merged by "
+        "one K3 launch; a collector's first batch runs layer by layer)",
         "BASELINE configs[3], full geometry: ViT-B/16 (random init) probed model, all 12 encoder blocks (B,197,768) fp32, "
         "aggregate_transformer_max, 7 262 208 B/image; embed = NativeSigLip at the SigLIP-so400m geometry (27 x 1152, 16 heads "
-        "of 72, MLP 4304, patch 14 -> 256 tokens, D = 1152), on the same stream", steps=4, B=B, check_n=B, overlap=False, keep_db=db)
+        "of 72, MLP 4304, patch 14 -> 256 tokens, D = 1152), on the same stream", steps=8, B=B, check_n=B, overlap=False, keep_db=db)
     assert all(v.shape == (768, args.k, 1152) for v in db.values()) and len(db) == 12
     agg_db = {name: v.mean(1) for name, v in db.items()}  # what a user hands text_probing (README: `concept_db[layer].mean(1)`)
     lens = Lens(fm, device=dev)
@@ -635,6 +637,19 @@ def config4_leg(dev, fm, args):
         keep_db=db, overlap=False)
     widths = (192, 384, 768, 1536)
     assert all(db[n].shape == (c, args.k, 512) for n, c in zip(layers, widths))
+    # the same collect with block outputs written NCHW-contiguous (synth.ConvNeXtBlock nchw_out): the depthwise convolutions stay
+    # on MIOpen's NCHW kernels instead of its naive NHWC one (60 % of the forward above) and K1 runs its row kernel
+    model_nchw = synth.convnext_l(nchw_out=True).to(dev)
+    model_nchw.load_state_dict(model.state_dict())
+    nchw = collect_leg(
+        dev, fm, args, model_nchw, layers, aggregators.aggregate_conv_max,
+        "rowreduce (K1, NCHW-contiguous fp32 stage outputs: rows of S = 3136 / 784 / 196 / 49 floats)",
+        "the same ConvNeXt-L weights with every block's residual sum written NCHW-contiguous (one transposing add per block)",
+        steps=4, B=B, check_n=B, overlap=False)
+    out["nchw_block_outputs"] = {k_: nchw[k_] for k_ in ("workload", "images_per_s", "roofline", "reduce_cache_policy") if k_ in nchw}
+    out["nchw_block_outputs"]["self_check"] = nchw.get("self_check")
+    del model_nchw, nchw
+    torch.cuda.empty_cache()
 
     # ---- (ii) relevance visualizer: forward + LRP backward per batch, both top-k states ----
     n_rel, b_rel = 128, 32
@@ -717,7 +732,7 @@ def config4_leg(dev, fm, args):
         "components": comps, "k": args.k, "D": 512, "input_bytes": in_bytes,
         "clarity_k7": {"bound": "hbm", "achieved": by_cl / ms_cl / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                        "frac": by_cl / ms_cl / 1e6 / HBM_PEAK_GBPS, "kernel_ms": ms_cl, "launches": n_cl, "wall_ms": w_cl * 1e3,
-                       "note": "C*n*D*4 bytes read once; the 4 layers are 2.4-19 MB each: launch-latency-sized"},
+                       "note": "C*n*D*4 bytes read once; all four layers (2.4-19 MB each) in ONE sl_clarity_multi launch"},
         "polysemanticity_k9": {"bound": "valu/lds", "components_per_s": comps / w_po, "kernel_ms": ms_po, "launches": n_po, "wall_ms": w_po * 1e3,
                                "input_GBps": by_po / ms_po / 1e6,
                                "note": "Gram matrix of each component from C*n*D*4 input bytes (read once), then sklearn's k-means++ / "

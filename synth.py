@@ -407,8 +407,9 @@ class _LayerNorm2d(nn.LayerNorm):
 class ConvNeXtBlock(nn.Module):
     """Liu et al. 2022: 7x7 depthwise conv -> LayerNorm -> 1x1 (4x) -> GELU -> 1x1 -> layer scale -> residual."""
 
-    def __init__(self, dim, layer_scale=1e-6):
+    def __init__(self, dim, layer_scale=1e-6, nchw_out=False):
         super().__init__()
+        self.nchw_out = nchw_out
         self.dwconv = nn.Conv2d(dim, dim, 7, padding=3, groups=dim)
         self.norm = nn.LayerNorm(dim, eps=1e-6)
         self.pwconv1 = nn.Linear(dim, 4 * dim)
@@ -419,6 +420,12 @@ class ConvNeXtBlock(nn.Module):
     def forward(self, x):
         h = self.dwconv(x).permute(0, 2, 3, 1)
         h = self.pwconv2(self.act(self.pwconv1(self.norm(h)))) * self.gamma
+        if self.nchw_out:
+            # `x + h.permute(...)` takes the permuted branch's layout: every block output — and so every later depthwise
+            # convolution's input — is channels_last-strided (torchvision's and timm's blocks behave the same), which on ROCm sends
+            # the 7x7 depthwise convolutions to MIOpen's naive NHWC kernel (60 % of the forward).  This variant writes the sum
+            # NCHW-contiguous instead (one transposing add), keeping the convolutions on their NCHW kernels.
+            return torch.add(x, h.permute(0, 3, 1, 2), out=torch.empty_like(x, memory_format=torch.contiguous_format))
         return x + h.permute(0, 3, 1, 2)
 
 
@@ -427,12 +434,13 @@ class ConvNeXt(nn.Module):
     front of stages 1-3, global average pool, LayerNorm, linear head.  ``stages.<i>`` outputs ``(B, dims[i], 56 >> i, 56 >> i)``
     at 224 x 224: ConvNeXt-L = depths (3, 3, 27, 3), dims (192, 384, 768, 1536) -> S = 3136 / 784 / 196 / 49."""
 
-    def __init__(self, depths=(3, 3, 27, 3), dims=(192, 384, 768, 1536), num_classes=1000, layer_scale=1e-6):
+    def __init__(self, depths=(3, 3, 27, 3), dims=(192, 384, 768, 1536), num_classes=1000, layer_scale=1e-6, nchw_out=False):
         super().__init__()
         self.downsample_layers = nn.ModuleList([nn.Sequential(nn.Conv2d(3, dims[0], 4, 4), _LayerNorm2d(dims[0], eps=1e-6))])
         for i in range(3):
             self.downsample_layers.append(nn.Sequential(_LayerNorm2d(dims[i], eps=1e-6), nn.Conv2d(dims[i], dims[i + 1], 2, 2)))
-        self.stages = nn.ModuleList([nn.Sequential(*[ConvNeXtBlock(d, layer_scale) for _ in range(n)]) for n, d in zip(depths, dims)])
+        self.stages = nn.ModuleList([nn.Sequential(*[ConvNeXtBlock(d, layer_scale, nchw_out) for _ in range(n)])
+                                     for n, d in zip(depths, dims)])
         self.norm = nn.LayerNorm(dims[-1], eps=1e-6)
         self.head = nn.Linear(dims[-1], num_classes)
         for m in self.modules():
