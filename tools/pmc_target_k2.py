@@ -25,6 +25,12 @@ def main():
             N.reduce_tokens(xs[i % nbuf], N.SL_TOK_MAX, 0, cand, None)
         torch.cuda.synchronize()
         del xs
+    # round 5: the table form — twelve (256, 197, 768) block outputs in ONE launch (sl_reduce_tokens_multi), 1.86 GB
+    xs = [torch.randn((256, 197, 768), device=DEV) for _ in range(12)]
+    cand = torch.empty((12, 256, 768), dtype=torch.bfloat16, device=DEV)
+    for _ in range(REPS):
+        N.reduce_multi("tokens", xs, N.SL_TOK_MAX, 0, cand)
+    torch.cuda.synchronize()
 
 
 if __name__ == "__main__":

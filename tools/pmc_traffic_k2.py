@@ -6,7 +6,7 @@ of the bytes of wide streaming reads: x 2 x 1024; WRITE_SIZE in KiB).  Rows are 
 import csv
 import sys
 
-SHAPES = [((256, 197, 768), 4), ((256, 197, 768), 2), ((256, 3136, 192), 4), ((256, 784, 384), 4), ((256, 196, 768), 4), ((256, 49, 1536), 4)]
+SHAPES = [((12 * 256, 197, 768), 4), ((256, 197, 768), 4), ((256, 197, 768), 2), ((256, 3136, 192), 4), ((256, 784, 384), 4), ((256, 196, 768), 4), ((256, 49, 1536), 4)]
 
 
 def load(path, counter):
