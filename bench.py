@@ -145,7 +145,8 @@ def finish_job(cv, embeds, id_start, n_total, sharded):
     if sharded:
         sld.merge_actmax_cache(cv.actmax_cache)
         return {n: sld.gather_concept_db_sharded(embeds, id_start, n_total, cv.get_max_reference(n)) for n in cv.layer_names}
-    return {n: N.gather_rows(embeds, cv.actmax_cache.cache[n].device_state()[1]) for n in cv.layer_names}
+    # one K5 launch over the ids of all layers (what `_compute_concept_db` runs), straight from the device-resident states
+    return cv._gather_layers(embeds, {n: cv.actmax_cache.cache[n].device_state()[1] for n in cv.layer_names}, True)
 
 
 @torch.no_grad()
@@ -497,7 +498,8 @@ def policy_report(cv):
     return out
 
 
-def collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, cast=None, check_n=None, overlap=None, keep_db=None):
+def collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, cast=None, check_n=None, overlap=None, keep_db=None,
+                traffic_key=None):
     """A short run of the same step on another probed model / aggregator / activation dtype, so that the reduce kernel that
     configuration selects gets its own driver-measured roofline object (algorithmic bytes / per-dispatch HIP-event time, as
     for the headline) and its own oracle self-check.  ``overlap``: embed on a second stream (None = as the headline)."""
@@ -506,12 +508,12 @@ def collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, c
     if overlap is not None:
         OVERLAP = bool(overlap)
     try:
-        return _collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, cast, check_n, keep_db)
+        return _collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, cast, check_n, keep_db, traffic_key)
     finally:
         OVERLAP = saved
 
 
-def _collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, cast, check_n, keep_db=None):
+def _collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, cast, check_n, keep_db=None, traffic_key=None):
     # MIOpen / hipBLASLt pick their kernels, and each hooked layer's reduce settles its cache policy (N.ReducePolicyTuner: 8 launches)
     warm = [synth.synth_images_u8(torch.arange(10**7 + (i % 2) * B, 10**7 + (i % 2 + 1) * B, device=dev)) for i in range(2)] * 5
     cv_w = make_cv(model, 10 * B, args.k, args.tie_mode, layers, agg)
@@ -533,10 +535,24 @@ def _collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, 
         keep_db.update(db)
     del db
     gbps = nbytes / ms / 1e6 if ms else None
+    # HBM bytes per launch from separate rocprofv3 --pmc passes over the same kernel instances (profiles/roofline_traffic.json
+    # "legs": read = 2 x FETCH_SIZE x 1024 per MI355X_MICROARCH.md): the measured traffic / algorithmic ratio of the leg's kernel
+    # applied to this run's algorithmic bytes per launch; not measured in this run, and said so
+    traffic, traffic_source = None, None
+    try:
+        legs = json.loads((ROOT / "profiles" / "roofline_traffic.json").read_text()).get("legs", {})
+        ratio = legs.get(traffic_key or "", {}).get("traffic_over_algorithmic")
+        if ratio and launches:
+            traffic = ratio * nbytes / launches
+            traffic_source = (f"{legs.get('source')}: HBM read bytes / algorithmic bytes = {ratio} for this kernel at these shapes, "
+                              "applied to this run's algorithmic bytes per launch")
+    except Exception:
+        pass
     out = {
         "workload": workload, "images_per_s": n / dt, "steps": steps, "batch": B, "reduce_cache_policy": policy_report(cv),
         "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": gbps / HBM_PEAK_GBPS if gbps else None, "traffic": None, "kernel": kernel, "launches": launches,
+                     "frac": gbps / HBM_PEAK_GBPS if gbps else None, "traffic": traffic, "traffic_source": traffic_source,
+                     "kernel": kernel, "launches": launches,
                      "avg_launch_us": ms / max(launches, 1) * 1e3, "algorithmic_bytes_per_launch": nbytes / max(launches, 1),
                      "condition": "in-pipeline: inputs written by the model's last kernel microseconds earlier, "
                                   + ("embed on a second stream" if OVERLAP else "embed on the same stream")},
@@ -579,7 +595,8 @@ def config3_leg(dev, args):
         "one K3 launch; a collector's first batch runs layer by layer)",
         "BASELINE configs[3], full geometry: ViT-B/16 (random init) probed model, all 12 encoder blocks (B,197,768) fp32, "
         "aggregate_transformer_max, 7 262 208 B/image; embed = NativeSigLip at the SigLIP-so400m geometry (27 x 1152, 16 heads "
-        "of 72, MLP 4304, patch 14 -> 256 tokens, D = 1152), on the same stream", steps=8, B=B, check_n=B, overlap=False, keep_db=db)
+        "of 72, MLP 4304, patch 14 -> 256 tokens, D = 1152), on the same stream", steps=8, B=B, check_n=B, overlap=False, keep_db=db,
+        traffic_key="config3_full")
     assert all(v.shape == (768, args.k, 1152) for v in db.values()) and len(db) == 12
     agg_db = {name: v.mean(1) for name, v in db.items()}  # what a user hands text_probing (README: `concept_db[layer].mean(1)`)
     lens = Lens(fm, device=dev)
@@ -634,7 +651,7 @@ def config4_leg(dev, fm, args):
         "BASELINE configs[4] collect stage: ConvNeXt-L (random init) probed model, stages.0-3 outputs fp32 NCHW, aggregate_conv_max, "
         "4 515 840 B/image (the stage outputs arrive channels_last — the residual add takes its permuted branch's layout — so K1 "
         "runs its component-contiguous kernel); embed = the headline's CLIP ViT-B/32, on the same stream", steps=4, B=B, check_n=B,
-        keep_db=db, overlap=False)
+        keep_db=db, overlap=False, traffic_key="config4_full")
     widths = (192, 384, 768, 1536)
     assert all(db[n].shape == (c, args.k, 512) for n, c in zip(layers, widths))
     # the same collect with block outputs written NCHW-contiguous (synth.ConvNeXtBlock nchw_out): the depthwise convolutions stay
