@@ -1134,6 +1134,13 @@ def main():
         # are fp32 values carried as two bf16 halves (three MFMA products, fp32 accumulate: 8e-7 on cosines, tolerance 1e-4);
         # `images_per_s_fp32_gemm` is the same job with no bf16 operand anywhere
         "dtype": {"native": "f32 (encoder GEMMs split-bf16x3, fp32 accumulate)", "native-f32": "f32", "torch": "f32"}[args.fm],
+        # the rule behind that parenthesis (tests/test_gpu_native_clip.py, profiles/r05_tower_accuracy.txt): a 3-product bf16 split
+        # carries ~2^-16 relative error per product; un-normalised features land within ~1e-5 of their scale — 2-4e-5 absolute at
+        # scale 3-4 with residual channels at 150-300 injected (bar: 1e-4 absolute vs float64), cosines 2-4e-7; `--fm native-f32`
+        # (NativeClip(gemm="f32")) is the fp32-MFMA arithmetic at torch-fp32's own distance from float64 (4-7e-6)
+        "dtype_note": "bf16x3 = fp32 operands as two bf16 halves, three MFMA products, fp32 accumulate: features within 1e-4 absolute of "
+                      "float64 also with massive activations (2-4e-5 measured), cosines 2-4e-7; images_per_s_fp32_gemm is the same job in "
+                      "fp32-MFMA arithmetic (no bf16 operand anywhere)",
         "data": "synthetic",
         "config": {
             "workload": "BASELINE configs[1]: ResNet-50 (random init) layer2-4, synthetic 224x224 images, "
