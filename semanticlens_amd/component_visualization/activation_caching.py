@@ -337,6 +337,7 @@ class ActMaxCache(ActCache):
         # grouped, and every later launch re-checks the versions (an in-place edit raises instead of collecting wrong values).
         # The reference's tie order only (`tie_mode="aten"`); SEMANTICLENS_AMD_GROUP_LAYERS=0 switches it off.
         self._grouping = self.tie_mode == "aten" and os.environ.get("SEMANTICLENS_AMD_GROUP_LAYERS", "1") != "0"
+        self._group_device_types = ("cuda",)  # host tensors only in tests/test_layer_groups_host.py (kernels replaced by stand-ins)
         self._probe: dict[str, tuple] | None = {}  # first batch: layer -> (signature, tensor, version); None once planned
         self._group_of: dict[str, int] = {}
         self._groups: list[dict] = []
@@ -404,7 +405,7 @@ class ActMaxCache(ActCache):
         """True when ``outs`` was taken over (stashed, or collected with its group); False = collect it now, alone."""
         if self._probe is not None:
             if layer_name not in self._probe:
-                if outs.is_cuda:
+                if outs.device.type in self._group_device_types:
                     self._probe[layer_name] = (self._signature(outs, native), outs.detach(), self._version(outs))
                 return False
             self._plan_groups()  # a layer fires for the second time: the first batch is over
@@ -414,14 +415,14 @@ class ActMaxCache(ActCache):
             return False
         group = self._groups[gid]
         self.cache[layer_name]._before_flush = (lambda g=gid: self._flush_group(g))  # the ActMax may have been replaced (load)
-        stash = group["stash"]
-        if layer_name in stash:  # the previous forward did not reach every member: finish it layer by layer
+        if layer_name in group["stash"]:  # the previous forward did not reach every member: finish it layer by layer
             self._flush_group(gid)
-        if stash:
-            first = next(iter(stash.values()))
+        if group["stash"]:
+            first = next(iter(group["stash"].values()))
             if self._signature(first[0], first[3]) != self._signature(outs, native) or first[0].shape[0] != outs.shape[0]:
                 self._flush_group(gid)
                 return False
+        stash = group["stash"]  # (_flush_group installs a fresh dict)
         stash[layer_name] = (outs.detach(), version, start, native, module)
         if len(stash) == len(group["layers"]):
             self._run_group(gid)
