@@ -170,3 +170,20 @@ def test_colreduce2_fuzz_against_the_oracle(seed, nw):
     res = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_k2.py"), str(seed), "150"], env=env, capture_output=True, text=True,
                          timeout=600, cwd=root)
     assert res.returncode == 0 and "fuzz_k2 ok: 150 cases" in res.stdout, (res.stdout[-600:], res.stderr[-1500:])
+
+
+@pytest.mark.parametrize("B,c,k", [(6000, 5, 20), (3000, 9, 100), (15000, 3, 20), (1279, 40, 20), (1281, 40, 20), (700, 300, 7)])
+def test_aten_update_long_rows_and_both_branches(B, c, k):
+    """K3 in the reference's tie order at row lengths that change the kernel's shape: rows of tens of KB in LDS (one or two rows per
+    workgroup, more than 64 KB of dynamic LDS), rows too long for the LDS (the one-lane-per-row kernel), and batch sizes on both
+    sides of torch.topk's `k * 64 <= n` switch between partial_sort and nth_element + sort."""
+    rng = np.random.RandomState(B + c + k)
+    am = ActMax(k, c, tie_mode="aten")
+    ref = oracle.ActMaxOracle(k, c, oracle.MODE_ATEN)
+    for step in range(2):
+        acts = (rng.randint(0, 40, size=(B, c)).astype(np.float32) / 8) if step else np.maximum(rng.randn(B, c), 0).astype(np.float32)
+        ids = np.arange(step * B, (step + 1) * B)
+        am.update(torch.from_numpy(acts), torch.from_numpy(ids))
+        ref.update(acts, ids)
+        assert np.array_equal(bits(am.activations), ref.vals), step
+        assert np.array_equal(am.sample_ids.numpy(), ref.ids), step
