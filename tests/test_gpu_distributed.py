@@ -138,7 +138,9 @@ def _bench_line(extra_env, args, nproc):
 def test_bench_two_ranks_sharing_one_gpu_over_gloo():
     """BASELINE configs[2] code path (`bench.py --gpus N`): per-rank collect, packed all-gather, K4 merge, sharded K5
     gather + all-reduce, max-over-ranks timing — with two ranks on ONE GPU and gloo as the transport."""
-    line = _bench_line({"SL_BENCH_BACKEND": "gloo", "SL_BENCH_SHARE_GPU": "1"}, ["--steps", "3", "--batches-per-step", "2", "--warmup", "1", "--batch", "64", "--min-warmup-seconds", "0.3"], 2)
+    line = _bench_line({"SL_BENCH_BACKEND": "gloo", "SL_BENCH_SHARE_GPU": "1"}, ["--steps", "3", "--batches-per-step", "2", "--warmup", "1", "--batch", "64", "--min-warmup-seconds", "0.3",
+                                                                                 "--strong-images", "1500", "--strong-pool-batches", "4"], 2)
+    assert line["strong_scaling"]["images"] == 1500 and line["strong_scaling"]["tie_mode"] == "total"  # (the default is the 1.28 M-image job: 200 s here)
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
     assert line["config"]["images_total"] == 2 * 3 * 2 * 64 and line["value"] > 0
     line = _bench_line({"SL_BENCH_BACKEND": "gloo", "SL_BENCH_SHARE_GPU": "1"},
