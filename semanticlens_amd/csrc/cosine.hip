@@ -38,6 +38,8 @@ struct CosineEpi {
   int64_t N;
   __device__ inline float column(int64_t col) const { return rb[col]; }
   __device__ inline void store(int64_t row, int64_t col, float acc, float cv) const { __builtin_nontemporal_store(acc * ra[row] * cv, &out[row * N + col]); }
+  // the same epilogue for a GEMM over columns [c0, ...) of the output (gemm_bf16x3.hpp: column-strip split)
+  CosineEpi shifted(int64_t c0) const { return CosineEpi{ra, rb + c0, out + c0, N}; }
 };
 // operands were normalised before the bf16 split: the accumulator is the cosine
 struct PlainEpi {
@@ -45,6 +47,7 @@ struct PlainEpi {
   int64_t N;
   __device__ inline float column(int64_t) const { return 0.f; }
   __device__ inline void store(int64_t row, int64_t col, float acc, float) const { __builtin_nontemporal_store(acc, &out[row * N + col]); }
+  PlainEpi shifted(int64_t c0) const { return PlainEpi{out + c0, N}; }
 };
 
 size_t align256_(size_t n) { return (n + 255) & ~(size_t)255; }
@@ -118,14 +121,21 @@ struct MultiEpi {
   float* out[kMaxFusedLayers];
   int64_t start[kMaxFusedLayers + 1];
   int n;
+  int64_t c0;  // column-strip split: this launch's column 0 is column c0 of the concatenation
   __device__ float column(int64_t col) const {
+    col += c0;
     int l = 0;
     while (l + 1 < n && col >= start[l + 1]) ++l;
     return __int_as_float(l);
   }
   __device__ void store(int64_t row, int64_t col, float acc, float cv) const {
     const int l = __float_as_int(cv);
-    __builtin_nontemporal_store(acc, &out[l][row * (start[l + 1] - start[l]) + (col - start[l])]);
+    __builtin_nontemporal_store(acc, &out[l][row * (start[l + 1] - start[l]) + (col + c0 - start[l])]);
+  }
+  MultiEpi shifted(int64_t by) const {
+    MultiEpi e = *this;
+    e.c0 += by;
+    return e;
   }
 };
 
@@ -142,14 +152,21 @@ struct MultiCosineEpi {
   int n;
   const float* ra;
   const float* rb;
+  int64_t c0;
   __device__ LayerCol column(int64_t col) const {
+    col += c0;
     int l = 0;
     while (l + 1 < n && col >= start[l + 1]) ++l;
     return LayerCol{l, rb[col]};
   }
   __device__ void store(int64_t row, int64_t col, float acc, LayerCol cv) const {
     const int l = cv.layer;
-    __builtin_nontemporal_store(acc * ra[row] * cv.rinv, &out[l][row * (start[l + 1] - start[l]) + (col - start[l])]);
+    __builtin_nontemporal_store(acc * ra[row] * cv.rinv, &out[l][row * (start[l + 1] - start[l]) + (col + c0 - start[l])]);
+  }
+  MultiCosineEpi shifted(int64_t by) const {
+    MultiCosineEpi e = *this;
+    e.c0 += by;
+    return e;
   }
 };
 

@@ -63,6 +63,16 @@ struct LinearEpi {
     if (rem >= g) { q += 1; rem -= g; }
   }
   __device__ inline float column(int64_t col) const { return bias ? bias[col] : 0.f; }
+  // the same epilogue for a GEMM over columns [c0, ...) of the output (c0 a multiple of 32; gemm_bf16x3.hpp: column-strip split)
+  LinearEpi shifted(int64_t c0) const {
+    LinearEpi e = *this;
+    if (e.bias) e.bias += c0;
+    if (e.res) e.res += c0;
+    if (e.out) e.out += c0;
+    if (e.out_sp) e.out_sp += (c0 >> 5) * 64;  // split_pos: 64 elements per 32-column tile of a row
+    if (e.rowadd) e.rowadd += c0;
+    return e;
+  }
   // what `store` adds from memory, fetched ahead of the stores by kernels that batch their epilogue (gemm_8phase.hpp);
   // `store_fetched(..., fetch(row, col))` == `store(...)` bit for bit (same operands, same order of additions)
   static constexpr bool kFetches = RES || REMAP;

@@ -1006,6 +1006,53 @@ torch.save(outs, sys.argv[1])
         assert err <= 2e-6 * max(scale, 1.0) * 4, (i, err, scale)
 
 
+def test_column_strip_split_keeps_every_bit(tmp_path):
+    """A GEMM whose last column tile is partial may be cut at the last full tile (gemm_bf16x3.hpp `strip_split_columns`: the big
+    kernel on the first 256 n columns, the strip's own kernel on the rest with the epilogue shifted): same bits as the uncut GEMM
+    (`SL_G3_STRIP=0`) for every epilogue — plain, cosine routing over several layers, bias, residual in place, GELU -> split output,
+    scattered rows + positional table — at shapes the cost model does cut (so400m's N = 1152 and 4304 at 64 images, 3 x 257 layers)."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[2])
+from semanticlens_amd import _native as N
+torch.manual_seed(0)
+dev = "cuda:0"
+outs = []
+for (M, Nn, K) in [(16384, 1152, 96), (16384, 4304, 64), (16130, 1100, 40)]:
+    x = torch.randn(M, K, device=dev); w = torch.randn(Nn, K, device=dev) * 0.1; b = torch.randn(Nn, device=dev)
+    sx, sw = N.Split.of(x), N.Split.of(w)
+    res = torch.randn(M, Nn, device=dev)
+    o1 = N.linear3(sx, sw, b)
+    o2 = res.clone(); N.linear3(sx, sw, b, residual=o2, out=o2)
+    sp = N.Split(M, Nn, dev); N.linear3(sx, sw, b, act=N.SL_ACT_GELU, out_split=sp)
+    outs += [o1.cpu(), o2.cpu(), sp.hi.cpu().view(torch.int16), sp.lo.cpu().view(torch.int16)]
+    if M % 64 == 0:  # rows scattered behind a class-token row per group of 64, positional rows added
+        T = 65
+        tab = torch.randn(T, Nn, device=dev)
+        o4 = torch.zeros((M // 64) * T, Nn, device=dev)
+        N.linear3(sx, sw, b, out=o4, scatter=(64, T, 1), rowadd=tab)
+        outs.append(o4.cpu())
+q = torch.randn(16384, 72, device=dev)
+outs.append(N.similarity(q, torch.randn(1152, 72, device=dev)).cpu())
+layers = [torch.randn(c, 72, device=dev) for c in (257, 640, 255)]  # 1152 columns routed to three outputs
+outs += [o.cpu() for o in N.similarity_multi(q, layers)]
+torch.save(outs, sys.argv[1])
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for strip in ("1", "0"):
+        out = tmp_path / f"strip_{strip}.pt"
+        subprocess.run([sys.executable, "-c", code, str(out), root], check=True, env=dict(os.environ, SL_G3_STRIP=strip))
+        res[strip] = torch.load(out)
+    assert len(res["1"]) == len(res["0"]) >= 15
+    for i, (a, b) in enumerate(zip(res["1"], res["0"])):
+        assert torch.equal(a, b), (i, tuple(a.shape))
+
+
 @pytest.mark.parametrize("rpg,gs,ro", [(1, 3, 1), (2, 2, 0), (7, 9, 2), (49, 50, 1), (197, 200, 3), (1000, 1001, 1)])
 def test_linear_row_scatter_maps_rows_exactly(rpg, gs, ro):
     """The scattering epilogue (patch embeddings land behind the class token of their image and take their row of the positional
