@@ -81,6 +81,24 @@ def test_sharded_merge_two_ranks_gloo(tmp_path):
             assert np.array_equal(got[f"i_{name}"], ref.ids), (name, r)
 
 
+def test_sharded_merge_eight_ranks_gloo(tmp_path):
+    """BASELINE configs[2]'s rank count: 8 ranks, 150 samples in shards of 19 (the last one 17), ONE packed all-gather, every rank
+    ends with the single-process top-k (tie-heavy values: the total order must not depend on which rank held a sample)."""
+    import oracle
+
+    rng = np.random.RandomState(8)
+    acts = {"a": (rng.randint(0, 24, size=(150, 10)) / 8.0).astype(np.float32), "b": np.maximum(rng.randn(150, 7), 0).astype(np.float32)}
+    k = 11
+    mp.spawn(_worker, args=(8, _free_port(), acts, k, str(tmp_path)), nprocs=8, join=True)
+    for name in ("a", "b"):
+        ref = oracle.ActMaxOracle(k, acts[name].shape[1], oracle.MODE_TOTAL)
+        ref.update(acts[name], np.arange(150))
+        for r in range(8):
+            got = np.load(tmp_path / f"rank{r}.npz")
+            assert np.array_equal(got[f"v_{name}"].view(np.uint16), ref.vals), (name, r)
+            assert np.array_equal(got[f"i_{name}"], ref.ids), (name, r)
+
+
 def test_sharded_merge_with_an_empty_shard_gloo(tmp_path):
     """N=2 samples over 3 ranks: the last rank's shard is empty — it must still take part in the all-gather (with
     sentinel states of the agreed width) and end with the global top-k."""
