@@ -53,7 +53,7 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])  # 8 = BASELINE configs[2]'s rank count (47 samples: shards of 6, the last one 5)
 def test_sharded_build_equals_single_process(world, tmp_path):
     cv, fm = _build()
     want = cv._compute_concept_db(fm, batch_size=8)
