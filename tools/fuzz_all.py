@@ -181,12 +181,18 @@ def fuzz_scores(n=120):
             nc = int(rng.randint(2, min(k, 6) + 1))
             got = scores.polysemanticity_score(Vd, n_clusters=nc); sync()
             want = oracle.polysemanticity(V, n_clusters=nc)
-            try:
-                np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-5, atol=1e-5, err_msg=f"poly k={nc}")
-            except AssertionError:  # keep the case for a post-mortem on the host (near-tie or defect?)
+            g = got.cpu().numpy()
+            bad = np.where(np.abs(g - want) > 1e-5 + 1e-5 * np.abs(want))[0]
+            if len(bad):
+                # scikit-learn's own outcome hangs on BLAS rounding when k-means++ meets a structural candidate tie (two mutually
+                # nearest outliers: tools/k9_postmortem.py); such components are reported, anything else is a defect
+                from k9_postmortem import near_tie
+
                 Path("gpurun_out").mkdir(exist_ok=True)
-                np.savez(f"gpurun_out/fuzz_poly_fail_seed{seed}_{it}.npz", V=V, nc=nc, got=got.cpu().numpy(), want=want)
-                raise
+                np.savez(f"gpurun_out/fuzz_poly_fail_seed{seed}_{it}.npz", V=V, nc=nc, got=g, want=want)
+                for c in bad:
+                    assert near_tie(V[c], nc), f"poly k={nc}: component {c} differs ({g[c]} vs {want[c]}) without a tie in sklearn's decisions"
+                    print(f"   poly k={nc}: component {c} differs ({g[c]:.6f} vs {want[c]:.6f}) at a structural k-means++ tie", flush=True)
 
 
 def fuzz_preprocess(n=120):
