@@ -19,7 +19,10 @@
 //     point, strict-convergence / tol = mean(var) * 1e-4 tests, max_iter 300, final E-step when not
 //     strictly converged), best-of-n_init by inertia unless `_is_same_clustering`.
 // fp64 Gram-space arithmetic is not bit-identical to sklearn's coordinate arithmetic; decisions can
-// differ only on numerical near-ties (measured agreement: see DESIGN.md).
+// differ only on numerical near-ties.  One kind is structural, not a coincidence: two mutually nearest outliers j1, j2
+// (nobody else closer to them than the centres chosen so far) have k-means++ potentials S + d(j1, j2) EACH, so which of
+// the two scikit-learn takes hangs on the rounding of its BLAS distances (tools/k9_postmortem.py; ~1 in 1 500 components
+// of tiny random inputs ends in another clustering for it: profiles/r05_k9_near_tie.txt).
 #include "common.hpp"
 
 namespace sl {
