@@ -127,11 +127,12 @@ int sl_actmax_update(uint16_t* d_vals, int64_t* d_ids, int64_t C, int64_t k, con
                      const int64_t* d_sample_ids, int64_t id_base, int64_t B, int ties, void* d_ws, size_t ws_bytes,
                      void* stream);
 size_t sl_actmax_aten_ws_bytes(int64_t C, int64_t k, int64_t B);
-/* SL_TIES_ATEN update of L states of one (C, k) from one (L, B, C) candidate buffer (sl_reduce_*_multi's output) in one launch;
- * h_id_bases: the sample id of each layer's first candidate row (the reference's per-layer counter, activation_caching.py:410-413).
+/* SL_TIES_ATEN update of L states (their own component counts h_Cs[l], one k) from L candidate matrices (B, C_l) in ONE launch
+ * — every hooked layer of a forward pass merged once per batch instead of once per layer (activation_caching.py:388-418 fires per
+ * layer).  h_id_bases: the sample id of each layer's first candidate row (the reference's per-layer counter, :410-413).
  * `_supported`: 1 when (k + B) rows fit the one-wavefront-per-row kernel, else update layer by layer. */
-int sl_actmax_update_multi(uint16_t* const* h_d_vals, int64_t* const* h_d_ids, const int64_t* h_id_bases, int L, int64_t C,
-                           int64_t k, const uint16_t* d_cand, int64_t B, void* stream);
+int sl_actmax_update_multi(uint16_t* const* h_d_vals, int64_t* const* h_d_ids, const int64_t* h_id_bases, const int64_t* h_Cs,
+                           const uint16_t* const* h_d_cands, int L, int64_t k, int64_t B, void* stream);
 int sl_actmax_update_multi_supported(int64_t C, int64_t k, int64_t B);
 
 /* ---- K4: merge R other states (e.g. all-gathered per-rank states) into this one ----------

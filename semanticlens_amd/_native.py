@@ -47,7 +47,7 @@ SIGNATURES = {
     "sl_actmax_merge": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _int, _vp]),
     "sl_actmax_update": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _int, _vp, _sz, _vp]),
     "sl_actmax_aten_ws_bytes": (_sz, [_i64, _i64, _i64]),
-    "sl_actmax_update_multi": (_int, [_vp, _vp, _vp, _int, _i64, _i64, _vp, _i64, _vp]),
+    "sl_actmax_update_multi": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _vp]),
     "sl_actmax_update_multi_supported": (_int, [_i64, _i64, _i64]),
     "sl_reduce_conv_multi": (_int, [_vp, _int, _int, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp]),
     "sl_reduce_tokens_multi": (_int, [_vp, _int, _int, _i64, _i64, _i64, _i64, _i64, _i64, _int, _i64, _vp, _vp]),
@@ -292,16 +292,18 @@ def actmax_update_multi_supported(C: int, k: int, B: int) -> bool:
     return bool(lib().sl_actmax_update_multi_supported(C, k, B))
 
 
-def actmax_update_multi(states: list[tuple[torch.Tensor, torch.Tensor]], cand: torch.Tensor, id_bases: list[int], B: int):
-    """``SL_TIES_ATEN`` update of ``L`` states ``(C, k)`` from ``cand`` ``(L, B, C)`` in one launch."""
+def actmax_update_multi(states: list[tuple[torch.Tensor, torch.Tensor]], cands: list[torch.Tensor], id_bases: list[int], B: int):
+    """``SL_TIES_ATEN`` update of ``L`` states ``(C_l, k)`` from ``L`` candidate matrices ``(B, C_l)`` bf16 in one launch."""
     L = len(states)
-    C, k = states[0][0].shape
-    assert cand.is_contiguous() and tuple(cand.shape) == (L, B, C)
+    k = states[0][0].shape[1]
+    assert len(cands) == L and all(c.is_contiguous() and tuple(c.shape) == (B, v.shape[0]) and v.shape[1] == k for c, (v, _) in zip(cands, states))
     vp = (_vp * L)(*[v.data_ptr() for v, _ in states])
     ip = (_vp * L)(*[i.data_ptr() for _, i in states])
+    cp = (_vp * L)(*[c.data_ptr() for c in cands])
     hb = (_i64 * L)(*id_bases)
-    with _on(cand.device):
-        rc = lib().sl_actmax_update_multi(vp, ip, hb, L, C, k, _ptr(cand), B, _stream(cand))
+    hc = (_i64 * L)(*[v.shape[0] for v, _ in states])
+    with _on(cands[0].device):
+        rc = lib().sl_actmax_update_multi(vp, ip, hb, hc, cp, L, k, B, _stream(cands[0]))
     _check(rc, "sl_actmax_update_multi")
 
 

@@ -169,9 +169,10 @@ class ActMax:
         N.actmax_update(vals, ids, cand, sid, 0, B, N.TIE_MODES[self.tie_mode], self._aten_ws(B, a.device))
         self._dev_newer = True
 
-    def collect(self, outs: torch.Tensor, native: tuple, id_base: int, site=None):
+    def collect(self, outs: torch.Tensor, native: tuple, id_base: int, site=None, k3_queue=None):
         """Fused hook path: reduce ``outs`` on the device and merge; samples get ids id_base + b.  ``site``: what identifies the
-        producer of ``outs`` (the hooked module), for the cache-policy tuner of its reduce."""
+        producer of ``outs`` (the hooked module), for the cache-policy tuner of its reduce.  ``k3_queue(act_max, cand, id_base, B)``
+        (``ActMaxCache``, reference tie order only): takes the merge over, to run it with the other layers' of this forward."""
         kind, code, pos = native
         x = N.to_device(outs.detach())
         B = x.shape[0]
@@ -197,6 +198,9 @@ class ActMax:
         else:
             self._policy_tuner.run(lambda: N.reduce_tokens(x, code, pos, cand, None), x.numel() * x.element_size(), B)
         if self.tie_mode == "aten":
+            if k3_queue is not None:
+                k3_queue(self, cand, id_base, B)
+                return
             N.actmax_update(vals, ids, cand, None, id_base, B, N.SL_TIES_ATEN, self._aten_ws(B, x.device))
             self._dev_newer = True
         else:
@@ -338,6 +342,15 @@ class ActMaxCache(ActCache):
         # The reference's tie order only (`tie_mode="aten"`); SEMANTICLENS_AMD_GROUP_LAYERS=0 switches it off.
         self._grouping = self.tie_mode == "aten" and os.environ.get("SEMANTICLENS_AMD_GROUP_LAYERS", "1") != "0"
         self._group_device_types = ("cuda",)  # host tensors only in tests/test_layer_groups_host.py (kernels replaced by stand-ins)
+        # ---- one top-k merge per forward (round 5) ----
+        # K3's time is a chain of LDS round trips per row, not a function of the number of rows, so the merges of ALL hooked layers
+        # of a forward (any shapes: each layer keeps its own candidate matrix) wait for the last layer and run as ONE
+        # `sl_actmax_update_multi` launch: ResNet-50 layer2-4 3 x 18-20 us -> ~24.  No activation is kept for this (K1 / K2 ran in
+        # the hook); the queue is flushed when the last layer of the first batch's firing order has fired, when a layer fires again,
+        # on any state read and when the hooks are removed.  SEMANTICLENS_AMD_BATCH_K3=0 switches it off.
+        self._batch_k3 = self._grouping and os.environ.get("SEMANTICLENS_AMD_BATCH_K3", "1") != "0"
+        self._k3_queue: list[tuple] = []  # (layer name, ActMax, candidates (B, C), id_base, B)
+        self._k3_last: str | None = None  # the last layer of a forward, known once the first batch is over
         self._probe: dict[str, tuple] | None = {}  # first batch: layer -> (signature, tensor, version); None once planned
         self._group_of: dict[str, int] = {}
         self._groups: list[dict] = []
@@ -362,7 +375,11 @@ class ActMaxCache(ActCache):
                 self.sample_idx_counter[layer_name] += batch_size
                 if self._grouping and self._collect_grouped(layer_name, module, outs, native, start):
                     return
-                self.cache[layer_name].collect(outs, native, start, site=(id(module), layer_name))
+                queue = None
+                if self._batch_k3 and self._k3_last is not None:
+                    self._flush_k3(only_if_queued=layer_name)  # its candidate buffer is about to be rewritten
+                    queue = (lambda am, cand, base, B, name=layer_name: self._enqueue_k3(name, am, cand, base, B))
+                self.cache[layer_name].collect(outs, native, start, site=(id(module), layer_name), k3_queue=queue)
                 return
             # user-defined aggregator: (B, C) tensor on any device, then K3 alone
             aggregated_acts = self.aggregation_fn(outs)
@@ -392,6 +409,10 @@ class ActMaxCache(ActCache):
         for name, (sig, tensor, version) in self._probe.items():
             if version is not None and self._version(tensor) == version:
                 by_sig.setdefault(sig[:3] + sig[4:], []).append(name)  # strides are re-checked per batch (they scale with B)
+        if self._batch_k3 and self._probe:
+            self._k3_last = list(self._probe)[-1]
+            for name in self._probe:
+                self.cache[name]._before_flush = self._flush_deferred
         self._probe = None
         for names in by_sig.values():
             if len(names) >= 2:
@@ -399,7 +420,7 @@ class ActMaxCache(ActCache):
                 self._groups.append({"layers": names, "stash": {}, "cand": {}})
                 for name in names:
                     self._group_of[name] = gid
-                    self.cache[name]._before_flush = (lambda g=gid: self._flush_group(g))
+                    self.cache[name]._before_flush = self._flush_deferred
 
     def _collect_grouped(self, layer_name, module, outs, native, start) -> bool:
         """True when ``outs`` was taken over (stashed, or collected with its group); False = collect it now, alone."""
@@ -414,7 +435,7 @@ class ActMaxCache(ActCache):
         if version is None:
             return False
         group = self._groups[gid]
-        self.cache[layer_name]._before_flush = (lambda g=gid: self._flush_group(g))  # the ActMax may have been replaced (load)
+        self.cache[layer_name]._before_flush = self._flush_deferred  # the ActMax may have been replaced (load)
         if layer_name in group["stash"]:  # the previous forward did not reach every member: finish it layer by layer
             self._flush_group(gid)
         if group["stash"]:
@@ -470,15 +491,59 @@ class ActMaxCache(ActCache):
         cand = group["cand"].get(B)
         if cand is None or cand.device != x0.device:
             cand = group["cand"][B] = torch.empty((len(names), B, C), dtype=torch.bfloat16, device=x0.device)
+        if any(q[0] in names for q in self._k3_queue):  # merges of an earlier forward still read this candidate buffer
+            self._flush_k3()
         N.reduce_multi(kind, [e[0] for e in entries], code, pos, cand)
-        N.actmax_update_multi(states, cand, [e[2] for e in entries], B)
+        if self._batch_k3 and self._k3_last is not None:
+            for l, (name, e) in enumerate(zip(names, entries)):
+                self._enqueue_k3(name, self.cache[name], cand[l], e[2], B)
+            return
+        N.actmax_update_multi(states, [cand[l] for l in range(len(names))], [e[2] for e in entries], B)
         for name in names:
             self.cache[name]._dev_newer = True
+
+    # ---- one top-k merge per forward ----------------------------------------------------------------------------------------
+    def _enqueue_k3(self, name, am, cand, id_base, B):
+        if any(q[0] == name for q in self._k3_queue) or (self._k3_queue and self._k3_queue[0][4] != B):
+            self._flush_k3()
+        self._k3_queue.append((name, am, cand, id_base, B))
+        stashed = sum(len(g["stash"]) for g in self._groups)
+        if name == self._k3_last and not stashed:
+            self._flush_k3()
+
+    def _flush_k3(self, only_if_queued: str | None = None):
+        """Run the queued merges: one launch for all of them (or layer by layer when k + B rows do not fit the wave kernel)."""
+        if not self._k3_queue or (only_if_queued is not None and not any(q[0] == only_if_queued for q in self._k3_queue)):
+            return
+        queue, self._k3_queue = self._k3_queue, []
+        B = queue[0][4]
+        states = []
+        for _, am, cand, _, _ in queue:
+            hook, am._before_flush = am._before_flush, None
+            try:
+                states.append(am._device_state(cand.device))
+            finally:
+                am._before_flush = hook
+        if len(queue) > 1 and N.actmax_update_multi_supported(max(q[1].n_latents for q in queue), self.n_collect, B):
+            N.actmax_update_multi(states, [q[2] for q in queue], [q[3] for q in queue], B)
+        else:
+            for (_, am, cand, id_base, _), (vals, ids) in zip(queue, states):
+                N.actmax_update(vals, ids, cand, None, id_base, B, N.SL_TIES_ATEN, am._aten_ws(B, cand.device))
+        for _, am, _, _, _ in queue:
+            am._dev_newer = True
+
+    def _flush_deferred(self):
+        """Everything a state read must see: stashed activations of every group, then the queued merges."""
+        for gid in range(len(self._groups)):
+            self._flush_group(gid)
+        self._flush_k3()
 
     def _flush_group(self, gid: int):
         """Collect whatever the group has stashed, layer by layer (a forward that did not reach every member, or a state read)."""
         group = self._groups[gid]
         stash, group["stash"] = group["stash"], {}
+        if stash:
+            self._flush_k3()  # a layer's merges run in batch order: queued ones first
         for name, (tensor, version, start, native, module) in stash.items():
             self._check_unmodified(name, tensor, version)
             am = self.cache[name]
@@ -489,8 +554,7 @@ class ActMaxCache(ActCache):
                 am._before_flush = hook
 
     def _finalize(self):
-        for gid in range(len(self._groups)):
-            self._flush_group(gid)
+        self._flush_deferred()
         if self._probe is not None:  # hooks removed before a second batch came: no tensor reference outlives the context
             self._probe = {}
         for act_max in self.cache.values():

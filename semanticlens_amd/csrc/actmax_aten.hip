@@ -225,24 +225,46 @@ __host__ __device__ inline size_t wave_row_bytes(int n, int k) {
   return (size_t)n * 8 + (((size_t)n * 2 + 7) & ~(size_t)7) + (size_t)k * 8 + 96 * 4;
 }
 
-// The states of up to kMaxK3Layers layers with the same (C, k), fed from one (L, B, C) candidate buffer (round 5: the hooks of L
-// identical transformer blocks merged by ONE launch; a single layer is a table of one).  "Virtual" component v of the L * C
-// belongs to layer v / C.
+// The states of up to kMaxK3Layers layers (their own component counts, one k) updated by ONE launch (round 5: every hooked layer
+// of a forward pass — the L identical blocks of a transformer, or ResNet-50's layer2-4 — merged once per batch; a single layer is
+// a table of one).  "Virtual" component v of the sum of the C_l belongs to the layer with cstart[l] <= v < cstart[l + 1]; each
+// layer has its own (B, C_l) candidate matrix.  The kernel's time is a chain of LDS round trips per row, not a function of the
+// number of rows (17 us at 512 rows, 19.8 at 2 048, 39.6 at 9 216), so three launches of 18-20 us become one of ~24.
 constexpr int kMaxK3Layers = 32;
 struct K3States {
   uint16_t* vals[kMaxK3Layers];
   int64_t* ids[kMaxK3Layers];
+  const uint16_t* cand[kMaxK3Layers];
   int64_t id_base[kMaxK3Layers];
+  int64_t cstart[kMaxK3Layers + 1];
 };
 
 template <int ROWS>
-__global__ __launch_bounds__(64 * ROWS) void actmax_update_aten_wave_kernel(K3States tab, int64_t C, int64_t Ctot, int k,
-                                                                            const uint16_t* __restrict__ cand,
+__global__ __launch_bounds__(64 * ROWS) void actmax_update_aten_wave_kernel(K3States tab, int L, int64_t Ctot, int k,
                                                                             const int64_t* __restrict__ sample_ids, int B) {
   extern __shared__ __align__(16) unsigned char smem[];
+  // where each of this workgroup's rows lives (the table is indexed with the uniform loop counter only: scalar loads)
+  __shared__ const uint16_t* s_cand[ROWS];
+  __shared__ uint16_t* s_vals[ROWS];
+  __shared__ int64_t* s_ids[ROWS];
+  __shared__ int64_t s_base[ROWS], s_c[ROWS], s_C[ROWS];
   const int n = k + B;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t c0 = (int64_t)blockIdx.x * ROWS;
+  if (threadIdx.x < ROWS) {
+    const int64_t v = c0 + threadIdx.x;
+    for (int l = 0; l < L; ++l) {
+      if (v >= tab.cstart[l] && v < tab.cstart[l + 1]) {
+        s_cand[threadIdx.x] = tab.cand[l];
+        s_vals[threadIdx.x] = tab.vals[l];
+        s_ids[threadIdx.x] = tab.ids[l];
+        s_base[threadIdx.x] = tab.id_base[l];
+        s_c[threadIdx.x] = v - tab.cstart[l];
+        s_C[threadIdx.x] = tab.cstart[l + 1] - tab.cstart[l];
+      }
+    }
+  }
+  __syncthreads();
   const size_t rb = wave_row_bytes(n, k);
   auto rowA = [&](int r) { return reinterpret_cast<uint32_t*>(smem + r * rb); };
   auto rowT = [&](int r) { return rowA(r) + n; };
@@ -250,39 +272,36 @@ __global__ __launch_bounds__(64 * ROWS) void actmax_update_aten_wave_kernel(K3St
   auto rowStk = [&](int r) { return reinterpret_cast<uint32_t*>(rowIds(r) + k); };
   auto rowRaw = [&](int r) { return reinterpret_cast<uint16_t*>(rowStk(r) + 96); };
   // all_acts = cat([state, batch_acts]) — activation_caching.py:137.  The (B, C) candidates are transposed on the way in:
-  // consecutive threads take the ROWS adjacent components of one sample (ROWS x 2 contiguous bytes)
+  // consecutive threads take the ROWS adjacent components of one sample (ROWS x 2 contiguous bytes within a layer)
   for (int idx = threadIdx.x; idx < B * ROWS; idx += 64 * ROWS) {
     const int b = idx / ROWS, r = idx % ROWS;
-    const int64_t v = c0 + r;
-    if (v < Ctot) {
-      const int64_t l = v / C, c = v - l * C;
-      const uint16_t h = cand[(l * B + b) * C + c];
+    if (c0 + r < Ctot) {
+      const uint16_t h = s_cand[r][(int64_t)b * s_C[r] + s_c[r]];
       rowA(r)[k + b] = (bf16_order_key(h) << 16) | (uint32_t)(k + b);
       rowRaw(r)[k + b] = h;
     }
   }
   for (int idx = threadIdx.x; idx < k * ROWS; idx += 64 * ROWS) {
     const int r = idx / k, j = idx % k;
-    const int64_t v = c0 + r;
-    if (v < Ctot) {
-      const int64_t l = v / C, so = (v - l * C) * k + j;
-      const uint16_t h = tab.vals[l][so];
+    if (c0 + r < Ctot) {
+      const int64_t so = s_c[r] * k + j;
+      const uint16_t h = s_vals[r][so];
       rowA(r)[j] = (bf16_order_key(h) << 16) | (uint32_t)j;
       rowRaw(r)[j] = h;
-      rowIds(r)[j] = tab.ids[l][so];
+      rowIds(r)[j] = s_ids[r][so];
     }
   }
-  __syncthreads();  // the only workgroup barrier: from here on every wave owns its row
+  __syncthreads();  // the last workgroup barrier: from here on every wave owns its row
   if (c0 + w >= Ctot) return;
   uint32_t* A = rowA(w);
   wave_topk_row(A, rowT(w), rowStk(w), n, k, lane);  // :140
   // gather values / ids through the selected positions — :140-141 (the old state was copied to LDS above: in place is safe)
   const uint16_t* raw = rowRaw(w);
   const int64_t* old_ids = rowIds(w);
-  const int64_t l = (c0 + w) / C, so = (c0 + w - l * C) * k;
-  uint16_t* vals = tab.vals[l];
-  int64_t* ids = tab.ids[l];
-  const int64_t id_base = tab.id_base[l];
+  const int64_t so = s_c[w] * k;
+  uint16_t* vals = s_vals[w];
+  int64_t* ids = s_ids[w];
+  const int64_t id_base = s_base[w];
   for (int j0 = 0; j0 < k; j0 += 64) {
     const int j = j0 + lane;
     if (j < k) {
@@ -304,9 +323,8 @@ bool wave_impl() {  // SL_K3_ATEN_IMPL = wave (default) | lane (round 4: one lan
   return impl == 1;
 }
 
-int launch_wave(ProfScope& prof, const K3States& tab, int L, int64_t C, int64_t k, const uint16_t* d_cand, const int64_t* d_sample_ids,
-                int64_t B, hipStream_t st) {
-  const int64_t n = k + B, Ctot = (int64_t)L * C;
+int launch_wave(ProfScope& prof, const K3States& tab, int L, int64_t k, const int64_t* d_sample_ids, int64_t B, hipStream_t st) {
+  const int64_t n = k + B, Ctot = tab.cstart[L];
   const size_t rb = wave_row_bytes((int)n, (int)k);
 #define SL_K3_WAVE(ROWS_)                                                                                                        \
   do {                                                                                                                           \
@@ -315,7 +333,7 @@ int launch_wave(ProfScope& prof, const K3States& tab, int L, int64_t C, int64_t 
       SL_CHECK_HIP(hipFuncSetAttribute((const void*)actmax_update_aten_wave_kernel<ROWS_>,                                        \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                    \
     SL_LAUNCH(prof, actmax_update_aten_wave_kernel<ROWS_>, dim3((unsigned)((Ctot + ROWS_ - 1) / ROWS_)), dim3(64 * ROWS_), lds,    \
-              st, tab, C, Ctot, (int)k, d_cand, d_sample_ids, (int)B);                                                             \
+              st, tab, L, Ctot, (int)k, d_sample_ids, (int)B);                                                             \
   } while (0)
   // eight rows per workgroup (16 contiguous candidate bytes per sample) while the rows fit; fewer for long rows or few components
   if (rb * 8 <= kLdsBudget && Ctot >= 1024) SL_K3_WAVE(8);
@@ -339,8 +357,9 @@ int actmax_update_aten(ProfScope& prof, uint16_t* d_vals, int64_t* d_ids, int64_
              sl_actmax_aten_ws_bytes(C, k, B));
   if (wave_impl() && n <= 65535 && wave_row_bytes((int)n, (int)k) <= kLdsMax) {
     K3States tab;
-    tab.vals[0] = d_vals, tab.ids[0] = d_ids, tab.id_base[0] = id_base;
-    return launch_wave(prof, tab, 1, C, k, d_cand, d_sample_ids, B, st);
+    tab.vals[0] = d_vals, tab.ids[0] = d_ids, tab.cand[0] = d_cand, tab.id_base[0] = id_base;
+    tab.cstart[0] = 0, tab.cstart[1] = C;
+    return launch_wave(prof, tab, 1, k, d_sample_ids, B, st);
   }
   int rpb = (int)((C + 511) / 512);  // spread rows over >= 512 waves when C allows
   const int lds_cap = (int)(kLdsBudget / ((size_t)n * 4));
@@ -363,24 +382,32 @@ SL_API int sl_actmax_update_multi_supported(int64_t C, int64_t k, int64_t B) {
   return (C >= 1 && k >= 1 && B >= 1 && sl::wave_impl() && n <= 16384 && sl::wave_row_bytes((int)n, (int)k) <= sl::kLdsMax) ? 1 : 0;
 }
 
-SL_API int sl_actmax_update_multi(uint16_t* const* h_d_vals, int64_t* const* h_d_ids, const int64_t* h_id_bases, int L, int64_t C,
-                                  int64_t k, const uint16_t* d_cand, int64_t B, void* stream) {
+SL_API int sl_actmax_update_multi(uint16_t* const* h_d_vals, int64_t* const* h_d_ids, const int64_t* h_id_bases, const int64_t* h_Cs,
+                                  const uint16_t* const* h_d_cands, int L, int64_t k, int64_t B, void* stream) {
   using namespace sl;
-  SL_REQUIRE(L >= 0 && C >= 0 && k >= 0 && B >= 0, "sl_actmax_update_multi: negative shape");
-  if (L == 0 || C * k == 0 || B == 0) return 0;
-  SL_REQUIRE(h_d_vals && h_d_ids && h_id_bases && d_cand, "sl_actmax_update_multi: null pointer");
-  SL_REQUIRE(sl_actmax_update_multi_supported(C, k, B), "sl_actmax_update_multi: k + B = %lld rows do not fit the one-wave-per-row kernel "
+  SL_REQUIRE(L >= 0 && k >= 0 && B >= 0, "sl_actmax_update_multi: negative shape");
+  if (L == 0 || k == 0 || B == 0) return 0;
+  SL_REQUIRE(h_d_vals && h_d_ids && h_id_bases && h_Cs && h_d_cands, "sl_actmax_update_multi: null pointer");
+  SL_REQUIRE(sl_actmax_update_multi_supported(1, k, B), "sl_actmax_update_multi: k + B = %lld rows do not fit the one-wave-per-row kernel "
              "(update the layers one by one with sl_actmax_update)", (long long)(k + B));
   hipStream_t st = (hipStream_t)stream;
   for (int l0 = 0; l0 < L; l0 += kMaxK3Layers) {
-    const int n = L - l0 < kMaxK3Layers ? L - l0 : kMaxK3Layers;
     K3States tab;
-    for (int i = 0; i < n; ++i) {
-      SL_REQUIRE(h_d_vals[l0 + i] && h_d_ids[l0 + i], "sl_actmax_update_multi: null state");
-      tab.vals[i] = h_d_vals[l0 + i], tab.ids[i] = h_d_ids[l0 + i], tab.id_base[i] = h_id_bases[l0 + i];
+    int n = 0;
+    int64_t total = 0;
+    for (int i = l0; i < L && i < l0 + kMaxK3Layers; ++i) {
+      SL_REQUIRE(h_Cs[i] >= 0, "sl_actmax_update_multi: negative component count");
+      if (h_Cs[i] == 0) continue;
+      SL_REQUIRE(h_d_vals[i] && h_d_ids[i] && h_d_cands[i], "sl_actmax_update_multi: null state or candidates");
+      tab.vals[n] = h_d_vals[i], tab.ids[n] = h_d_ids[i], tab.cand[n] = h_d_cands[i], tab.id_base[n] = h_id_bases[i];
+      tab.cstart[n] = total;
+      total += h_Cs[i];
+      ++n;
     }
-    ProfScope prof(SL_PROF_MERGE, st, (double)n * ((double)B * C * 2 + (double)C * k * 10));
-    const int rc = launch_wave(prof, tab, n, C, k, d_cand + (int64_t)l0 * B * C, nullptr, B, st);
+    if (n == 0) continue;
+    tab.cstart[n] = total;
+    ProfScope prof(SL_PROF_MERGE, st, (double)total * ((double)B * 2 + (double)k * 10));
+    const int rc = launch_wave(prof, tab, n, k, nullptr, B, st);
     if (rc) return rc;
   }
   return 0;

@@ -184,22 +184,52 @@ def test_multi_reduce_equals_tensor_by_tensor(dtype, code):
 
 def test_multi_update_equals_layer_by_layer():
     g = torch.Generator().manual_seed(7)
-    for L, C, k, B in ((4, 100, 20, 64), (2, 7, 3, 5), (33, 16, 9, 12), (3, 768, 20, 256)):
-        cand = (torch.randint(0, 9, (L, B, C), generator=g).float() / 4).to(torch.bfloat16).to(DEV)  # tie-heavy
+    for Cs, k, B in (([100] * 4, 20, 64), ([7, 7], 3, 5), ([16] * 33, 9, 12), ([768] * 3, 20, 256), ([512, 1024, 2048], 20, 256),
+                     ([5, 300, 1, 64, 17], 7, 33), ([192, 384, 768, 1536], 100, 64)):
+        L = len(Cs)
+        cands = [(torch.randint(0, 9, (B, C), generator=g).float() / 4).to(torch.bfloat16).to(DEV) for C in Cs]  # tie-heavy
         multi, single = [], []
-        for _ in range(L):
+        for C in Cs:
             for store in (multi, single):
                 v = torch.empty((C, k), dtype=torch.bfloat16, device=DEV)
                 i = torch.empty((C, k), dtype=torch.int64, device=DEV)
                 N.actmax_init(v, i)
                 store.append((v, i))
-        assert N.actmax_update_multi_supported(C, k, B)
+        assert N.actmax_update_multi_supported(max(Cs), k, B)
         for step in range(3):
             bases = [1000 * l + step * B for l in range(L)]
-            N.actmax_update_multi(multi, cand, bases, B)
+            N.actmax_update_multi(multi, cands, bases, B)
             for l, (v, i) in enumerate(single):
-                ws = torch.empty(N.actmax_aten_ws_bytes(C, k, B), dtype=torch.uint8, device=DEV)
-                N.actmax_update(v, i, cand[l], None, bases[l], B, N.SL_TIES_ATEN, ws)
-            cand = cand.roll(1, dims=1).contiguous()
+                ws = torch.empty(N.actmax_aten_ws_bytes(Cs[l], k, B), dtype=torch.uint8, device=DEV)
+                N.actmax_update(v, i, cands[l], None, bases[l], B, N.SL_TIES_ATEN, ws)
+            cands = [c.roll(1, dims=0).contiguous() for c in cands]
         for (v, i), (v1, i1) in zip(multi, single):
             assert torch.equal(v.view(torch.int16), v1.view(torch.int16)) and torch.equal(i, i1)
+
+
+def test_layers_of_different_shapes_share_one_merge_launch_per_forward(monkeypatch):
+    """ResNet-style hooking: three layers of three shapes.  Nothing is grouped or stashed (K1 runs inside every hook), but from the
+    second batch on the three top-k merges of a forward run as ONE launch when the last layer has fired; a state read between
+    layers of a forward and SEMANTICLENS_AMD_BATCH_K3=0 give the same states."""
+    torch.manual_seed(5)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU())
+            self.b = nn.Sequential(nn.Conv2d(8, 24, 3, stride=2, padding=1), nn.ReLU())
+            self.c = nn.Sequential(nn.Conv2d(24, 40, 3, stride=2, padding=1), nn.ReLU())
+
+        def forward(self, x):
+            return self.c(self.b(self.a(x))).mean((1, 2, 3))
+
+    model = Net().to(DEV).eval()
+    g = torch.Generator().manual_seed(6)
+    batches = [torch.randn(b, 3, 16, 16, generator=g).to(DEV) for b in (9, 9, 9, 9, 4)]
+    on = _run_stream(model, ["a", "b", "c"], agg.aggregate_conv_max, "conv", batches, read_mid=True, expect_launches=(15, 3 + 4))
+    assert not on._groups and on._k3_last == "c"
+    monkeypatch.setenv("SEMANTICLENS_AMD_BATCH_K3", "0")
+    off = _run_stream(model, ["a", "b", "c"], agg.aggregate_conv_max, "conv", batches, expect_launches=(15, 15))
+    for name in ("a", "b", "c"):
+        assert np.array_equal(bits(on.cache[name].activations), bits(off.cache[name].activations))
+        assert torch.equal(on.cache[name].sample_ids, off.cache[name].sample_ids)

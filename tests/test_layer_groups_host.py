@@ -42,21 +42,28 @@ def standins(monkeypatch):
             am._o = oracle.ActMaxOracle(am.n_collect, C, oracle.MODE_ATEN)
         return am._o
 
-    def collect(self, outs, native, id_base, site=None):
+    def collect(self, outs, native, id_base, site=None, k3_queue=None):
         a = oracle.agg_tokens(outs.detach().float().numpy(), "max")
-        oracle_of(self, a.shape[1]).update(a, np.arange(id_base, id_base + a.shape[0]))
         if not self.is_setup:
             self.n_latents = a.shape[1]
             self._setup_tensors()
         log.append(("single", site[1]))
+        if k3_queue is not None:  # K1 now, the merge with the other layers of this forward
+            k3_queue(self, torch.from_numpy(a).to(torch.bfloat16), id_base, a.shape[0])
+            return
+        oracle_of(self, a.shape[1]).update(a, np.arange(id_base, id_base + a.shape[0]))
+
+    def update_one(vals, ids, cand, sample_ids, id_base, B, ties, ws):
+        oracle_of(vals, cand.shape[1]).update(cand.float().numpy(), np.arange(id_base, id_base + B))
+        log.append(("update_one", 1))
 
     def reduce_multi(kind, xs, code, pos, cand):
         for l, x in enumerate(xs):
             cand[l] = torch.from_numpy(oracle.agg_tokens(x.float().numpy(), "max")).to(torch.bfloat16)
         log.append(("reduce_multi", len(xs)))
 
-    def update_multi(states, cand, id_bases, B):
-        for (am, _), c, base in zip(states, cand, id_bases):
+    def update_multi(states, cands, id_bases, B):
+        for (am, _), c, base in zip(states, cands, id_bases):
             oracle_of(am, c.shape[1]).update(c.float().numpy(), np.arange(base, base + B))
         log.append(("update_multi", len(states)))
 
@@ -64,6 +71,8 @@ def standins(monkeypatch):
     monkeypatch.setattr(ActMax, "_device_state", lambda self, device: (self, None))
     monkeypatch.setattr(N, "reduce_multi", reduce_multi)
     monkeypatch.setattr(N, "actmax_update_multi", update_multi)
+    monkeypatch.setattr(N, "actmax_update", update_one)
+    monkeypatch.setattr(ActMax, "_aten_ws", lambda self, B, device: None)
     monkeypatch.setattr(N, "actmax_update_multi_supported", lambda C, k, B: True)
     return log
 
@@ -110,8 +119,10 @@ def test_groups_are_planned_after_the_first_batch_and_launched_when_complete(sta
     first = [e for e in standins if e[0] == "single"][:5]
     assert [e[1] for e in first] == layers  # batch 1: every layer inside its own hook
     # batches 2 and 3: one multi reduce + one multi update for the four blocks, `odd` alone
-    assert standins.count(("reduce_multi", 4)) == 2 and standins.count(("update_multi", 4)) == 2
+    # ... and ONE merge for all five layers when the last one (`odd`) has fired
+    assert standins.count(("reduce_multi", 4)) == 2 and standins.count(("update_multi", 5)) == 2
     assert [e for e in standins if e[0] == "single"][5:] == [("single", "odd")] * 2
+    assert cache._k3_last == "odd" and not cache._k3_queue
 
 
 def test_state_read_and_unfinished_forward_flush_the_stash_layer_by_layer(standins):
