@@ -1198,10 +1198,12 @@ def main():
     # K3 (the streaming top-k merge) of the headline job: north_star's "activation top-k collect" is K1 + K3
     line["k3"] = {
         "kernel": ("actmax_update_aten_wave (one wavefront per component: libstdc++'s introselect / introsort steps evaluated by ballots, "
-                   "ids bit-identical to torch.topk's CPU order)" if args.tie_mode == "aten" else
+                   "ids bit-identical to torch.topk's CPU order); ONE launch per forward merges all hooked layers (a collector's first "
+                   "batch merges layer by layer)" if args.tie_mode == "aten" else
                    "actmax_merge (total order: value desc, id asc; one launch per --merge-every batches)"),
         "tie_mode": args.tie_mode, "launches": mrg_n, "avg_launch_us": mrg_ms / max(mrg_n, 1) * 1e3,
-        "k1_avg_launch_us": red_ms / max(red_n, 1) * 1e3,
+        "k1_avg_launch_us": red_ms / max(red_n, 1) * 1e3, "k1_launches": red_n,
+        "k1_plus_k3_us_per_batch": (red_ms + mrg_ms) / max(n_batches, 1) * 1e3,
         "collect_only_images_per_s": n_local / ((red_ms + mrg_ms) / 1e3) if red_ms else None,
         "bytes_per_launch_note": "reads B*C*2 candidate bytes + 10*C*k state bytes: latency-bound, not a bandwidth kernel",
     }
