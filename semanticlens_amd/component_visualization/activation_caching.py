@@ -342,13 +342,15 @@ class ActMaxCache(ActCache):
         # The reference's tie order only (`tie_mode="aten"`); SEMANTICLENS_AMD_GROUP_LAYERS=0 switches it off.
         self._grouping = self.tie_mode == "aten" and os.environ.get("SEMANTICLENS_AMD_GROUP_LAYERS", "1") != "0"
         self._group_device_types = ("cuda",)  # host tensors only in tests/test_layer_groups_host.py (kernels replaced by stand-ins)
-        # ---- one top-k merge per forward (round 5) ----
+        # ---- one top-k merge per forward (round 5; opt-in: SEMANTICLENS_AMD_BATCH_K3=1) ----
         # K3's time is a chain of LDS round trips per row, not a function of the number of rows, so the merges of ALL hooked layers
-        # of a forward (any shapes: each layer keeps its own candidate matrix) wait for the last layer and run as ONE
-        # `sl_actmax_update_multi` launch: ResNet-50 layer2-4 3 x 18-20 us -> ~24.  No activation is kept for this (K1 / K2 ran in
-        # the hook); the queue is flushed when the last layer of the first batch's firing order has fired, when a layer fires again,
-        # on any state read and when the hooks are removed.  SEMANTICLENS_AMD_BATCH_K3=0 switches it off.
-        self._batch_k3 = self._grouping and os.environ.get("SEMANTICLENS_AMD_BATCH_K3", "1") != "0"
+        # of a forward (any shapes: each layer keeps its own candidate matrix) can wait for the last layer and run as ONE
+        # `sl_actmax_update_multi` launch: ResNet-50 layer2-4 3 x 18-20 us -> ~23, K1 + K3 per batch 175 -> 139 us.  No activation is
+        # kept for this (K1 / K2 ran in the hook); the queue is flushed when the last layer of the first batch's firing order has
+        # fired, when a layer fires again, on any state read and when the hooks are removed.  Off by default: end to end nothing
+        # moves (the merges are 0.1 % of a step), and with the embed stage on a second stream the shifted phase between the two
+        # streams cost K1 0.011 of its in-pipeline fraction in every A/B pair (profiles/r05_k3_batching_ab.txt; none on one stream).
+        self._batch_k3 = self._grouping and os.environ.get("SEMANTICLENS_AMD_BATCH_K3", "0") == "1"
         self._k3_queue: list[tuple] = []  # (layer name, ActMax, candidates (B, C), id_base, B)
         self._k3_last: str | None = None  # the last layer of a forward, known once the first batch is over
         self._probe: dict[str, tuple] | None = {}  # first batch: layer -> (signature, tensor, version); None once planned

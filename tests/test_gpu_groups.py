@@ -209,8 +209,8 @@ def test_multi_update_equals_layer_by_layer():
 
 def test_layers_of_different_shapes_share_one_merge_launch_per_forward(monkeypatch):
     """ResNet-style hooking: three layers of three shapes.  Nothing is grouped or stashed (K1 runs inside every hook), but from the
-    second batch on the three top-k merges of a forward run as ONE launch when the last layer has fired; a state read between
-    layers of a forward and SEMANTICLENS_AMD_BATCH_K3=0 give the same states."""
+    second batch on — with SEMANTICLENS_AMD_BATCH_K3=1 — the three top-k merges of a forward run as ONE launch when the last layer has
+    fired; a state read in between and the default (one merge per layer) give the same states."""
     torch.manual_seed(5)
 
     class Net(nn.Module):
@@ -226,9 +226,10 @@ def test_layers_of_different_shapes_share_one_merge_launch_per_forward(monkeypat
     model = Net().to(DEV).eval()
     g = torch.Generator().manual_seed(6)
     batches = [torch.randn(b, 3, 16, 16, generator=g).to(DEV) for b in (9, 9, 9, 9, 4)]
+    monkeypatch.setenv("SEMANTICLENS_AMD_BATCH_K3", "1")  # opt-in
     on = _run_stream(model, ["a", "b", "c"], agg.aggregate_conv_max, "conv", batches, read_mid=True, expect_launches=(15, 3 + 4))
     assert not on._groups and on._k3_last == "c"
-    monkeypatch.setenv("SEMANTICLENS_AMD_BATCH_K3", "0")
+    monkeypatch.delenv("SEMANTICLENS_AMD_BATCH_K3")
     off = _run_stream(model, ["a", "b", "c"], agg.aggregate_conv_max, "conv", batches, expect_launches=(15, 15))
     for name in ("a", "b", "c"):
         assert np.array_equal(bits(on.cache[name].activations), bits(off.cache[name].activations))

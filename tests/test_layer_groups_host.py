@@ -110,7 +110,8 @@ def _batches(n, B=5, T=3):
     return [torch.randint(0, 7, (B, T, 6), generator=g).float() / 2 for _ in range(n)]  # tie-heavy
 
 
-def test_groups_are_planned_after_the_first_batch_and_launched_when_complete(standins):
+def test_groups_are_planned_after_the_first_batch_and_launched_when_complete(standins, monkeypatch):
+    monkeypatch.setenv("SEMANTICLENS_AMD_BATCH_K3", "1")  # opt-in: one merge per forward over ALL hooked layers
     torch.manual_seed(0)
     model = _Blocks().eval()
     layers = [f"blocks.{i}" for i in range(4)] + ["odd"]
@@ -125,7 +126,9 @@ def test_groups_are_planned_after_the_first_batch_and_launched_when_complete(sta
     assert cache._k3_last == "odd" and not cache._k3_queue
 
 
-def test_state_read_and_unfinished_forward_flush_the_stash_layer_by_layer(standins):
+@pytest.mark.parametrize("batch_k3", ["0", "1"])
+def test_state_read_and_unfinished_forward_flush_the_stash_layer_by_layer(standins, monkeypatch, batch_k3):
+    monkeypatch.setenv("SEMANTICLENS_AMD_BATCH_K3", batch_k3)
     torch.manual_seed(1)
     model = _Blocks().eval()
     layers = [f"blocks.{i}" for i in range(4)]
@@ -144,7 +147,9 @@ def test_state_read_and_unfinished_forward_flush_the_stash_layer_by_layer(standi
     assert standins.count(("reduce_multi", 4)) == 3  # batches 2, 4, 5
 
 
-def test_a_forward_that_stops_early_is_finished_by_the_next_one(standins):
+@pytest.mark.parametrize("batch_k3", ["0", "1"])
+def test_a_forward_that_stops_early_is_finished_by_the_next_one(standins, monkeypatch, batch_k3):
+    monkeypatch.setenv("SEMANTICLENS_AMD_BATCH_K3", batch_k3)
     torch.manual_seed(2)
     model = _Blocks().eval()
     layers = [f"blocks.{i}" for i in range(4)]
@@ -156,7 +161,9 @@ def test_a_forward_that_stops_early_is_finished_by_the_next_one(standins):
     model.stop_after = None
 
 
-def test_in_place_edits(standins):
+@pytest.mark.parametrize("batch_k3", ["0", "1"])
+def test_in_place_edits(standins, monkeypatch, batch_k3):
+    monkeypatch.setenv("SEMANTICLENS_AMD_BATCH_K3", batch_k3)
     torch.manual_seed(3)
     model = _Blocks().eval()
     layers = [f"blocks.{i}" for i in range(4)]
