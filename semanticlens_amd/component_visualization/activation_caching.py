@@ -410,7 +410,9 @@ class ActMaxCache(ActCache):
         by_sig: dict[tuple, list[str]] = {}
         for name, (sig, tensor, version) in self._probe.items():
             if version is not None and self._version(tensor) == version:
-                by_sig.setdefault(sig[:3] + sig[4:], []).append(name)  # strides are re-checked per batch (they scale with B)
+                # the batch stride scales with B (a short last batch) and is re-checked per launch; the inner strides (memory
+                # format) must agree for two layers to share a group
+                by_sig.setdefault(sig[:3] + (sig[3][1:],) + sig[4:], []).append(name)
         if self._batch_k3 and self._probe:
             self._k3_last = list(self._probe)[-1]
             for name in self._probe:
