@@ -490,7 +490,8 @@ def probing_leg(dev):
 def policy_report(cv):
     """Per hooked layer: which cache policy its reduce settled on (N.ReducePolicyTuner: 'default' = inputs below 256 MiB and the last
     240 MiB of larger ones with the default policy; 'nt>=96MiB,tail80MiB' = what outputs of residual adds want)."""
-    names = {None: "not tuned (input below 96 MiB, or policy set by the caller)", 0: "default", 1: "nt>=96MiB,tail80MiB"}
+    names = {None: "not tuned (input below 96 MiB, or policy set by the caller)", 0: "default", 1: "nt>=96MiB,tail80MiB",
+             2: "nt>=96MiB,tail128MiB"}
     out = {}
     for name in cv.layer_names:
         t = cv.actmax_cache.cache[name]._policy_tuner
@@ -515,9 +516,9 @@ def collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, c
 
 def _collect_leg(dev, fm, args, model, layers, agg, kernel, workload, steps, B, cast, check_n, keep_db=None, traffic_key=None):
     # MIOpen / hipBLASLt pick their kernels, and each hooked layer's reduce settles its cache policy (N.ReducePolicyTuner: 8 launches)
-    warm = [synth.synth_images_u8(torch.arange(10**7 + (i % 2) * B, 10**7 + (i % 2 + 1) * B, device=dev)) for i in range(2)] * 5
-    cv_w = make_cv(model, 10 * B, args.k, args.tie_mode, layers, agg)
-    finish_job(cv_w, run_steps(cv_w, fm, warm, 0, 10 * B, cast), 0, 10 * B, False)
+    warm = [synth.synth_images_u8(torch.arange(10**7 + (i % 2) * B, 10**7 + (i % 2 + 1) * B, device=dev)) for i in range(2)] * 7
+    cv_w = make_cv(model, 14 * B, args.k, args.tie_mode, layers, agg)
+    finish_job(cv_w, run_steps(cv_w, fm, warm, 0, 14 * B, cast), 0, 14 * B, False)
     batches = [synth.synth_images_u8(torch.arange(s * B, (s + 1) * B, device=dev)) for s in range(steps)]
     n = steps * B
     cv = make_cv(model, n, args.k, args.tie_mode, layers, agg)

@@ -565,12 +565,14 @@ class ReducePolicyTuner:
     a residual ADD of two other tensors (transformer blocks, ConvNeXt) streamed three times its size through that cache: only
     ~80 MB of the output's tail are still there, and reading 240 MiB with the default policy thrashes (ConvNeXt-L's stage
     outputs: 0.625 of spec with the default, 0.693 with an 80 MiB tail; ViT-B/16's 155 MB block outputs 0.718 -> 0.742 with
-    nt from 96 MiB: ``profiles/r04_reduce_policy_sweep.txt``).  So each layer tries both on its first launches (one untimed +
+    nt from 96 MiB: ``profiles/r04_reduce_policy_sweep.txt``).  So each layer tries the candidates on its first launches (one untimed +
     ``TRIALS`` timed each, HIP events read back only once they have completed: no synchronisation) and keeps the faster;
     results do not depend on the policy.  Off when the caller chose a policy (``set_reduce_policy`` / ``SL_NT_MIN_BYTES`` /
     ``SL_REDUCE_TAIL_MB``) or with ``SL_REDUCE_AUTOTUNE=0``; inputs below 96 MiB are never tuned."""
 
-    CANDIDATES = ((None, None), (96 << 20, 80 << 20))  # (nt_min_bytes, tail_bytes); None = the library default
+    # (nt_min_bytes, tail_bytes); None = the library default.  Round 5: behind a three-stream residual add the 617 MB ConvNeXt-L
+    # stage reads 0.690 with an 80 MiB tail and 0.715 with 128 MiB (profiles/r05_k2_producer_lab.txt): a third candidate
+    CANDIDATES = ((None, None), (96 << 20, 80 << 20), (96 << 20, 128 << 20))
     MIN_BYTES = 96 << 20
     TRIALS = 3
 
