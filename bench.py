@@ -642,6 +642,44 @@ def config3_leg(dev, args):
 
 
 def config4_leg(dev, fm, args):
+    """`_config4_leg` under MIOpen's find mode (`torch.backends.cudnn.benchmark = True`, scoped to this leg).  ConvNeXt's block outputs
+    are channels_last-strided (the residual add takes its permuted branch's layout; torchvision's and timm's blocks behave the
+    same), and MIOpen's immediate-mode pick for an fp32 NHWC 7 x 7 depthwise convolution is its naive kernel — 60 % of the forward
+    (profiles/r04_cfg4_leg_kernel_stats.csv).  Its search finds a kernel that makes the whole forward 1.8x faster (418 -> 229 ms at
+    B = 256, tools/cfg4_miopen_find.py), which is what a user of this model on ROCm would switch on; the default-mode forward is
+    timed beside it so that the leg's images/s can be read either way.  The headline keeps the driver's setting."""
+    saved = torch.backends.cudnn.benchmark
+    model = synth.convnext_l().to(dev)
+    x = torch.randn(args.batch, 3, 224, 224, device=dev)
+
+    def fwd_ms(reps=3):
+        with torch.no_grad():
+            model(x)
+            model(x)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(reps):
+                model(x)
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps * 1e3
+
+    try:
+        torch.backends.cudnn.benchmark = False
+        ms_default = fwd_ms()
+        torch.backends.cudnn.benchmark = True
+        ms_find = fwd_ms()
+        del model, x
+        out = _config4_leg(dev, fm, args)
+    finally:
+        torch.backends.cudnn.benchmark = saved
+    out["miopen_find"] = {"enabled_for_this_leg": True, "convnext_l_forward_ms_default_mode": ms_default,
+                          "convnext_l_forward_ms_find_mode": ms_find, "batch": args.batch,
+                          "note": "torch.backends.cudnn.benchmark=True for this leg only: MIOpen's immediate-mode pick for the fp32 NHWC "
+                                  "depthwise convolutions is its naive kernel; images_per_s of this leg was 597 without the search"}
+    return out
+
+
+def _config4_leg(dev, fm, args):
     """BASELINE configs[4] on one GPU: ConvNeXt-L (random init, 198 M parameters), the four stage outputs
     (192 x 56^2, 384 x 28^2, 768 x 14^2, 1536 x 7^2: 4 515 840 B/image) through (i) the activation collect (K1 + K3, roofline),
     (ii) the relevance-maximisation visualizer (EpsilonPlusFlat LRP backward in PyTorch, K1 sum + abs-norm + K3) and
