@@ -664,18 +664,18 @@ def config4_leg(dev, fm, args):
         return (time.perf_counter() - t) / reps * 1e3
 
     try:
-        torch.backends.cudnn.benchmark = False
-        ms_default = fwd_ms()
+        # PyTorch keeps ONE per-shape algorithm cache for both modes: a shape first run in immediate mode keeps its naive kernel
+        # for the life of the process, so the search must be on before ConvNeXt's shapes are seen for the first time
         torch.backends.cudnn.benchmark = True
         ms_find = fwd_ms()
         del model, x
         out = _config4_leg(dev, fm, args)
     finally:
         torch.backends.cudnn.benchmark = saved
-    out["miopen_find"] = {"enabled_for_this_leg": True, "convnext_l_forward_ms_default_mode": ms_default,
-                          "convnext_l_forward_ms_find_mode": ms_find, "batch": args.batch,
+    out["miopen_find"] = {"enabled_for_this_leg": True, "convnext_l_forward_ms_find_mode": ms_find, "batch": args.batch,
                           "note": "torch.backends.cudnn.benchmark=True for this leg only: MIOpen's immediate-mode pick for the fp32 NHWC "
-                                  "depthwise convolutions is its naive kernel; images_per_s of this leg was 597 without the search"}
+                                  "depthwise convolutions is its naive kernel (forward 416-418 ms at B = 256, this leg 597 images/s: "
+                                  "tools/cfg4_miopen_find.py, profiles/r05_cfg4_miopen_find.txt)"}
     return out
 
 
