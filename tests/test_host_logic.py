@@ -750,13 +750,13 @@ def test_text_chunks_are_tokenised_one_ahead_in_the_same_order(monkeypatch):
     assert len(_encode_texts(FM(), texts, batch_size=None)) == 23  # one chunk: no thread
 
 
-def test_reduce_policy_tuner_measures_both_policies_and_keeps_the_default_unless_clearly_slower(monkeypatch):
+def test_reduce_policy_tuner_measures_every_candidate_and_keeps_the_default_unless_clearly_slower(monkeypatch):
     """`N.ReducePolicyTuner`: one untimed + three timed launches per candidate, decision from the medians, the library default unless the
     other policy is > 2 % faster; off for small inputs and once the caller chose a policy."""
     applied = []
     monkeypatch.delenv("SL_NT_MIN_BYTES", raising=False), monkeypatch.delenv("SL_REDUCE_TAIL_MB", raising=False)
     monkeypatch.setattr(N, "_policy_explicit", False)
-    clock = {"now": 0.0, "cost": {None: 1.0, 96 << 20: 1.0}}
+    clock = {"now": 0.0, "cost": {}}
 
     class Ev:
         def __init__(self, enable_timing=True):
@@ -774,27 +774,33 @@ def test_reduce_policy_tuner_measures_both_policies_and_keeps_the_default_unless
     monkeypatch.setattr(torch.cuda, "Event", Ev)
 
     # a launch costs what the policy in force says
-    current = [None]
-    monkeypatch.setattr(N, "_set_reduce_policy_raw", lambda a, b: (applied.append((a, b)), current.__setitem__(0, a)))
+    current = [(None, None)]
+    monkeypatch.setattr(N, "_set_reduce_policy_raw", lambda a, b: (applied.append((a, b)), current.__setitem__(0, (a, b))))
+    cands = N.ReducePolicyTuner.CANDIDATES
+    assert cands[0] == (None, None) and len(cands) == 3
+    n_trials = 4 * len(cands)  # one untimed + three timed launches per candidate
 
-    def go(tuner, cost_default, cost_other, n=12, nbytes=200 << 20):
-        clock["cost"] = {None: cost_default, 96 << 20: cost_other}
+    def go(tuner, costs, n=n_trials + 4, nbytes=200 << 20):
+        clock["cost"] = dict(zip(cands, costs))
         for _ in range(n):
             tuner.run(lambda: clock.__setitem__("now", clock["now"] + clock["cost"][current[0]]), nbytes, 256)
 
     t = N.ReducePolicyTuner()
-    go(t, 1.0, 0.9)
-    assert t.choice == 1 and applied.count((96 << 20, 80 << 20)) >= 4 + (12 - 8)  # trials, then every launch under the chosen policy
+    go(t, (1.0, 0.9, 0.95))
+    assert t.choice == 1 and applied.count(cands[1]) >= 4 + 4  # trials, then every launch under the chosen policy
     assert applied[-1] == (None, None)  # always restored
     t = N.ReducePolicyTuner()
-    go(t, 1.0, 0.99)
+    go(t, (1.0, 0.95, 0.9))
+    assert t.choice == 2  # the 128 MiB tail (round 5: outputs of three-stream residual adds)
+    t = N.ReducePolicyTuner()
+    go(t, (1.0, 0.99, 0.985))
     assert t.choice == 0  # within 2 %: the default stays
     t = N.ReducePolicyTuner()
     before = len(applied)
-    go(t, 1.0, 0.5, nbytes=50 << 20)
+    go(t, (1.0, 0.5, 0.5), nbytes=50 << 20)
     assert t.choice is None and len(applied) == before  # below 96 MiB: never touched
     monkeypatch.setattr(N, "_policy_explicit", True)
     t = N.ReducePolicyTuner()
-    go(t, 1.0, 0.5)
+    go(t, (1.0, 0.5, 0.5))
     assert t.choice is None and len(applied) == before  # the caller's explicit policy wins
     assert N.ReducePolicyTuner.for_site(("m", "layer")) is N.ReducePolicyTuner.for_site(("m", "layer"))
