@@ -537,6 +537,7 @@ inline int launch_split(const float* x, const float* scale, int64_t R, int64_t K
 // grid-size rules pick for a strip that narrow (128 x 128 tiles).  Every output element keeps its accumulation order (all tile
 // variants are bit-identical), so results do not change.  Measured (`tools/gemm_strip_lab.py`, profiles/r05_gemm_strip_lab.txt):
 // M = 16 384: o-proj 173 -> 98 + 31 us, fc2 514 -> 310 + 96 us; M = 65 536: 495 -> 384 + 80, 1 523 -> 1 194 + 257.
+// The cut may also fall one or two FULL tiles earlier when that lands the big kernel on whole rounds.
 // Cost model, in rounds of the big kernel: t tiles cost floor(t / CUs) + (0.7 + 0.3 f) for a partial round filling a fraction f of
 // the CUs; a strip of s 128 x 128 tiles costs 0.12 + 0.0014 s.  SL_G3_STRIP=0 switches the split off.
 inline double g8_rounds_model(int64_t tiles, int64_t cus) {
@@ -550,18 +551,25 @@ inline int64_t strip_split_columns(int64_t M, int64_t N) {
   }();
   const int64_t cus = num_cus();
   const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256;
-  const int64_t nmain = N / 256, rest = N - nmain * 256;  // full column tiles, width of the partial one
-  if (!on || rest == 0 || nmain < 1 || tn != nmain + 1) return 0;
+  if (!on || tn < 2) return 0;
   const double whole = g8_rounds_model(tm * tn, cus);
-  const int64_t strip_tiles = ((M + 127) / 128) * ((rest + 127) / 128);
-  const double cut = g8_rounds_model(tm * nmain, cus) + 0.12 + 0.0014 * (double)strip_tiles;
-  return cut < 0.97 * whole ? nmain * 256 : 0;
+  // cut after m full column tiles, the strip up to three tiles wide: so400m's QKV at 64 images (N = 3456 = 13.5 tiles, 896 tiles =
+  // 3.5 rounds) runs 12 column tiles in exactly three rounds and a 384-column strip
+  int64_t best_m = 0;
+  double best = 0.97 * whole;
+  for (int64_t m = tn - 1; m >= 1 && m >= tn - 3; --m) {
+    const int64_t rest = N - m * 256;
+    const int64_t strip_tiles = ((M + 127) / 128) * ((rest + 127) / 128);
+    const double cut = g8_rounds_model(tm * m, cus) + 0.12 + 0.0014 * (double)strip_tiles;
+    if (cut < best) best = cut, best_m = m;
+  }
+  return best_m * 256;
 }
 
 // A (M rows), B (N rows): split matrices of K columns (layout above)
 template <class Epi>
 int launch_gemm3_nt(ProfScope& prof, const uint16_t* A, int64_t M, const uint16_t* B, int64_t N, int64_t K, const Epi& epi,
-                    hipStream_t st, bool may_split = true) {
+                    hipStream_t st, int may_split = 1) {  // 1: may cut a strip off, 0: the main part of a cut, 2: the strip itself
   const int64_t tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
   SL_REQUIRE(tm * tn < (1ll << 31), "GEMM: too many tiles");
   if (tm * tn == 0) return 0;
@@ -573,13 +581,15 @@ int launch_gemm3_nt(ProfScope& prof, const uint16_t* A, int64_t M, const uint16_
     const char* e = getenv("SL_G3_TILE");
     return e ? atoi(e) : 0;
   }();
-  if (may_split && !forced && gemm8::fits(M, N, 4 * Kp) && gemm8::worth_it(M, N) && !gemmw4::prefer(M, N) &&
+  if (may_split == 2 && !forced && gemm8::fits(M, N, 4 * Kp) && Kp / 32 >= 8 && !gemmsk::prefer(M, N, Kp / 32))
+    return gemmsk::launch<2>(prof, A, M, B, N, 4 * Kp, Kp / 32, epi, st);  // strips are priced (and run) as 128 x 128 tiles
+  if (may_split == 1 && !forced && gemm8::fits(M, N, 4 * Kp) && gemm8::worth_it(M, N) && !gemmw4::prefer(M, N) &&
       !gemmsk::prefer(M, N, Kp / 32)) {
     const int64_t c0 = strip_split_columns(M, N);
     if (c0 > 0) {
-      if (int rc = launch_gemm3_nt(prof, A, M, B, c0, K, epi, st, false)) return rc;
+      if (int rc = launch_gemm3_nt(prof, A, M, B, c0, K, epi, st, 0)) return rc;
       ProfScope strip(SL_PROF_GEMM, st, 0.0);  // its time counts, its flops are in `prof`'s work already
-      return launch_gemm3_nt(strip, A, M, B + c0 * 2 * Kp, N - c0, K, epi.shifted(c0), st, false);
+      return launch_gemm3_nt(strip, A, M, B + c0 * 2 * Kp, N - c0, K, epi.shifted(c0), st, 2);
     }
   }
   const int64_t tm3 = (M + BM3 - 1) / BM3;

@@ -1022,7 +1022,7 @@ from semanticlens_amd import _native as N
 torch.manual_seed(0)
 dev = "cuda:0"
 outs = []
-for (M, Nn, K) in [(16384, 1152, 96), (16384, 4304, 64), (16130, 1100, 40)]:
+for (M, Nn, K) in [(16384, 1152, 96), (16384, 4304, 64), (16130, 1100, 40), (16384, 3456, 40)]:  # the last: cut one full tile early
     x = torch.randn(M, K, device=dev); w = torch.randn(Nn, K, device=dev) * 0.1; b = torch.randn(Nn, device=dev)
     sx, sw = N.Split.of(x), N.Split.of(w)
     res = torch.randn(M, Nn, device=dev)
