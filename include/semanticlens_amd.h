@@ -134,6 +134,11 @@ size_t sl_actmax_aten_ws_bytes(int64_t C, int64_t k, int64_t B);
 int sl_actmax_update_multi(uint16_t* const* h_d_vals, int64_t* const* h_d_ids, const int64_t* h_id_bases, const int64_t* h_Cs,
                            const uint16_t* const* h_d_cands, int L, int64_t k, int64_t B, void* stream);
 int sl_actmax_update_multi_supported(int64_t C, int64_t k, int64_t B);
+/* HOST-only (no device, no stream): the n-element row h_vals_bf16 in, the k positions torch.topk's CPU kernel would select
+ * (activation_caching.py:140: `torch.topk(all_acts, k, dim=1)`; ATen TopKImpl.h -> libstdc++ partial_sort / nth_element + sort,
+ * comparator (isnan(a) && !isnan(b)) || a > b) out, best first.  The restatement SL_TIES_ATEN's kernels evaluate; the host side runs
+ * it against the installed torch.topk once per process (a torch / libstdc++ pair with another tie order is reported, not followed). */
+int sl_aten_topk_order_host(const uint16_t* h_vals_bf16, int64_t n, int64_t k, int32_t* h_positions);
 
 /* ---- K4: merge R other states (e.g. all-gathered per-rank states) into this one ----------
  * No reference counterpart (the reference is single-process); semantics = SL_TIES_TOTAL

@@ -49,6 +49,7 @@ SIGNATURES = {
     "sl_actmax_aten_ws_bytes": (_sz, [_i64, _i64, _i64]),
     "sl_actmax_update_multi": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _vp]),
     "sl_actmax_update_multi_supported": (_int, [_i64, _i64, _i64]),
+    "sl_aten_topk_order_host": (_int, [_vp, _i64, _i64, _vp]),
     "sl_reduce_conv_multi": (_int, [_vp, _int, _int, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp]),
     "sl_reduce_tokens_multi": (_int, [_vp, _int, _int, _i64, _i64, _i64, _i64, _i64, _i64, _int, _i64, _vp, _vp]),
     "sl_actmax_merge_states": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),
@@ -321,6 +322,53 @@ def actmax_merge(vals, ids, cand: torch.Tensor, slot_stride: int, id_bases: list
     with _on(vals.device):
         rc = lib().sl_actmax_merge(_ptr(vals), _ptr(ids), C, k, _ptr(cand), slot_stride, hb, hr, n, _stream(vals))
     _check(rc, "sl_actmax_merge")
+
+
+def aten_topk_order_host(row_bf16: torch.Tensor, k: int) -> torch.Tensor:
+    """Positions ``torch.topk(row, k)`` selects on the CPU according to the library's restatement (host code, no device)."""
+    row = row_bf16.detach().to("cpu", torch.bfloat16).contiguous()
+    out = torch.empty(k, dtype=torch.int32)
+    _check(lib().sl_aten_topk_order_host(row.data_ptr(), row.numel(), k, out.data_ptr()), "sl_aten_topk_order_host")
+    return out
+
+
+_ATEN_SELFTEST: dict | None = None
+
+
+def aten_order_selftest(rows: int = 200, force: bool = False) -> dict:
+    """Once per process (first ``tie_mode="aten"`` use): the restatement the K3 kernels evaluate against the INSTALLED
+    ``torch.topk`` on ``rows`` tie-heavy bf16 rows covering both of ATen's branches (``k * 64 <= n``: partial_sort; else
+    nth_element + sort) — ~1 ms of host work.  The restatement is pinned to libstdc++ 11's introselect / introsort and
+    torch 2.10's TopKImpl.h (the reference locks torch 2.7.1, same code); a host whose pair orders ties differently gets a
+    warning naming the versions, because ``aten`` ids would then differ from what ``torch.topk`` gives THERE."""
+    global _ATEN_SELFTEST
+    if _ATEN_SELFTEST is not None and not force:
+        return _ATEN_SELFTEST
+    g = torch.Generator().manual_seed(1234)
+    bad, cases = 0, 0
+    shapes = [(20, 64), (20, 256), (100, 32), (5, 7), (1, 1), (3, 250), (2, 128), (20, 2000), (100, 6500)]  # (k, B): n = k + B
+    for i in range(rows):
+        k, B = shapes[i % len(shapes)]
+        n = k + B
+        row = (torch.randint(0, 12, (n,), generator=g).float() / 4).to(torch.bfloat16)  # ties are the point
+        if i % 7 == 0:
+            row[int(torch.randint(0, n, (1,), generator=g))] = float("nan")
+        if i % 5 == 0:
+            row[:k] = -0.0  # a fresh state: the sentinel (activation_caching.py:108)
+        want = torch.topk(row, k).indices.to(torch.int32)
+        got = aten_topk_order_host(row, k)
+        cases += 1
+        bad += int(not torch.equal(want, got))
+    _ATEN_SELFTEST = {"rows": cases, "mismatches": bad, "torch": torch.__version__}
+    if bad:
+        import warnings
+
+        warnings.warn(
+            f"semanticlens_amd: tie_mode='aten' reproduces torch.topk's CPU tie order as restated for libstdc++ 11 / torch 2.7-2.10 "
+            f"(ATen TopKImpl.h); the installed torch {torch.__version__} selects different positions on {bad} of {cases} tie-heavy rows. "
+            "Top-k VALUES are unaffected; sample ids among tied values may differ from torch.topk on this host.  tie_mode='total' is "
+            "independent of the host library.", RuntimeWarning, stacklevel=3)
+    return _ATEN_SELFTEST
 
 
 def actmax_aten_ws_bytes(C: int, k: int, B: int) -> int:

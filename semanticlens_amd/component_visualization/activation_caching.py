@@ -25,6 +25,7 @@ from __future__ import annotations
 import inspect
 import logging
 import os
+import warnings
 from collections import Counter, OrderedDict
 from collections.abc import Callable
 from contextlib import contextmanager
@@ -97,6 +98,10 @@ class ActMax:
 
     def _device_state(self, device: torch.device):
         if self._dev_vals is None or self._dev_vals.device != device:
+            if self.tie_mode == "aten":
+                # first use of the reference's tie order in this process: the restatement the kernels evaluate is checked against the
+                # installed torch.topk (200 tie-heavy rows, ~10 ms of host work, cached); a differing host is warned about
+                N.aten_order_selftest()
             self.flush()
             self._sync_host()
             self._dev_vals = self._host_vals.to(device).contiguous()
@@ -340,7 +345,10 @@ class ActMaxCache(ActCache):
         # records every hooked output's `_version`; only layers whose output was still unmodified when the next batch began are
         # grouped, and every later launch re-checks the versions (an in-place edit raises instead of collecting wrong values).
         # The reference's tie order only (`tie_mode="aten"`); SEMANTICLENS_AMD_GROUP_LAYERS=0 switches it off.
+        # A version mismatch at launch time (an in-place edit that the first batch did not show) takes that layer out of its group
+        # for the rest of the run, with one warning; SEMANTICLENS_AMD_GROUP_LAYERS=strict raises instead.
         self._grouping = self.tie_mode == "aten" and os.environ.get("SEMANTICLENS_AMD_GROUP_LAYERS", "1") != "0"
+        self._group_strict = os.environ.get("SEMANTICLENS_AMD_GROUP_LAYERS", "1") == "strict"
         self._group_device_types = ("cuda",)  # host tensors only in tests/test_layer_groups_host.py (kernels replaced by stand-ins)
         # ---- one top-k merge per forward (round 5; opt-in: SEMANTICLENS_AMD_BATCH_K3=1) ----
         # K3's time is a chain of LDS round trips per row, not a function of the number of rows, so the merges of ALL hooked layers
@@ -449,26 +457,58 @@ class ActMaxCache(ActCache):
                 return False
         stash = group["stash"]  # (_flush_group installs a fresh dict)
         stash[layer_name] = (outs.detach(), version, start, native, module)
-        if len(stash) == len(group["layers"]):
+        if all(name in stash for name in group["layers"]):
             self._run_group(gid)
         return True
 
-    @classmethod
-    def _check_unmodified(cls, layer_name, tensor, version):
-        if cls._version(tensor) != version:
+    def _check_unmodified(self, layer_name, tensor, version, start=None) -> bool:
+        """False when ``tensor`` was written in place since its hook stashed it.  The layer then leaves its group for good (it is
+        collected inside its own hook from the next batch on, like the reference does) and ONE warning says which samples were
+        aggregated from the edited tensor; ``SEMANTICLENS_AMD_GROUP_LAYERS=strict`` raises instead."""
+        if self._version(tensor) == version:
+            return True
+        if self._group_strict:
             raise RuntimeError(
                 f"the output of hooked layer {layer_name!r} was modified in place after its forward hook ran; layers with identical "
                 "outputs are collected together once the last of them has fired, which needs the earlier outputs intact. "
                 "Set SEMANTICLENS_AMD_GROUP_LAYERS=0 to collect every layer inside its own hook.")
+        self._ungroup(layer_name)
+        where = "" if start is None else f" (samples {start}..{start + tensor.shape[0] - 1} of this layer were aggregated AFTER the edit)"
+        warnings.warn(
+            f"the output of hooked layer {layer_name!r} was modified in place after its forward hook ran{where}; the layer is collected "
+            "inside its own hook from now on.  Set SEMANTICLENS_AMD_GROUP_LAYERS=0 to collect every layer that way from the first "
+            "batch, or =strict to raise here.", RuntimeWarning, stacklevel=2)
+        return False
+
+    def _ungroup(self, layer_name: str):
+        """Take ``layer_name`` out of its group; a group left with one member is dissolved."""
+        gid = self._group_of.pop(layer_name, None)
+        if gid is None:
+            return
+        group = self._groups[gid]
+        group["layers"] = [n for n in group["layers"] if n != layer_name]
+        if len(group["layers"]) < 2:
+            for n in group["layers"]:
+                self._group_of.pop(n, None)
+            group["layers"] = []
 
     def _run_group(self, gid: int):
         """All members have fired: one multi-tensor reduce, one multi-state top-k update."""
         group = self._groups[gid]
         stash, names = group["stash"], group["layers"]
+        names = list(names)
         entries = [stash[name] for name in names]
         group["stash"] = {}
-        for name, (tensor, version, _, _, _) in zip(names, entries):
-            self._check_unmodified(name, tensor, version)
+        intact = [self._check_unmodified(name, tensor, version, start) for name, (tensor, version, start, _, _) in zip(names, entries)]
+        if not all(intact):  # nothing of this batch is lost: every member is collected now, alone
+            for name, (tensor, _, start, nat, module) in zip(names, entries):
+                am = self.cache[name]
+                hook, am._before_flush = am._before_flush, None
+                try:
+                    am.collect(tensor, nat, start, site=(id(module), name))
+                finally:
+                    am._before_flush = hook
+            return
         x0, _, _, native, _ = entries[0]
         kind, code, pos = native
         B = x0.shape[0]
@@ -549,7 +589,7 @@ class ActMaxCache(ActCache):
         if stash:
             self._flush_k3()  # a layer's merges run in batch order: queued ones first
         for name, (tensor, version, start, native, module) in stash.items():
-            self._check_unmodified(name, tensor, version)
+            self._check_unmodified(name, tensor, version, start)
             am = self.cache[name]
             hook, am._before_flush = am._before_flush, None
             try:

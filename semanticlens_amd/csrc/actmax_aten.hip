@@ -16,6 +16,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 namespace sl {
 namespace {
@@ -312,8 +313,12 @@ __global__ __launch_bounds__(64 * ROWS) void actmax_update_aten_wave_kernel(K3St
   }
 }
 
-constexpr size_t kLdsBudget = 64 * 1024;
-constexpr size_t kLdsMax = 160 * 1024;
+// dynamic LDS a launch may ask for: the kernel also holds 48 x ROWS bytes of static tables (s_cand ... s_C, ROWS <= 8), which count
+// against the same 64 KiB (no attribute set) / 160 KiB (the CU's LDS) limits — round-5 advisor: rows within 384 bytes of a limit
+// failed at launch while `_supported` said yes
+constexpr size_t kLdsStatic = 48 * 8 + 128;
+constexpr size_t kLdsBudget = 64 * 1024 - kLdsStatic;
+constexpr size_t kLdsMax = 160 * 1024 - kLdsStatic;
 
 bool wave_impl() {  // SL_K3_ATEN_IMPL = wave (default) | lane (round 4: one lane per row)
   static const int impl = [] {
@@ -410,6 +415,20 @@ SL_API int sl_actmax_update_multi(uint16_t* const* h_d_vals, int64_t* const* h_d
     const int rc = launch_wave(prof, tab, n, k, nullptr, B, st);
     if (rc) return rc;
   }
+  return 0;
+}
+
+/* Host-only: the positions torch.topk's CPU kernel selects from ONE row of n bf16 values (TopKImpl.h through libstdc++, restated in
+ * aten_topk_order.hpp), best first.  No device is touched: the Python side checks this against the installed torch.topk once per
+ * process, so that a torch / libstdc++ pair that orders ties differently is noticed instead of silently giving other sample ids. */
+SL_API int sl_aten_topk_order_host(const uint16_t* h_vals_bf16, int64_t n, int64_t k, int32_t* h_positions) {
+  SL_REQUIRE(h_vals_bf16 && h_positions, "sl_aten_topk_order_host: null pointer");
+  SL_REQUIRE(n >= 1 && n <= 65535 && k >= 0 && k <= n, "sl_aten_topk_order_host: need 1 <= n <= 65535 and 0 <= k <= n");
+  std::vector<uint32_t> a((size_t)n);
+  for (int64_t j = 0; j < n; ++j) a[(size_t)j] = (sl::bf16_order_key(h_vals_bf16[j]) << 16) | (uint32_t)j;
+  uint32_t* p = a.data();
+  sl::aten_order::topk_order(p, (int)n, (int)k);
+  for (int64_t j = 0; j < k; ++j) h_positions[j] = (int32_t)(a[(size_t)j] & 0xFFFFu);
   return 0;
 }
 

@@ -1405,7 +1405,7 @@ bool launch_colreduce2(ProfScope& prof, const MultiSrc& x, int64_t B, int T_, in
     if (util > best + 1e-9) best = util, lpr = c;
   }
   if (forced_lpr == 64 || forced_lpr == 32 || forced_lpr == 16) lpr = forced_lpr;
-  const int64_t cw = (int64_t)lpr * EPP, nchunk = (F + cw - 1) / cw, tasks = B * nchunk, cus = num_cus();
+  const int64_t cw = (int64_t)lpr * EPP, nchunk = (F + cw - 1) / cw, cus = num_cus();
   const int64_t nt_min_bytes = nt_min_bytes_();
   const int64_t per_b = (int64_t)T_ * F * (int64_t)sizeof(T), all = B * per_b;
   // of a table of tensors only the LAST one was written a moment ago: the default-policy tail never reaches into the others
@@ -1419,9 +1419,13 @@ bool launch_colreduce2(ProfScope& prof, const MultiSrc& x, int64_t B, int T_, in
   // (behind a ViT block's GEMMs, tools/k2_leg_probe.py) the same shape reads 0.717 of spec with four waves and 0.671 with
   // eight; the half-precision kernels (100 registers, 16 waves per CU) lose 15 % with eight once there are two tasks per CU
   // ((256, 257, 1024) bf16: 6.07 -> 5.15 TB/s).  profiles/r04_k2_lab.txt
+  // A table of L tensors takes the wave count ONE of its tensors would take alone: the waves split the reduced axis, so the
+  // fp32 summation order of mean / absmean / sum follows NW, and a layer's candidates must not depend on whether its batch
+  // was reduced alone (a collector's first batch, SEMANTICLENS_AMD_GROUP_LAYERS=0) or as a member of a group.
+  const int64_t tasks_one = x.per * nchunk;
   int nw = 4;
-  if (tasks * 2 < cus && inst_rows >= 128 && lpr == 64) nw = 16;
-  else if (tasks < (sizeof(T) == 4 ? 2 : 1) * cus && inst_rows >= 64) nw = 8;
+  if (tasks_one * 2 < cus && inst_rows >= 128 && lpr == 64) nw = 16;
+  else if (tasks_one < (sizeof(T) == 4 ? 2 : 1) * cus && inst_rows >= 64) nw = 8;
   if (forced_nw == 4 || forced_nw == 8 || (forced_nw == 16 && lpr == 64)) nw = forced_nw;
 #define SL_COL2(NW_, LPR_) launch_colreduce2_as<T, OP, NW_, LPR_>(prof, x, B, T_, F, sb, st_, t0, t1, denom, tail_from, cand, outf, st)
 #define SL_COL2_NW(LPR_)                 \

@@ -383,18 +383,13 @@ def encode_text_sharded(fm, texts: list[str], batch_size: int | None = None, gro
 
 
 @torch.no_grad()
-def text_probing_sharded(fm, query, aggregated_concept_db, templates=None, batch_size=None, group=None):
-    """Multi-GPU ``Lens.text_probing`` (lens.py:331-362): same result on every rank, equal to the single-process one.
+def probe_sharded(embeds: torch.Tensor, aggregated_concept_db, group=None, gather: bool = True):
+    """``lens._probe`` (lens.py:206-214) with the query rows of ``embeds`` (replicated, ``(Q, D)``) sharded across the ranks
+    against the replicated DB; the similarity rows are all-gathered so that every rank returns the single-process result
+    (``gather=False``: this rank's rows ``shard_range(Q, rank, R)`` only, no collective)."""
+    from semanticlens_amd.lens import _probe
 
-    The (templated) prompt list is sharded through the text tower and all-gathered, the template mean (which mixes
-    prompts of different queries, SURVEY.md finding 4) runs on the full list, then query rows are sharded through the
-    cosine GEMM against the replicated DB and the similarity rows are all-gathered."""
-    from semanticlens_amd.lens import _embed_text_probes, _probe
-
-    queries = query if isinstance(query, list) else [query]
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    embeds = _embed_text_probes(fm, queries, templates, batch_size,
-                                encode=lambda texts, bs: encode_text_sharded(fm, texts, bs, group))
     Q, D = embeds.shape
     lo, hi = shard_range(Q, rank, world)
 
@@ -404,19 +399,42 @@ def text_probing_sharded(fm, query, aggregated_concept_db, templates=None, batch
     if isinstance(aggregated_concept_db, torch.Tensor):
         if quirky(aggregated_concept_db):
             return _probe(embeds, aggregated_concept_db)
-        return all_gather_rows(_probe(embeds[lo:hi], aggregated_concept_db), Q, group)
+        part = _probe(embeds[lo:hi], aggregated_concept_db)
+        return all_gather_rows(part, Q, group) if gather else part
     plain = {k: v for k, v in aggregated_concept_db.items() if not quirky(v)}
     local = _probe(embeds[lo:hi], plain) if plain else {}
     out = {}
     for k, v in aggregated_concept_db.items():  # keep the caller's layer order
-        out[k] = all_gather_rows(local[k], Q, group) if k in local else _probe(embeds, {k: v})[k]
+        if k in local:
+            out[k] = all_gather_rows(local[k], Q, group) if gather else local[k]
+        else:
+            out[k] = _probe(embeds, {k: v})[k]
     return out
+
+
+@torch.no_grad()
+def text_probing_sharded(fm, query, aggregated_concept_db, templates=None, batch_size=None, group=None):
+    """Multi-GPU ``Lens.text_probing`` (lens.py:331-362): same result on every rank, equal to the single-process one.
+
+    The (templated) prompt list is sharded through the text tower and all-gathered, the template mean (which mixes
+    prompts of different queries, SURVEY.md finding 4) runs on the full list, then query rows are sharded through the
+    cosine GEMM against the replicated DB and the similarity rows are all-gathered (``probe_sharded``)."""
+    from semanticlens_amd.lens import _embed_text_probes
+
+    queries = query if isinstance(query, list) else [query]
+    embeds = _embed_text_probes(fm, queries, templates, batch_size,
+                                encode=lambda texts, bs: encode_text_sharded(fm, texts, bs, group))
+    return probe_sharded(embeds, aggregated_concept_db, group)
 
 
 @torch.no_grad()
 def eval_sharded(score_fn, concept_db, group=None):
     """Per-component scores (``clarity_score`` / ``polysemanticity_score``: every component is independent) with the
-    component axis sharded across ranks; ``concept_db``: ``(C, n, D)`` tensor or dict of them, replicated."""
+    component axis sharded across ranks; ``concept_db``: ``(C, n, D)`` tensor or dict of them, replicated.
+
+    A dict of ``(C_l, n, D)`` layers costs ONE exchange: rank r scores rows ``shard_range(C_l, r, R)`` of every layer (clarity: all
+    layers in one K7 launch, like ``Lens.eval_clarity``), the per-layer blocks (padded to ``ceil(C_l / R)``) travel in one
+    all-gather, and every rank cuts the layers back out."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
 
     def one(V):
@@ -433,4 +451,33 @@ def eval_sharded(score_fn, concept_db, group=None):
 
     if isinstance(concept_db, torch.Tensor):
         return one(concept_db)
-    return {k: one(v) for k, v in concept_db.items()}
+    keys = list(concept_db)
+    if len(keys) < 2 or not all(isinstance(concept_db[k], torch.Tensor) and concept_db[k].ndim == 3 and concept_db[k].shape[0] > 0
+                                and concept_db[k].is_cuda for k in keys):
+        return {k: one(v) for k, v in concept_db.items()}
+    from semanticlens_amd.scores import clarity_score
+
+    cuts = {k: shard_range(concept_db[k].shape[0], rank, world) for k in keys}
+    mine = [k for k in keys if cuts[k][1] > cuts[k][0]]
+    parts = {}
+    if score_fn is clarity_score and len(mine) > 1:
+        outs = N.clarity_multi([concept_db[k][cuts[k][0]:cuts[k][1]] for k in mine])
+        if outs is not None:
+            parts = dict(zip(mine, outs))
+    for k in mine:
+        if k not in parts:
+            parts[k] = score_fn(concept_db[k][cuts[k][0]:cuts[k][1]])
+    probe = next(iter(parts.values())) if parts else score_fn(concept_db[keys[0]][:1])
+    pers = [-(-concept_db[k].shape[0] // world) for k in keys]
+    block = torch.zeros(sum(pers), dtype=probe.dtype, device=concept_db[keys[0]].device)
+    off = 0
+    for k, per in zip(keys, pers):
+        if k in parts:
+            block[off:off + parts[k].shape[0]] = parts[k].to(block.device)
+        off += per
+    full = all_gather_rows(block.reshape(1, -1), world, group)  # (R, sum of per-layer blocks)
+    out, off = {}, 0
+    for k, per in zip(keys, pers):
+        out[k] = full[:, off:off + per].reshape(-1)[: concept_db[k].shape[0]].contiguous()
+        off += per
+    return out

@@ -135,16 +135,36 @@ def _bench_line(extra_env, args, nproc):
     return json.loads(lines[0])
 
 
+BUILD_ONLY = ["--no-tokens-leg", "--no-config4-leg", "--no-probing", "--no-cpu-baseline"]  # the headline job (+ strong scaling) alone
+
+
 def test_bench_two_ranks_sharing_one_gpu_over_gloo():
     """BASELINE configs[2] code path (`bench.py --gpus N`): per-rank collect, packed all-gather, K4 merge, sharded K5
-    gather + all-reduce, max-over-ranks timing — with two ranks on ONE GPU and gloo as the transport."""
+    gather + all-reduce, max-over-ranks timing — with two ranks on ONE GPU and gloo as the transport.  The N > 1 line is COMPLETE:
+    configs[3] / configs[4] collect legs with the cross-rank merge, text_probing with the query rows sharded, the scores with the
+    component axis sharded, the CPU baseline (rank 0) and the oracle / single-process parity of each."""
     line = _bench_line({"SL_BENCH_BACKEND": "gloo", "SL_BENCH_SHARE_GPU": "1"}, ["--steps", "3", "--batches-per-step", "2", "--warmup", "1", "--batch", "64", "--min-warmup-seconds", "0.3",
-                                                                                 "--strong-images", "1500", "--strong-pool-batches", "4"], 2)
+                                                                                 "--strong-images", "1500", "--strong-pool-batches", "4", "--cpu-images", "64"], 2)
     assert line["strong_scaling"]["images"] == 1500 and line["strong_scaling"]["tie_mode"] == "total"  # (the default is the 1.28 M-image job: 200 s here)
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
     assert line["config"]["images_total"] == 2 * 3 * 2 * 64 and line["value"] > 0
+    chk = line["sharded_check"]
+    assert chk["topk_values_equal"] and chk["topk_ids_equal"] and chk["concept_db_equal"] and chk["probe_equal"] and chk["scores_equal"], chk
+    tp = line["text_probing"]
+    assert tp["n_gpus"] == 2 and tp["value"] > 0 and tp["roofline"]["frac"] > 0 and tp["compute_only"]["value"] >= tp["value"] * 0.5
+    assert tp["sharded_check"]["equals_single_process_bitwise"] and tp["sharded_check"]["max_abs_diff_vs_oracle_64_queries"] < 1e-4
+    assert tp["from_prompts"]["n_gpus"] == 2 and tp["from_prompts"]["queries_per_s"] > 0
+    c3, c4 = line["config3_full"], line["config4_full"]
+    assert c3["n_gpus"] == 2 and c3["images"] == 2 * 8 * 64 and c3["self_check"] == "ok" and c3["roofline"]["frac"] > 0
+    assert c3["text_probing_from_prompts"]["n_gpus"] == 2 and c3["text_probing_from_prompts"]["max_abs_diff_vs_oracle_64_queries"] < 1e-4
+    assert c4["n_gpus"] == 2 and c4["images"] == 2 * 4 * 64 and c4["self_check"] == "ok"
+    assert c4["relevance_visualizer"]["n_gpus"] == 2 and c4["relevance_visualizer"]["images"] == 256
+    sc = c4["scores_full_db"]
+    assert sc["n_gpus"] == 2 and sc["sharded_equals_single_process"] is True and all(v < 1e-4 for v in sc["max_abs_diff_vs_oracle"].values())
+    cpu = line["cpu_baseline"]
+    assert cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["all_cores"]["value"] > 0 and cpu["kind"] == "port"
     line = _bench_line({"SL_BENCH_BACKEND": "gloo", "SL_BENCH_SHARE_GPU": "1"},
-                       ["--scaling", "strong", "--images", "500", "--batches-per-step", "1", "--warmup", "1", "--batch", "64", "--min-warmup-seconds", "0"], 2)
+                       ["--scaling", "strong", "--images", "500", "--batches-per-step", "1", "--warmup", "1", "--batch", "64", "--min-warmup-seconds", "0"] + BUILD_ONLY, 2)
     assert line["scaling"] == "strong" and line["config"]["images_total"] == 500 and line["steps"] == 4
 
 
@@ -361,7 +381,7 @@ def test_bench_launches_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["SL_BENCH_SHARE_GPU"] = "1"
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--batches-per-step", "2", "--warmup", "1",
-           "--batch", "64", "--min-warmup-seconds", "0.2", "--strong-images", "333", "--strong-pool-batches", "2"]
+           "--batch", "64", "--min-warmup-seconds", "0.2", "--strong-images", "333", "--strong-pool-batches", "2"] + BUILD_ONLY
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]

@@ -118,7 +118,7 @@ def test_grouping_off_gives_the_same_states(monkeypatch):
         assert torch.equal(on.cache[name].sample_ids, off.cache[name].sample_ids)
 
 
-def test_in_place_edit_keeps_a_layer_out_of_its_group_or_raises():
+def test_in_place_edit_keeps_a_layer_out_of_its_group_or_raises(monkeypatch):
     torch.manual_seed(3)
     model = _TokenBlocks(depth=4, inplace_after=1).to(DEV).eval()
     layers = [f"blocks.{i}" for i in range(4)]
@@ -128,8 +128,9 @@ def test_in_place_edit_keeps_a_layer_out_of_its_group_or_raises():
     model.edit = True
     cache = _run_stream(model, layers, agg.aggregate_transformer_max, "tokens", batches)
     assert [g_["layers"] for g_ in cache._groups] == [["blocks.0", "blocks.2", "blocks.3"]]
-    # (ii) the edit starts AFTER the groups were planned: the launch refuses instead of reducing modified values
+    # (ii) the edit starts AFTER the groups were planned.  strict: the launch refuses instead of reducing modified values
     model.edit = False
+    monkeypatch.setenv("SEMANTICLENS_AMD_GROUP_LAYERS", "strict")
     cache = ActMaxCache(layers, agg.aggregate_transformer_max, n_collect=5, tie_mode="aten")
     with torch.no_grad(), cache.hook_context(model):
         model(batches[0])
@@ -138,6 +139,28 @@ def test_in_place_edit_keeps_a_layer_out_of_its_group_or_raises():
         with pytest.raises(RuntimeError, match="modified in place after its forward hook"):
             model(batches[2])
     model.edit = False
+    # default: one warning, the edited layer leaves its group, the other members lose nothing and the run goes on
+    monkeypatch.delenv("SEMANTICLENS_AMD_GROUP_LAYERS")
+    cache = ActMaxCache(layers, agg.aggregate_transformer_max, n_collect=5, tie_mode="aten")
+    ref = ActMaxCache(layers, agg.aggregate_transformer_max, n_collect=5, tie_mode="aten")
+    ref._grouping = False  # every layer inside its own hook: sees the values before the edit
+    with torch.no_grad(), cache.hook_context(model):
+        model(batches[0])
+        model(batches[1])
+        model.edit = True
+        with pytest.warns(RuntimeWarning, match="'blocks.1' was modified in place"):
+            model(batches[2])
+        model(batches[3])  # blocks.1 now alone in its hook (before the edit), the other three as a group
+    assert [g_["layers"] for g_ in cache._groups] == [["blocks.0", "blocks.2", "blocks.3"]]
+    model.edit = False
+    with torch.no_grad(), ref.hook_context(model):
+        for i, b in enumerate(batches):
+            model.edit = i >= 2
+            model(b)
+    model.edit = False
+    for name in ("blocks.0", "blocks.2", "blocks.3"):
+        assert np.array_equal(bits(cache.cache[name].activations), bits(ref.cache[name].activations)), name
+        assert torch.equal(cache.cache[name].sample_ids, ref.cache[name].sample_ids), name
 
 
 def test_conv_layers_channels_last_and_nchw():
@@ -170,7 +193,9 @@ def test_conv_layers_channels_last_and_nchw():
 def test_multi_reduce_equals_tensor_by_tensor(dtype, code):
     codes = {"max": N.SL_TOK_MAX, "mean": N.SL_TOK_MEAN, "absmax": N.SL_TOK_ABSMAX, "absmean": N.SL_TOK_ABSMEAN}
     g = torch.Generator().manual_seed(6)
-    for L, B, T, F in ((3, 5, 17, 96), (33, 2, 9, 64), (2, 4, 50, 768), (4, 3, 8, 30), (2, 7, 197, 200)):  # 33 > one table; F = 30: fallback
+    # 33 > one table; F = 30: fallback; (12, 8, 197, 768) and (12, 32, 197, 768): alone a tensor is below two tasks per CU (16 / 8 waves
+    # split the token axis), the table of 12 is not — a sum must not change its order with the company it is reduced in (advisor, round 5)
+    for L, B, T, F in ((3, 5, 17, 96), (33, 2, 9, 64), (2, 4, 50, 768), (4, 3, 8, 30), (2, 7, 197, 200), (12, 8, 197, 768), (12, 32, 197, 768)):
         xs = [torch.randn(B, T, F, generator=g).to(DEV).to(dtype) for _ in range(L)]
         xs[0][0, 1, 2] = float("nan")
         xs[-1][1, 0, 3] = float("inf")

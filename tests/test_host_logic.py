@@ -804,3 +804,34 @@ def test_reduce_policy_tuner_measures_every_candidate_and_keeps_the_default_unle
     go(t, (1.0, 0.5, 0.5))
     assert t.choice is None and len(applied) == before  # the caller's explicit policy wins
     assert N.ReducePolicyTuner.for_site(("m", "layer")) is N.ReducePolicyTuner.for_site(("m", "layer"))
+
+
+# ---- the aten tie order's host self-test: restatement vs the installed torch.topk, no device -----------------------
+def test_aten_order_restatement_equals_the_installed_torch_topk():
+    """`sl_aten_topk_order_host` is host code: the positions the K3 kernels' restatement selects against `torch.topk` on the CPU of
+    THIS container (torch 2.10 / libstdc++ 11), both ATen branches, NaN, the -0.0 sentinel row."""
+    res = N.aten_order_selftest(rows=400, force=True)
+    assert res["rows"] == 400 and res["mismatches"] == 0, res
+    g = torch.Generator().manual_seed(77)
+    for k, n in ((20, 276), (100, 164), (20, 1300), (1, 64), (7, 7), (100, 6600)):  # k * 64 <= n: partial_sort — 1300, 64, 6600
+        for _ in range(25):
+            row = (torch.randint(-3, 9, (n,), generator=g).float() / 2).to(torch.bfloat16)
+            assert torch.equal(N.aten_topk_order_host(row, k), torch.topk(row, k).indices.to(torch.int32)), (k, n)
+    with pytest.raises(ValueError, match="sl_aten_topk_order_host"):
+        N.aten_topk_order_host(torch.zeros(4, dtype=torch.bfloat16), 5)
+
+
+def test_aten_order_selftest_warns_on_a_host_with_another_tie_order(monkeypatch):
+    """A torch whose topk breaks ties differently (here: a stable sort, lowest position first) is reported once, with versions."""
+    real = torch.topk
+
+    def stable_topk(x, k, *a, **kw):
+        order = torch.sort(x.float().nan_to_num(nan=float("inf")), descending=True, stable=True).indices[:k]
+        return type("R", (), {"indices": order, "values": x[order]})()
+
+    monkeypatch.setattr(torch, "topk", stable_topk)
+    with pytest.warns(RuntimeWarning, match="selects different positions on"):
+        res = N.aten_order_selftest(force=True)
+    assert res["mismatches"] > 0
+    monkeypatch.setattr(torch, "topk", real)
+    assert N.aten_order_selftest(force=True)["mismatches"] == 0

@@ -77,7 +77,7 @@ def standins(monkeypatch):
     return log
 
 
-def _stream(model, layers, batches, log, k=4, before_batch=None, after_batch=None):
+def _stream(model, layers, batches, log, k=4, before_batch=None, after_batch=None, edited=None):
     cache = ActMaxCache(layers, agg.aggregate_transformer_max, n_collect=k, tie_mode="aten")
     cache._group_device_types = ("cpu",)
     mods = dict(model.named_modules())
@@ -92,7 +92,7 @@ def _stream(model, layers, batches, log, k=4, before_batch=None, after_batch=Non
             model(x)
             for n in layers:
                 if len(taps[n]) > n_before[n]:
-                    a = oracle.agg_tokens(taps[n][-1], "max")
+                    a = oracle.agg_tokens(taps[n][-1] * (edited or {}).get((bi, n), 1.0), "max")
                     refs.setdefault(n, oracle.ActMaxOracle(k, a.shape[1], oracle.MODE_ATEN)).update(a, np.arange(seen[n], seen[n] + x.shape[0]))
                     seen[n] += x.shape[0]
             if after_batch:
@@ -175,9 +175,25 @@ def test_in_place_edits(standins, monkeypatch, batch_k3):
     def before(bi, cache):
         model.edit_after = 2 if bi == 2 else None  # starts after the groups were planned
 
+    # strict: the launch refuses instead of reducing modified values
+    monkeypatch.setenv("SEMANTICLENS_AMD_GROUP_LAYERS", "strict")
     with pytest.raises(RuntimeError, match="modified in place after its forward hook"):
         _stream(model, layers, _batches(4), standins, before_batch=before)
+    # default: ONE warning naming the samples, the edited layer leaves its group for good, every other member's batch is collected
+    # intact (layer by layer), and the run goes on — the edited layer's batch 3 is what the tensor held at launch time (x 0.5)
+    monkeypatch.delenv("SEMANTICLENS_AMD_GROUP_LAYERS")
+    del standins[:]
+    with pytest.warns(RuntimeWarning, match=r"'blocks.2' was modified in place.*samples 10\.\.14") as rec:
+        cache = _stream(model, layers, _batches(5), standins, before_batch=before, edited={(2, "blocks.2"): 0.5})
+    assert len([w for w in rec if "modified in place" in str(w.message)]) == 1
+    assert [g["layers"] for g in cache._groups] == [["blocks.0", "blocks.1", "blocks.3"]] and "blocks.2" not in cache._group_of
+    if batch_k3 == "0":
+        assert standins.count(("reduce_multi", 4)) == 1 and standins.count(("reduce_multi", 3)) == 2  # batch 2; batches 4 and 5
     model.edit_after = None
+    # a group left with one member is dissolved
+    cache._ungroup("blocks.0")
+    cache._ungroup("blocks.1")
+    assert cache._group_of == {} and cache._groups[0]["layers"] == []
 
 
 def test_switches(standins, monkeypatch):
