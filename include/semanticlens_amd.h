@@ -65,6 +65,12 @@ extern "C" {
 const char* sl_last_error(void);
 int sl_abi_version(void);
 /* number of HIP devices visible, or SL_E_HIP */
+/* Variant switches — which of several BIT-IDENTICAL kernel variants a dispatcher picks (0 = its own rule).  The parity tests walk the
+ * variants with these; production code never needs them.  Names: "g3_tile" (split-bf16 GEMM tile: 128, 256, 8, 160, 64, 1280),
+ * "f32_tile" (fp32-MFMA GEMM: 128, 8), "g3_strip_off" (1: no column-strip split), "colreduce_nw" (K2 waves per task: 4, 8, 16).
+ * The environment variable SL_OPTIONS="name=value,..." presets them for a process; an explicit call wins.  No reference counterpart. */
+int sl_set_option(const char* name, int64_t value);
+int64_t sl_get_option(const char* name); /* -1 for an unknown name */
 int sl_device_count(void);
 
 /* ---- K1: spatial reduce of a conv activation -------------------------------------------

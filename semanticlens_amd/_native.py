@@ -50,6 +50,8 @@ SIGNATURES = {
     "sl_actmax_update_multi": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _i64, _i64, _vp]),
     "sl_actmax_update_multi_supported": (_int, [_i64, _i64, _i64]),
     "sl_aten_topk_order_host": (_int, [_vp, _i64, _i64, _vp]),
+    "sl_set_option": (_int, [ctypes.c_char_p, _i64]),
+    "sl_get_option": (_i64, [ctypes.c_char_p]),
     "sl_reduce_conv_multi": (_int, [_vp, _int, _int, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp, _vp]),
     "sl_reduce_tokens_multi": (_int, [_vp, _int, _int, _i64, _i64, _i64, _i64, _i64, _i64, _int, _i64, _vp, _vp]),
     "sl_actmax_merge_states": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),
@@ -322,6 +324,16 @@ def actmax_merge(vals, ids, cand: torch.Tensor, slot_stride: int, id_bases: list
     with _on(vals.device):
         rc = lib().sl_actmax_merge(_ptr(vals), _ptr(ids), C, k, _ptr(cand), slot_stride, hb, hr, n, _stream(vals))
     _check(rc, "sl_actmax_merge")
+
+
+def set_option(name: str, value: int) -> None:
+    """Force one of several bit-identical kernel variants (``g3_tile``, ``f32_tile``, ``g3_strip_off``, ``colreduce_nw``; 0 = the
+    dispatcher's own rule).  For the parity tests; ``SL_OPTIONS="name=value,..."`` presets them for a process."""
+    _check(lib().sl_set_option(name.encode(), int(value)), "sl_set_option")
+
+
+def get_option(name: str) -> int:
+    return int(lib().sl_get_option(name.encode()))
 
 
 def aten_topk_order_host(row_bf16: torch.Tensor, k: int) -> torch.Tensor:

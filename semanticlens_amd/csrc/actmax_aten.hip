@@ -320,13 +320,7 @@ constexpr size_t kLdsStatic = 48 * 8 + 128;
 constexpr size_t kLdsBudget = 64 * 1024 - kLdsStatic;
 constexpr size_t kLdsMax = 160 * 1024 - kLdsStatic;
 
-bool wave_impl() {  // SL_K3_ATEN_IMPL = wave (default) | lane (round 4: one lane per row)
-  static const int impl = [] {
-    const char* e = getenv("SL_K3_ATEN_IMPL");
-    return (e && strcmp(e, "lane") == 0) ? 0 : 1;
-  }();
-  return impl == 1;
-}
+constexpr bool wave_impl() { return true; }  // (the one-lane-per-row kernel of round 4 remains the path for rows too long for the LDS)
 
 int launch_wave(ProfScope& prof, const K3States& tab, int L, int64_t k, const int64_t* d_sample_ids, int64_t B, hipStream_t st) {
   const int64_t n = k + B, Ctot = tab.cstart[L];

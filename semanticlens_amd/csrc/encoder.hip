@@ -231,94 +231,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
-// ---- multi-head attention, head_dim 64 --------------------------------------------------------------------
-// qkv: (B*T, 3*H*64) rows [q | k | v], head h at columns h*64.  softmax(q k^T / sqrt(64)) v, optional causal mask.
-// One 256-thread workgroup per (batch, head): K and V of the head sit in LDS (T x 64 floats each); a query row is
-// owned by 4 adjacent lanes, each holding 16 of the 64 dims of q and of the output accumulator, so a wave covers 16
-// rows and the workgroup 64 rows per pass.  Scores are reduced over the 4 lanes with two quad DPP adds and fed
-// to an online softmax (running max / sum, accumulator rescaled per key), so no T x T score buffer exists and
-// ~6 waves per SIMD are resident (the first version, one wave per head with 64-float q and o arrays per lane
-// and a score buffer, ran at one wave per SIMD and took 39 % of the encoder's time).
-constexpr int kDh = 64;
-__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, int T, int H, int causal,
-                                                         float* __restrict__ out, uint16_t* __restrict__ osp) {
-  extern __shared__ __align__(16) float smem[];
-  float* sK = smem;                    // T x 64
-  float* sV = smem + (size_t)T * kDh;  // T x 64
-  const int tid = threadIdx.x;
-  const int64_t b = blockIdx.x / H;
-  const int h = blockIdx.x % H;
-  const int64_t ld = 3ll * H * kDh;
-  const float* base = qkv + b * T * ld + h * kDh;
-  for (int e = tid; e < T * (kDh / 4); e += 256) {
-    const int t = e / (kDh / 4), c = e % (kDh / 4);
-    reinterpret_cast<float4*>(sK)[e] = *reinterpret_cast<const float4*>(base + t * ld + (int64_t)H * kDh + c * 4);
-    reinterpret_cast<float4*>(sV)[e] = *reinterpret_cast<const float4*>(base + t * ld + 2ll * H * kDh + c * 4);
-  }
-  __syncthreads();
-  const int part = tid & 3;  // which 16 dims of the head this lane owns
-  for (int r0 = 0; r0 < T; r0 += 64) {
-    const int i = r0 + (tid >> 2);
-    const bool active = i < T;
-    float q[16], o[16];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (active) v = *reinterpret_cast<const float4*>(base + (int64_t)i * ld + part * 16 + c * 4);
-      q[4 * c + 0] = v.x * 0.125f; q[4 * c + 1] = v.y * 0.125f; q[4 * c + 2] = v.z * 0.125f; q[4 * c + 3] = v.w * 0.125f;
-      o[4 * c + 0] = 0.f; o[4 * c + 1] = 0.f; o[4 * c + 2] = 0.f; o[4 * c + 3] = 0.f;
-    }
-    // keys any row of this wave may need: rows of a wave are r0 + 16*w .. + 15
-    const int wave_last_row = r0 + (tid >> 6) * 16 + 15;
-    const int jmax = causal ? (wave_last_row + 1 < T ? wave_last_row + 1 : T) : T;
-    float m = -__builtin_huge_valf(), l = 0.f;
-    for (int j = 0; j < jmax; ++j) {
-      const float4* kj = reinterpret_cast<const float4*>(sK + (size_t)j * kDh + part * 16);
-      float sp = 0.f;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float4 kv = kj[c];
-        sp += q[4 * c] * kv.x + q[4 * c + 1] * kv.y + q[4 * c + 2] * kv.z + q[4 * c + 3] * kv.w;
-      }
-      // sum over the 4 lanes of the row (quad_perm [1,0,3,2] then [2,3,0,1])
-      sp += bits_f32((uint32_t)__builtin_amdgcn_update_dpp(0, (int)f32_bits(sp), 0xB1, 0xF, 0xF, false));
-      sp += bits_f32((uint32_t)__builtin_amdgcn_update_dpp(0, (int)f32_bits(sp), 0x4E, 0xF, 0xF, false));
-      const bool masked = causal && j > i;
-      const float s = masked ? -__builtin_huge_valf() : sp;
-      const float mn = fmaxf(m, s);
-      const float alpha = expf(m - mn);          // first key: exp(-inf) = 0
-      const float pj = masked ? 0.f : expf(s - mn);
-      l = l * alpha + pj;
-      m = mn;
-      const float4* vj = reinterpret_cast<const float4*>(sV + (size_t)j * kDh + part * 16);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float4 vv = vj[c];
-        o[4 * c + 0] = o[4 * c + 0] * alpha + pj * vv.x;
-        o[4 * c + 1] = o[4 * c + 1] * alpha + pj * vv.y;
-        o[4 * c + 2] = o[4 * c + 2] * alpha + pj * vv.z;
-        o[4 * c + 3] = o[4 * c + 3] * alpha + pj * vv.w;
-      }
-    }
-    if (active) {
-      const float inv = 1.f / l;
-      const int64_t o0 = (b * T + i) * (int64_t)H * kDh + h * kDh + part * 16;
-      if (out) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          *reinterpret_cast<float4*>(out + o0 + c * 4) = make_float4(o[4 * c] * inv, o[4 * c + 1] * inv, o[4 * c + 2] * inv, o[4 * c + 3] * inv);
-      }
-      if (osp) {
-#pragma unroll
-        for (int d = 0; d < 16; ++d) store_split(o[d] * inv, b * T + i, h * kDh + part * 16 + d, split_kp((int64_t)H * kDh), osp);
-      }
-    }
-  }
-}
-
+// (The first attention kernel of the tower — VALU, four lanes per query row, head_dim 64 — was superseded by the two matrix-core
+// kernels below in round 2 and left the product library in round 6: tools/native/attention_valu_lab.hpp.)
 // ---- the same attention on the fp32-input matrix cores ---------------------------------------------------------
-// The VALU kernel above re-reads K and V from LDS for every group of 16 query rows (1.6 MB of LDS traffic per head at
-// T = 50) and is LDS-bandwidth bound.  Here a wave owns 32 query rows and works on 32-key tiles with
+// The VALU kernel re-read K and V from LDS for every group of 16 query rows (1.6 MB of LDS traffic per head at
+// T = 50) and was LDS-bandwidth bound.  Here a wave owns 32 query rows and works on 32-key tiles with
 // v_mfma_f32_32x32x2_f32 (exact fp32 products and accumulation):
 //   S^T (keys x queries) = K Q^T : A = K rows from LDS (lane l: key l % 32, dims 32 (l / 32) + s), B = Q^T from
 //                                  registers (lane l: query l % 32, the same 32 dims, pre-scaled by 1/8)
@@ -341,7 +258,7 @@ __host__ __device__ constexpr int attn_chunk(int D) { return D <= 64 ? 256 : (D 
 template <int D>
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __restrict__ qkv, int T, int H, int causal, float scale,
                                                               float* __restrict__ out, uint16_t* __restrict__ osp) {
-  constexpr int kDh = D;  // shadows the 64 of the VALU kernel
+  constexpr int kDh = D;
   constexpr int NT = (D + 31) / 32;
   constexpr int HD = D / 2;  // dims per half-wave in the score product (multiple of 4)
   constexpr int kKvLd = attn_ld(D);
@@ -988,34 +905,19 @@ SL_API int sl_attention(const float* d_qkv, int64_t B, int64_t T, int64_t H, int
   if (B == 0) return 0;
   SL_REQUIRE(d_qkv && (d_out || d_out_split), "sl_attention: null pointer");
   SL_REQUIRE(B * H < (1ll << 31), "sl_attention: too many heads");
-  static const int impl = [] {
-    const char* e = getenv("SL_ATTENTION_IMPL");  // "valu": the 4-lanes-per-row kernel (head_dim 64, T <= 256)
-    return (e && strcmp(e, "valu") == 0) ? 0 : 1;
-  }();
   hipStream_t st = (hipStream_t)stream;
-  if (impl == 1) {
-    switch (head_dim) {
-      case 32: return launch_attention_mfma<32>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
-      case 64: return launch_attention_mfma<64>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
-      case 72: return launch_attention_mfma<72>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
-      case 80: return launch_attention_mfma<80>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
-      case 88: return launch_attention_mfma<88>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
-      case 96: return launch_attention_mfma<96>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
-      case 104: return launch_attention_mfma<104>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
-      case 128: return launch_attention_mfma<128>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
-      default: break;
-    }
-    SL_REQUIRE(false, "sl_attention: head_dim=%lld (built: 32, 64, 72, 80, 88, 96, 104, 128)", (long long)head_dim);
+  switch (head_dim) {
+    case 32: return launch_attention_mfma<32>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
+    case 64: return launch_attention_mfma<64>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
+    case 72: return launch_attention_mfma<72>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
+    case 80: return launch_attention_mfma<80>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
+    case 88: return launch_attention_mfma<88>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
+    case 96: return launch_attention_mfma<96>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
+    case 104: return launch_attention_mfma<104>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
+    case 128: return launch_attention_mfma<128>(d_qkv, B, T, H, causal, d_out, d_out_split, st);
+    default: break;
   }
-  SL_REQUIRE(head_dim == kDh, "sl_attention (valu kernel): head_dim=%lld (only 64 is built)", (long long)head_dim);
-  SL_REQUIRE(T <= 256, "sl_attention (valu kernel): sequence length %lld exceeds 256", (long long)T);
-  const size_t smem = (size_t)T * kDh * 4 * 2;
-  if (smem > 64 * 1024)
-    SL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL(attention_kernel, dim3((unsigned)(B * H)), dim3(256), smem, st, d_qkv, (int)T, (int)H, causal, d_out,
-                     d_out_split);
-  SL_CHECK_HIP(hipGetLastError());
-  return 0;
+  SL_REQUIRE(false, "sl_attention: head_dim=%lld (built: 32, 64, 72, 80, 88, 96, 104, 128)", (long long)head_dim);
 }
 
 template <int D>
@@ -1025,12 +927,8 @@ static int launch_attention_bf16x3(const float* qkv, int64_t B, int64_t T, int64
   const int64_t kc = Tp < attn3_kc() ? Tp : attn3_kc();
   const int NT = (D + 31) / 32;
   const size_t smem = 2 * (size_t)kc * (attn3_dp(D) * 2 + 16) + 2 * (size_t)(NT * 32) * (kc * 2 + 16);
-  static const int max_waves = [] {
-    const char* e = getenv("SL_ATTN_WAVES");  // 4: the round-3 launch shape for every sequence length
-    return e ? atoi(e) : 8;
-  }();
   const float scale = (float)(1.0 / sqrt((double)D));
-  if (Tp / 32 > 4 && max_waves >= 8 && D <= 96) {  // head_dim 104 / 128 would spill at 256 registers per wave
+  if (Tp / 32 > 4 && D <= 96) {  // head_dim 104 / 128 would spill at 256 registers per wave
     const int waves = (int)(Tp / 32 < 8 ? Tp / 32 : 8);
     if (smem > 64 * 1024)
       SL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_bf16x3_kernel<D, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

@@ -377,15 +377,9 @@ int launch(ProfScope& prof, const void* A, int64_t M, const void* B, int64_t N, 
   return 0;
 }
 
-// kernel choice shared by the bf16x3 and the f32 launchers: the 8-phase kernel from `SL_G8_MIN_PCT` percent of a tile per
-// CU upwards (default 50: the encoder's 150-600-tile GEMMs gain, ViT-B/32 image encode 9.66 -> 9.08 ms)
-inline bool worth_it(int64_t M, int64_t N) {
-  static const int min_pct = [] {
-    const char* e = getenv("SL_G8_MIN_PCT");
-    return e ? atoi(e) : 50;
-  }();
-  return tiles_of(M, N) * 100 >= (int64_t)min_pct * num_cus();
-}
+// kernel choice shared by the bf16x3 and the f32 launchers: the 8-phase kernel from half a tile per CU upwards (the encoder's
+// 150-600-tile GEMMs gain, ViT-B/32 image encode 9.66 -> 9.08 ms)
+inline bool worth_it(int64_t M, int64_t N) { return tiles_of(M, N) * 2 >= (int64_t)num_cus(); }
 
 // fp32-input MFMA mode: a tile takes 5.3x longer than in bf16x3 mode and the 128 x 128 kernel reaches 0.76-0.83 of peak on
 // its own, so the big kernel only pays when its last round is nearly full or there is a single round

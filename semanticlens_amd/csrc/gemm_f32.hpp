@@ -191,11 +191,8 @@ int launch_gemm_nt(ProfScope& prof, const float* A, int64_t M, const float* B, i
   if (tm * tn == 0) return 0;
   const bool vec = (K % 4 == 0) && (((uintptr_t)A | (uintptr_t)B) & 15) == 0;
   // Large grids whose rows are whole 128-byte lines: the 256 x 256 8-phase kernel (gemm_8phase.hpp), same bits.
-  // SL_F32_TILE=128 / 8 forces one of the two (tests).
-  static const int forced = [] {
-    const char* e = getenv("SL_F32_TILE");
-    return e ? atoi(e) : 0;
-  }();
+  // option "f32_tile" = 128 / 8 forces one of the two (tests).
+  const int forced = (int)option(OPT_F32_TILE);
   if (vec && K % 32 == 0 && K > 0 && gemm8::fits(M, N, K * 4) && (forced ? forced == 8 : gemm8::worth_it_f32(M, N)))
     return gemm8::launch<gemm8::MODE_F32>(prof, A, M, B, N, K * 4, K / 32, epi, st);
   if (vec)

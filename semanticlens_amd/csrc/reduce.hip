@@ -1229,10 +1229,7 @@ void launch_rowreduce_fast(ProfScope& prof, const float* x, int64_t R, int S, fl
   const int64_t cap = (int64_t)num_cus() * 8;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  static const int reverse = [] {
-    const char* e = getenv("SL_REDUCE_REVERSE");
-    return e ? atoi(e) : 0;
-  }();
+  constexpr int reverse = 0;  // (walking the batches backwards was an A/B of round 2; the kernel keeps the parameter)
   const int64_t nt_min_bytes = nt_min_bytes_(), tail_bytes = tail_bytes_();  // cache policy: see the top of this file
   const int64_t bytes = R * (int64_t)S * 4;
   if (bytes >= nt_min_bytes) {
@@ -1275,10 +1272,7 @@ void launch_rowreduce_dma(ProfScope& prof, const T* x, int64_t R, int S, float d
 // U = tasks per batch (<= 4) so that a batch is at most 4 KiB; false when a task alone is larger
 template <int G, int OP, bool ALIGNED, typename T, bool MULTI = false>
 bool try_rowreduce_dma(ProfScope& prof, const T* x, int64_t R, int S, float denom, uint16_t* cand, float* outf, hipStream_t st) {
-  static const bool enabled = [] {
-    const char* e = getenv("SL_REDUCE_DMA");  // 0: always the VGPR-load kernels (A/B measurements)
-    return !(e && atoi(e) == 0);
-  }();
+  constexpr bool enabled = true;
   constexpr int RPT = kWave / G;
   const int64_t task_bytes = (int64_t)RPT * S * (int64_t)sizeof(T);
   if (!enabled || task_bytes > (MULTI && sizeof(T) == 2 ? 16 * 1024 : kDmaMaxBatch) || (task_bytes & 15) != 0 || R % RPT != 0 || R * (int64_t)S * (int64_t)sizeof(T) < (8ll << 20) ||
@@ -1376,24 +1370,13 @@ void launch_colreduce2_as(ProfScope& prof, const MultiSrc& x, int64_t B, int T_,
 template <typename T, int OP>
 bool launch_colreduce2(ProfScope& prof, const MultiSrc& x, int64_t B, int T_, int64_t F, int64_t sb, int64_t st_, int t0, int t1,
                        float denom, uint16_t* cand, float* outf, hipStream_t st) {
-  static const int impl = [] {  // SL_COLREDUCE_IMPL = v2 (default) | vgpr (rounds 1-3) | dma (LDS-DMA rings; -DSL_K2_DMA_LAB builds only)
-    const char* e = getenv("SL_COLREDUCE_IMPL");
-    return e ? (strcmp(e, "vgpr") == 0 ? 0 : strcmp(e, "dma") == 0 ? 2 : 1) : 1;
-  }();
-  static const int forced_nw = [] {
-    const char* e = getenv("SL_COLREDUCE_NW");
-    return e ? atoi(e) : 0;
-  }();
-  static const int forced_lpr = [] {
-    const char* e = getenv("SL_COLREDUCE_LPR");
-    return e ? atoi(e) : 0;
-  }();
+  const int forced_nw = (int)option(OPT_COLREDUCE_NW);  // sl_set_option("colreduce_nw", 4 / 8 / 16): tests walk every instance
   constexpr int EPP = 16 / (int)sizeof(T);
   const int64_t rows = t1 - t0;
   const int64_t L = B / x.per;
   bool aligned = true;
   for (int64_t l = 0; l < L; ++l) aligned = aligned && ((uintptr_t)x.ptr[l] & 15) == 0;
-  if (impl != 1 || !aligned || (F % EPP) != 0 || ((st_ * (int64_t)sizeof(T)) & 15) != 0 ||
+  if (!aligned || (F % EPP) != 0 || ((st_ * (int64_t)sizeof(T)) & 15) != 0 ||
       ((sb * (int64_t)sizeof(T)) & 15) != 0 || rows < 1)
     return false;
   // lanes per row: the widest chunk that wastes no lane, else the one that wastes least (ties: wider = fewer tasks)
@@ -1404,7 +1387,6 @@ bool launch_colreduce2(ProfScope& prof, const MultiSrc& x, int64_t B, int T_, in
     const double util = (double)pr / (double)(((pr + c - 1) / c) * c);
     if (util > best + 1e-9) best = util, lpr = c;
   }
-  if (forced_lpr == 64 || forced_lpr == 32 || forced_lpr == 16) lpr = forced_lpr;
   const int64_t cw = (int64_t)lpr * EPP, nchunk = (F + cw - 1) / cw, cus = num_cus();
   const int64_t nt_min_bytes = nt_min_bytes_();
   const int64_t per_b = (int64_t)T_ * F * (int64_t)sizeof(T), all = B * per_b;
@@ -1448,10 +1430,6 @@ bool launch_colreduce2(ProfScope& prof, const MultiSrc& x, int64_t B, int T_, in
   return true;
 }
 
-#ifdef SL_K2_DMA_LAB  // lab only (tools/k2_lab.py, profiles/r04_k2_lab.txt): K2 through LDS-DMA rings — measured, lost, not shipped
-#include "../../tools/native/colreduce_dma_lab.hpp"
-#endif
-
 template <typename T, int OP>
 void launch_colreduce(ProfScope& prof, const T* x, int64_t B, int T_, int64_t F, int64_t sb, int64_t st_, int t0, int t1,
                       float denom, uint16_t* cand, float* outf, hipStream_t st) {
@@ -1459,9 +1437,6 @@ void launch_colreduce(ProfScope& prof, const T* x, int64_t B, int T_, int64_t F,
   one.ptr[0] = x;
   one.per = B;
   if (launch_colreduce2<T, OP>(prof, one, B, T_, F, sb, st_, t0, t1, denom, cand, outf, st)) return;
-#ifdef SL_K2_DMA_LAB
-  if (launch_colreduce_dma<T, OP>(prof, x, B, T_, F, sb, st_, t0, t1, denom, cand, outf, st)) return;
-#endif
   int64_t blocks = B * ((F + 255) / 256);
   const int64_t cap = (int64_t)num_cus() * 8;
   if (blocks > cap) blocks = cap;
@@ -1473,10 +1448,7 @@ void launch_colreduce(ProfScope& prof, const T* x, int64_t B, int T_, int64_t F,
   if (bytes >= nt_min_bytes) tail_from = tail_bytes > 0 ? (bytes > tail_bytes ? (bytes - tail_bytes) / per_b * nchunk : 0) : INT64_MAX;
   // waves per task (they split the reduced axis): enough of them that a CU holds ~24 waves with 8 loads in flight each.
   // (B, 197, 768) at B = 256 is 768 tasks: 4-wave workgroups put 12 waves on a CU (5.4 TB/s cold), 8-wave ones 24.
-  static const int forced_nw = [] {
-    const char* e = getenv("SL_COLREDUCE_NW");
-    return e ? atoi(e) : 0;
-  }();
+  const int forced_nw = (int)option(OPT_COLREDUCE_NW);
   const int64_t tasks = B * nchunk, rows = t1 - t0, cus = num_cus();
   int nw = 4;
   // measured cold (tools/reduce_dtype_bench.py, SL_COLREDUCE_NW = 4 / 8 / 16): (256, 197, 768) fp32 5.52 / 5.63 / 5.46 TB/s,

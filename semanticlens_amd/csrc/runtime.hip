@@ -1,5 +1,9 @@
 // Error reporting + event-bracketed measurement for libsemanticlens_hip.so.
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "common.hpp"
@@ -18,6 +22,40 @@ void set_error(const char* fmt, ...) {
 int hip_fail(hipError_t e, const char* what) {
   set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
   return SL_E_HIP;
+}
+
+// ---- variant switches ---------------------------------------------------------------------------------------------------
+static const char* const kOptNames[OPT_COUNT] = {"g3_tile", "f32_tile", "g3_strip_off", "colreduce_nw"};
+static std::atomic<int64_t> g_opts[OPT_COUNT];
+static std::once_flag g_opts_once;
+
+static int opt_id(const char* name) {
+  for (int i = 0; i < OPT_COUNT; ++i)
+    if (name && strcmp(name, kOptNames[i]) == 0) return i;
+  return -1;
+}
+
+static void opts_from_env() {  // SL_OPTIONS="g3_tile=128,colreduce_nw=8": the same switches for a whole process (subprocess tests)
+  const char* e = getenv("SL_OPTIONS");
+  if (!e) return;
+  std::string all(e);
+  size_t pos = 0;
+  while (pos < all.size()) {
+    size_t end = all.find(',', pos);
+    if (end == std::string::npos) end = all.size();
+    const std::string item = all.substr(pos, end - pos);
+    const size_t eq = item.find('=');
+    if (eq != std::string::npos) {
+      const int id = opt_id(item.substr(0, eq).c_str());
+      if (id >= 0) g_opts[id].store(atoll(item.c_str() + eq + 1));
+    }
+    pos = end + 1;
+  }
+}
+
+int64_t option(int id) {
+  std::call_once(g_opts_once, opts_from_env);
+  return g_opts[id].load(std::memory_order_relaxed);
 }
 
 struct ProfRec {
@@ -55,6 +93,19 @@ using namespace sl;
 
 SL_API const char* sl_last_error(void) { return g_err; }
 SL_API int sl_abi_version(void) { return SL_ABI_VERSION; }
+
+SL_API int sl_set_option(const char* name, int64_t value) {
+  const int id = opt_id(name);
+  SL_REQUIRE(id >= 0, "sl_set_option: unknown option '%s' (g3_tile, f32_tile, g3_strip_off, colreduce_nw)", name ? name : "(null)");
+  (void)option(id);  // the environment is read first, once: an explicit call wins over it
+  g_opts[id].store(value);
+  return 0;
+}
+
+SL_API int64_t sl_get_option(const char* name) {
+  const int id = opt_id(name);
+  return id < 0 ? -1 : option(id);
+}
 
 SL_API int sl_device_count(void) {
   int n = 0;

@@ -199,11 +199,7 @@ SL_API int sl_clarity_multi(const float* const* h_d_Vs, const int64_t* h_Cs, int
     SL_REQUIRE(h_Cs[i] == 0 || (h_d_Vs[i] && h_d_outs[i]), "sl_clarity: null pointer");
     fast = fast && (((uintptr_t)h_d_Vs[i]) & 15) == 0;
   }
-  static const bool force_two_pass = [] {
-    const char* e = getenv("SL_CLARITY_IMPL");
-    return e && strcmp(e, "two_pass") == 0;
-  }();
-  if (!fast || force_two_pass) {  // odd widths / unaligned slabs: the two-pass kernel, layer by layer
+  if (!fast) {  // odd widths / unaligned slabs: the two-pass kernel, layer by layer
     for (int i = 0; i < L; ++i)
       if (h_Cs[i] > 0) {
         const int rc = clarity_two_pass(h_d_Vs[i], h_Cs[i], n, D, h_d_outs[i], st);
@@ -226,9 +222,15 @@ SL_API int sl_clarity_multi(const float* const* h_d_Vs, const int64_t* h_Cs, int
     if (total == 0) continue;
     src.start[src.n_layers] = total;
     ProfScope prof(SL_PROF_SCORES, st, (double)total * n * D * 4);
+    // one component per workgroup while the grid stays modest (the dispatcher then balances the CUs by itself); beyond that every
+    // workgroup takes the SAME number of components.  Round 5 capped the grid at 8 per CU: 2 880 components over 2 048 resident
+    // workgroups gave 832 of them two components and the rest one — a second, 40 %-full round (25 us where 118 MB need 21)
     int64_t blocks = total;
-    const int64_t cap = (int64_t)num_cus() * 8;
-    if (blocks > cap) blocks = cap;
+    const int64_t cap = (int64_t)num_cus() * 64;
+    if (blocks > cap) {
+      const int64_t per = (total + cap - 1) / cap;
+      blocks = (total + per - 1) / per;
+    }
     const int ppl = (int)((D / 4 + 63) / 64);
 #define SL_CLARITY(P_)                                                                                                     \
   case P_:                                                                                                                  \

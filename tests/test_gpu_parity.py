@@ -946,11 +946,11 @@ torch.save(outs, sys.argv[1])
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for tile in ("128", "256", "512", "8", "160", "64", "1280"):
+    for tile in ("128", "256", "8", "160", "64", "1280"):
         out = tmp_path / f"g3_{tile}.pt"
-        subprocess.run([sys.executable, "-c", code, str(out), root], check=True, env=dict(os.environ, SL_G3_TILE=tile))
+        subprocess.run([sys.executable, "-c", code, str(out), root], check=True, env=dict(os.environ, SL_OPTIONS=f"g3_tile={tile}"))
         res[tile] = torch.load(out)
-    for other in ("256", "512", "8", "160", "64", "1280"):
+    for other in ("256", "8", "160", "64", "1280"):
         for a, b in zip(res["128"], res[other]):
             assert torch.equal(a, b), (other, tuple(a.shape))
     # the fp32-MFMA mode has two tile variants too (128 x 128 register-staged, 256 x 256 8-phase): same bits
@@ -958,7 +958,7 @@ torch.save(outs, sys.argv[1])
     for tile in ("128", "8"):
         out = tmp_path / f"f32_{tile}.pt"
         subprocess.run([sys.executable, "-c", code, str(out), root], check=True,
-                       env=dict(os.environ, SL_GEMM_MODE="f32", SL_F32_TILE=tile))
+                       env=dict(os.environ, SL_GEMM_MODE="f32", SL_OPTIONS=f"f32_tile={tile}"))
         f32[tile] = torch.load(out)
     for a, b in zip(f32["128"], f32["8"]):
         assert torch.equal(a, b), ("f32", tuple(a.shape))
@@ -996,7 +996,7 @@ torch.save(outs, sys.argv[1])
     res = {}
     for tile in ("128", "256", "8", "160", "64", "1280"):
         out = tmp_path / f"lin_{tile}.pt"
-        subprocess.run([sys.executable, "-c", code, str(out), root], check=True, env=dict(os.environ, SL_G3_TILE=tile))
+        subprocess.run([sys.executable, "-c", code, str(out), root], check=True, env=dict(os.environ, SL_OPTIONS=f"g3_tile={tile}"))
         res[tile] = torch.load(out)
     for other in ("256", "8", "160", "64", "1280"):
         for i, (a, b) in enumerate(zip(res["128"], res[other])):
@@ -1009,7 +1009,7 @@ torch.save(outs, sys.argv[1])
 def test_column_strip_split_keeps_every_bit(tmp_path):
     """A GEMM whose last column tile is partial may be cut at the last full tile (gemm_bf16x3.hpp `strip_split_columns`: the big
     kernel on the first 256 n columns, the strip's own kernel on the rest with the epilogue shifted): same bits as the uncut GEMM
-    (`SL_G3_STRIP=0`) for every epilogue — plain, cosine routing over several layers, bias, residual in place, GELU -> split output,
+    (option `g3_strip_off`) for every epilogue — plain, cosine routing over several layers, bias, residual in place, GELU -> split output,
     scattered rows + positional table — at shapes the cost model does cut (so400m's N = 1152 and 4304 at 64 images, 3 x 257 layers)."""
     import os
     import subprocess
@@ -1046,7 +1046,7 @@ torch.save(outs, sys.argv[1])
     res = {}
     for strip in ("1", "0"):
         out = tmp_path / f"strip_{strip}.pt"
-        subprocess.run([sys.executable, "-c", code, str(out), root], check=True, env=dict(os.environ, SL_G3_STRIP=strip))
+        subprocess.run([sys.executable, "-c", code, str(out), root], check=True, env=dict(os.environ, SL_OPTIONS=f"g3_strip_off={1 - int(strip)}"))
         res[strip] = torch.load(out)
     assert len(res["1"]) == len(res["0"]) >= 15
     for i, (a, b) in enumerate(zip(res["1"], res["0"])):

@@ -159,7 +159,7 @@ def test_reduce_policy_tuner_settles_per_layer_and_changes_no_result(monkeypatch
 def test_colreduce2_fuzz_against_the_oracle(seed, nw):
     """`tools/fuzz_k2.py` as a test: 150 random (B, T, F) token tensors and channels_last maps per seed — F from one 16-byte piece to
     4 352 components, 1-700 rows, fp32 / fp16 / bf16, every aggregator, planted NaN / +-inf / -0.0 — through colreduce2 (every LPR /
-    wave-count variant; `SL_COLREDUCE_NW=8` forces the eight-wave instances) against the oracle, synchronising after every call."""
+    wave-count variant; `SL_OPTIONS=colreduce_nw=8` forces the eight-wave instances) against the oracle, synchronising after every call."""
     import os
     import subprocess
     import sys
@@ -167,7 +167,7 @@ def test_colreduce2_fuzz_against_the_oracle(seed, nw):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
     if nw:
-        env["SL_COLREDUCE_NW"] = nw
+        env["SL_OPTIONS"] = f"colreduce_nw={nw}"
     res = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_k2.py"), str(seed), "150"], env=env, capture_output=True, text=True,
                          timeout=600, cwd=root)
     assert res.returncode == 0 and "fuzz_k2 ok: 150 cases" in res.stdout, (res.stdout[-600:], res.stderr[-1500:])

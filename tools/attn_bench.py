@@ -1,4 +1,4 @@
-"""Time sl_attention at the CLIP tower shapes (SL_ATTENTION_IMPL=valu selects the VALU kernel)."""
+"""Time sl_attention at the CLIP tower shapes (the VALU kernel of round 1 left the library in round 6: tools/native/attention_valu_lab.hpp)."""
 import sys
 from pathlib import Path
 

@@ -81,4 +81,4 @@ for it in range(cases):
         else:
             fin = np.isfinite(w2)
             assert np.array_equal(np.isnan(g2), np.isnan(w2)) and np.allclose(g2[fin], w2[fin], rtol=1e-2 if dt != torch.float32 else 2e-5, atol=1e-5), ("conv mean", it)
-print("fuzz_k2 ok:", cases, "cases, seed", seed, "SL_COLREDUCE_NW =", os.environ.get("SL_COLREDUCE_NW"))
+print("fuzz_k2 ok:", cases, "cases, seed", seed, "SL_OPTIONS =", os.environ.get("SL_OPTIONS"))

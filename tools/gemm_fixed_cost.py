@@ -1,5 +1,5 @@
 """What a GEMM launch costs besides its k loop: (12 800 x 768) outputs at K = 32 .. 3072, bare epilogue (fp32 stores), per
-dispatch from sl_prof (HIP events stamped by the dispatch itself).  SL_G3_TILE selects the kernel."""
+dispatch from sl_prof (HIP events stamped by the dispatch itself).  SL_OPTIONS=g3_tile=<n> selects the kernel."""
 import sys
 from pathlib import Path
 

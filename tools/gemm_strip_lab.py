@@ -1,6 +1,6 @@
 """What a column-strip split of the N = 1152 GEMMs (so400m o-proj / fc2: 4.5 column tiles of 256) could buy: times of the full GEMM,
-of its first 1024 columns and of the 128-column remainder, per tile variant (SL_G3_TILE is read once per process: run once per value).
-    for t in 0 8 256 128 1280 160; do SL_G3_TILE=$t python tools/gemm_strip_lab.py; done"""
+of its first 1024 columns and of the 128-column remainder, per tile variant (option g3_tile, here through SL_OPTIONS: run once per value).
+    for t in 0 8 256 128 1280 160; do SL_OPTIONS=g3_tile=$t python tools/gemm_strip_lab.py; done"""
 import os
 import sys
 from pathlib import Path
@@ -28,7 +28,7 @@ def timed(fn, reps=20):
     return ms / max(n, 1) * 1e3
 
 
-tile = os.environ.get("SL_G3_TILE", "auto")
+tile = os.environ.get("SL_OPTIONS", "auto")
 for M in (16384, 65536):
     for K in (1152, 4304):
         x = N.Split.of(torch.randn(M, K, device=DEV, generator=g))

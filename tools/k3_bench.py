@@ -2,7 +2,7 @@
 then time `sl_actmax_update` per launch (HIP events around 200 launches on one stream).
 
     python tools/k3_bench.py            # fuzz + timing with the default implementation (wave per row)
-    SL_K3_ATEN_IMPL=lane python tools/k3_bench.py --no-fuzz     # the round-4 kernel (one lane per row), timing only
+    (SL_K3_ATEN_IMPL=lane, the round-4 kernel as an A/B, was a switch of rounds 4-5: profiles/r05_k3_lane.txt)
 """
 import os
 import sys

@@ -11,6 +11,7 @@
 #include <random>
 #include <vector>
 #include "gemm_bf16x3.hpp"
+#include "../../tools/native/gemm3_pingpong_lab.hpp"
 #include "gemm_f32.hpp"
 
 namespace sl {
