@@ -437,13 +437,23 @@ def cpu_baseline(args, model_cpu, fm_cpu):
                 h.remove()
         return n / dt, dt, agg_s[0]
 
+    def job_b(b_, threads_):
+        nonlocal B
+        saved = B
+        B = b_
+        try:
+            return job(b_, threads_, warm=False)
+        finally:
+            B = saved
+
     threads = best_t
     n = max(B, (args.cpu_images // B) * B)
     rate, dt, agg_s = job(n, threads)
     # every core of the box, the same job on ONE batch (SURVEY §8d planned "all host cores"; on these boxes one thread per logical CPU is
     # an order of magnitude slower than the best count, so its sample is kept to one batch; pools are warm from the thread probe)
+    B_all = 32  # (64 images took 80 s with 256 threads on the round's first box)
     if all_cores != threads:
-        rate_all, dt_all, _ = job(B, all_cores, warm=False)
+        rate_all, dt_all, _ = job_b(B_all, all_cores)
         torch.set_num_threads(threads)
         oracle.set_threads(threads)
     else:
@@ -457,7 +467,8 @@ def cpu_baseline(args, model_cpu, fm_cpu):
         # `host_cores` = what the box has (logical CPUs / CPUs this process may run on).  Best count and all cores side by side:
         "value": rate, "unit": "images/s", "cores": threads, "threads": threads,
         "all_cores": {"value": rate_all, "unit": "images/s", "cores": all_cores,
-                      "sample": f"{B} images (one batch), the same job, {dt_all:.1f} s", "forward_images_per_s": thread_probe.get(all_cores)},
+                      "sample": f"{B_all if all_cores != threads else n} images (one batch), the same job, {dt_all:.1f} s",
+                      "forward_images_per_s": thread_probe.get(all_cores)},
         "host_cores": os.cpu_count(), "host_cores_affinity": affinity, "kind": "port",
         "sample": f"{n} synthetic images (batch {B}), same models/layers/k, torch-CPU forward + oracle collect "
                   f"(ATen tie order) + CPU CLIP encode + gather; {dt:.1f} s",
@@ -1546,7 +1557,7 @@ def main():
             dev, fm, args, model_h, LAYERS, aggregators.aggregate_conv_max,
             "rowreduce_h (K1 on fp16 NCHW activations: 16-byte pieces of 8 elements, fp32 compare, bf16 candidates)",
             "configs[1] with the probed ResNet-50 in fp16 (model.half(), fp16 inputs): layer2-4 activations are fp16, "
-            "1 404 928 B/image", steps=min(n_batches, 16), B=B, cast=torch.float16)
+            "1 404 928 B/image", steps=min(n_batches, 16), B=B, cast=torch.float16, traffic_key="half_precision_model")
         del model_h
     line.update(multi)
     if single and not sharded and not args.no_tokens_leg:

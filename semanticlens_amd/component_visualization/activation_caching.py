@@ -487,6 +487,9 @@ class ActMaxCache(ActCache):
             return
         group = self._groups[gid]
         group["layers"] = [n for n in group["layers"] if n != layer_name]
+        if any(q[0] in group["layers"] or q[0] == layer_name for q in self._k3_queue):
+            self._flush_k3()  # queued merges still read the (L, B, C) candidate buffers that are dropped next
+        group["cand"] = {}  # sized for the old member count
         if len(group["layers"]) < 2:
             for n in group["layers"]:
                 self._group_of.pop(n, None)
@@ -533,7 +536,7 @@ class ActMaxCache(ActCache):
                 self.cache[name].collect(tensor, nat, start, site=(id(module), name))
             return
         cand = group["cand"].get(B)
-        if cand is None or cand.device != x0.device:
+        if cand is None or cand.device != x0.device or cand.shape[0] != len(names):  # (a member may have left the group)
             cand = group["cand"][B] = torch.empty((len(names), B, C), dtype=torch.bfloat16, device=x0.device)
         if any(q[0] in names for q in self._k3_queue):  # merges of an earlier forward still read this candidate buffer
             self._flush_k3()

@@ -2,6 +2,7 @@
 
   python tools/prof_summarize.py trace  <dir> <out.csv>   # per-kernel count / total / avg / min / max (ns)
   python tools/prof_summarize.py pmc    <dir> <out.csv>   # per-kernel, per-counter mean value per dispatch
+  python tools/prof_summarize.py context <dir> <out.txt> <substring>   # where in the kernel stream a kernel runs: its neighbours
 """
 import csv
 import glob
@@ -46,5 +47,35 @@ def pmc(d, out):
             w.writerow([k, g, c, len(v), sum(v) / len(v), min(v), max(v)])
 
 
+def context(d, out, pattern):
+    """Occurrences of kernels whose name contains `pattern`, in time order, each with the three kernels before and after it,
+    its grid and its position in the run (fraction of the trace's span) — enough to name the leg / layer that launches it."""
+    files = glob.glob(f"{d}/**/*kernel_trace.csv", recursive=True)
+    assert files, f"no kernel_trace.csv under {d}"
+    rows = []
+    for f in files:
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                rows.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), short(row["Kernel_Name"])[:110],
+                             row.get("Grid_Size_X", row.get("Grid_Size", "")), row.get("Workgroup_Size_X", row.get("Workgroup_Size", ""))))
+    rows.sort()
+    t0, t1 = rows[0][0], rows[-1][1]
+    hits = [i for i, r in enumerate(rows) if pattern in r[2]]
+    with open(out, "w") as fh:
+        fh.write(f"{len(hits)} launches of *{pattern}* among {len(rows)} kernels; total {sum(rows[i][1] - rows[i][0] for i in hits) / 1e6:.2f} ms "
+                 f"of {sum(r[1] - r[0] for r in rows) / 1e6:.2f} ms of kernel time\n")
+        # distinct (grid, workgroup) shapes and where in the run they sit
+        shapes = defaultdict(list)
+        for i in hits:
+            shapes[(rows[i][3], rows[i][4])].append(i)
+        for (g, wg), idx in sorted(shapes.items(), key=lambda kv: -len(kv[1])):
+            durs = [rows[i][1] - rows[i][0] for i in idx]
+            pos = [(rows[i][0] - t0) / max(1, t1 - t0) for i in idx]
+            fh.write(f"grid {g} wg {wg}: {len(idx)} launches, avg {sum(durs) / len(durs) / 1e3:.1f} us, run position {min(pos):.3f}..{max(pos):.3f}\n")
+            i = idx[0]
+            for j in range(max(0, i - 3), min(len(rows), i + 4)):
+                fh.write(f"   {'>>' if j == i else '  '} {rows[j][2]}  [{(rows[j][1] - rows[j][0]) / 1e3:.1f} us]\n")
+
+
 if __name__ == "__main__":
-    {"trace": trace, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])
+    {"trace": trace, "pmc": pmc, "context": context}[sys.argv[1]](*sys.argv[2:])
