@@ -52,7 +52,7 @@ struct ProfScope {
 
 // ---- variant switches (include/semanticlens_amd.h sl_set_option): which of several bit-identical kernel variants a dispatcher
 // picks.  0 = the dispatcher's own rule.  Read on every dispatch (no latching): a test can force one variant after another in-process.
-enum { OPT_G3_TILE = 0, OPT_F32_TILE, OPT_G3_STRIP_OFF, OPT_COLREDUCE_NW, OPT_ATTN_SPLIT, OPT_COUNT };
+enum { OPT_G3_TILE = 0, OPT_F32_TILE, OPT_G3_STRIP_OFF, OPT_COLREDUCE_NW, OPT_COUNT };
 int64_t option(int id);
 
 inline int num_cus() {

@@ -436,22 +436,16 @@ __device__ __forceinline__ float exp_neg(float x) {
 // layer as shipped, 251 with the key-tile loop compiled out (staging + output), 417 with the K / V global loads compiled out.
 // Staging and MFMAs do not overlap: the 97 KB of LDS and 216 registers keep ONE workgroup per CU.  Tried and dropped: pulling the
 // next chunk's (and the next workgroup's first chunk's) lines into L2 with LDS-DMA touches into a dummy area — 605 -> 648 us.
-// `qsplit` workgroups share one (image, head): workgroup part p of it owns query tiles [p * per, (p + 1) * per), per = ceil(tiles /
-// qsplit), and stages K / V for itself in chunks of at most `kc_max` keys.  qsplit = 1, kc_max = 128: one workgroup per head (rounds
-// 3-5).  Round 6, long sequences: four-wave workgroups of ONE round each (qsplit = tiles / 4) with 64-key chunks need 50 KB of LDS,
-// so TWO of them share a CU (their 216 registers allow two waves per SIMD either way) and one stages while the other multiplies —
-// the overlap that one 97-KB workgroup per CU could not have.
 template <int D, int MAXW>
 __global__ __launch_bounds__(64 * MAXW, (D <= 96 ? 2 : 1)) void attention_bf16x3_kernel(const float* __restrict__ qkv, int T, int H, int causal, float scale,
-                                                                float* __restrict__ out, uint16_t* __restrict__ osp, int kc_max,
-                                                                int qsplit) {
+                                                                float* __restrict__ out, uint16_t* __restrict__ osp) {
   constexpr int kDh = D;
   constexpr int DP = attn3_dp(D), NS = DP / 16;  // k-steps of the score product
   constexpr int NT = (D + 31) / 32;              // output tiles of 32 dims
   constexpr int KROW = DP * 2 + 16;              // bytes per K row (one plane)
   extern __shared__ __align__(16) unsigned char smem3[];
   const int Tp = (T + 31) & ~31;
-  const int KC = Tp < kc_max ? Tp : kc_max;
+  const int KC = Tp < attn3_kc() ? Tp : attn3_kc();
   const int VROW = KC * 2 + 16;  // bytes per V^T row (one plane)
   unsigned char* sKh = smem3;
   unsigned char* sKl = sKh + (size_t)KC * KROW;
@@ -461,15 +455,11 @@ __global__ __launch_bounds__(64 * MAXW, (D <= 96 ? 2 : 1)) void attention_bf16x3
   const int nwaves = blockDim.x >> 6;
   const int w = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
-  const int head_idx = blockIdx.x / qsplit, part = blockIdx.x % qsplit;
-  const int64_t b = head_idx / H;
-  const int h = head_idx % H;
+  const int64_t b = blockIdx.x / H;
+  const int h = blockIdx.x % H;
   const int64_t ld = 3ll * H * kDh;
   const float* base = qkv + b * T * ld + h * kDh;
-  const int nqt_all = Tp / 32, kct = KC / 32;
-  const int per = (nqt_all + qsplit - 1) / qsplit;
-  const int qt_begin = part * per;
-  const int nqt = qt_begin + per < nqt_all ? qt_begin + per : nqt_all;  // one past this workgroup's last query tile
+  const int nqt = Tp / 32, kct = KC / 32;
   int loaded = -1;
   auto split8 = [](const float* v, abf16x8& hi, abf16x8& lo) __attribute__((always_inline)) {
 #pragma unroll
@@ -479,7 +469,7 @@ __global__ __launch_bounds__(64 * MAXW, (D <= 96 ? 2 : 1)) void attention_bf16x3
       lo[j] = (__bf16)(v[j] - (float)hb);
     }
   };
-  for (int qt0 = qt_begin; qt0 < nqt; qt0 += nwaves) {
+  for (int qt0 = 0; qt0 < nqt; qt0 += nwaves) {
     const int qt = qt0 + w;
     const bool active = qt < nqt;
     const int q = qt * 32 + li;
@@ -506,8 +496,8 @@ __global__ __launch_bounds__(64 * MAXW, (D <= 96 ? 2 : 1)) void attention_bf16x3
       for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
     float m = -__builtin_huge_valf(), l = 0.f;
     const int round_last = qt0 + nwaves < nqt ? qt0 + nwaves : nqt;
-    const int nkt_round = causal ? round_last : nqt_all;
-    const int nkt = !active ? 0 : (causal ? qt + 1 : nqt_all);
+    const int nkt_round = causal ? round_last : nqt;
+    const int nkt = !active ? 0 : (causal ? qt + 1 : nqt);
     for (int kc0 = 0; kc0 < nkt_round; kc0 += kct) {
       if (kc0 != loaded) {
         if (loaded >= 0) __syncthreads();
@@ -934,41 +924,22 @@ template <int D>
 static int launch_attention_bf16x3(const float* qkv, int64_t B, int64_t T, int64_t H, int causal, float* out, uint16_t* osp,
                                    hipStream_t st) {
   const int64_t Tp = (T + 31) & ~(int64_t)31;
+  const int64_t kc = Tp < attn3_kc() ? Tp : attn3_kc();
   const int NT = (D + 31) / 32;
-  const int nqt = (int)(Tp / 32);
-  auto lds_bytes = [&](int64_t kc_max, int waves) {
-    const int64_t kc = Tp < kc_max ? Tp : kc_max;
-    const size_t planes = 2 * (size_t)kc * (attn3_dp(D) * 2 + 16) + 2 * (size_t)(NT * 32) * (kc * 2 + 16);
-    const size_t stage = (size_t)waves * 32 * (D * 4 + 16);  // the output tiles pass through the same LDS
-    return planes > stage ? planes : stage;
-  };
+  const size_t smem = 2 * (size_t)kc * (attn3_dp(D) * 2 + 16) + 2 * (size_t)(NT * 32) * (kc * 2 + 16);
   const float scale = (float)(1.0 / sqrt((double)D));
-  const int mode = (int)option(OPT_ATTN_SPLIT);  // lab (round 6): 1 = one workgroup per head as in rounds 3-5, 2 = force the split
-  // Long sequences (more than four query tiles): one four-wave workgroup per ROUND of four query tiles, 64-key chunks — two workgroups
-  // per CU, one staging while the other multiplies.  Non-causal only: a causal head's rounds need different key ranges, and the text
-  // towers' sequences (64-77 tokens) fit one round anyway.
-  const bool split = mode == 2 || (mode != 1 && nqt > 4 && !causal && D <= 96);
-  if (split && nqt > 4) {
-    const int qsplit = (nqt + 3) / 4;
-    const size_t smem = lds_bytes(64, 4);
-    if (smem > 64 * 1024)
-      SL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_bf16x3_kernel<D, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL((attention_bf16x3_kernel<D, 4>), dim3((unsigned)(B * H * qsplit)), dim3(256), smem, st, qkv, (int)T, (int)H, causal,
-                       scale, out, osp, 64, qsplit);
-  } else if (nqt > 4 && D <= 96) {  // head_dim 104 / 128 would spill at 256 registers per wave
-    const int waves = nqt < 8 ? nqt : 8;
-    const size_t smem = lds_bytes(attn3_kc(), waves);
+  if (Tp / 32 > 4 && D <= 96) {  // head_dim 104 / 128 would spill at 256 registers per wave
+    const int waves = (int)(Tp / 32 < 8 ? Tp / 32 : 8);
     if (smem > 64 * 1024)
       SL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_bf16x3_kernel<D, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL((attention_bf16x3_kernel<D, 8>), dim3((unsigned)(B * H)), dim3(64 * waves), smem, st, qkv, (int)T, (int)H, causal,
-                       scale, out, osp, attn3_kc(), 1);
+                       scale, out, osp);
   } else {
-    const int waves = nqt < 4 ? nqt : 4;
-    const size_t smem = lds_bytes(attn3_kc(), waves);
+    const int waves = (int)(Tp / 32 < 4 ? Tp / 32 : 4);
     if (smem > 64 * 1024)
       SL_CHECK_HIP(hipFuncSetAttribute((const void*)attention_bf16x3_kernel<D, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL((attention_bf16x3_kernel<D, 4>), dim3((unsigned)(B * H)), dim3(64 * waves), smem, st, qkv, (int)T, (int)H, causal,
-                       scale, out, osp, attn3_kc(), 1);
+                       scale, out, osp);
   }
   SL_CHECK_HIP(hipGetLastError());
   return 0;

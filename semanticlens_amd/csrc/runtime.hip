@@ -25,7 +25,7 @@ int hip_fail(hipError_t e, const char* what) {
 }
 
 // ---- variant switches ---------------------------------------------------------------------------------------------------
-static const char* const kOptNames[OPT_COUNT] = {"g3_tile", "f32_tile", "g3_strip_off", "colreduce_nw", "attn_split"};
+static const char* const kOptNames[OPT_COUNT] = {"g3_tile", "f32_tile", "g3_strip_off", "colreduce_nw"};
 static std::atomic<int64_t> g_opts[OPT_COUNT];
 static std::once_flag g_opts_once;
 
