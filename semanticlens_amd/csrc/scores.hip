@@ -222,15 +222,13 @@ SL_API int sl_clarity_multi(const float* const* h_d_Vs, const int64_t* h_Cs, int
     if (total == 0) continue;
     src.start[src.n_layers] = total;
     ProfScope prof(SL_PROF_SCORES, st, (double)total * n * D * 4);
-    // one component per workgroup while the grid stays modest (the dispatcher then balances the CUs by itself); beyond that every
-    // workgroup takes the SAME number of components.  Round 5 capped the grid at 8 per CU: 2 880 components over 2 048 resident
-    // workgroups gave 832 of them two components and the rest one — a second, 40 %-full round (25 us where 118 MB need 21)
+    // grid (tools/clarity_lab.py, round 6): up to two rounds of resident workgroups (8 per CU) the components are walked by a
+    // resident grid (2 880 components x 40 KB: 25.5 us against 27.1 with one workgroup per component); beyond that one workgroup per
+    // component and the dispatcher balances (9 216 x 92 KB: 139.6 us = 0.76 of 8 TB/s against 150.4).  Fetching a component ahead
+    // of the one being reduced (two register buffers, two waves per SIMD) lost at both sizes: 31.9 / 148.8 us.
     int64_t blocks = total;
-    const int64_t cap = (int64_t)num_cus() * 64;
-    if (blocks > cap) {
-      const int64_t per = (total + cap - 1) / cap;
-      blocks = (total + per - 1) / per;
-    }
+    const int64_t cap = (int64_t)num_cus() * 8;
+    if (blocks > cap && blocks <= 2 * cap) blocks = cap;
     const int ppl = (int)((D / 4 + 63) / 64);
 #define SL_CLARITY(P_)                                                                                                     \
   case P_:                                                                                                                  \
