@@ -86,6 +86,7 @@ def parse():
     ap.add_argument("--pool-batches", type=int, default=0,
                     help="keep only this many distinct batches resident and cycle through them (ids stay unique); 0 = every "
                          "batch distinct.  For dataset sizes whose uint8 pixels exceed HBM (1.28 M images = 193 GB)")
+    ap.add_argument("--leg-steps", type=int, default=0, help="batches of the configs[3] / configs[4] collect legs (default 8 / 4; tests: fewer)")
     ap.add_argument("--no-self-check", action="store_true")
     ap.add_argument("--quick", action="store_true", help="headline + self-check only: none of the extra legs (tests)")
     ap.add_argument("--no-tokens-leg", action="store_true", help="skip the configs[3] leg (ViT-B/16 collect + so400m embed + 10k-prompt probing)")
@@ -381,7 +382,14 @@ def cpu_baseline(args, model_cpu, fm_cpu):
     with torch.no_grad():
         for t in cands:
             torch.set_num_threads(t)
+            t0 = time.perf_counter()
             model_cpu(probe[:16])
+            first = (time.perf_counter() - t0) / 16  # seconds per image of the first (16-image) call
+            if first > 3.0 * best_dt / 64:
+                # hopeless already (one thread per logical CPU of a 256-CPU box runs 15-20x below the best count: two more 64-image
+                # forwards there cost 90 s of the leg): its first call is its figure
+                thread_probe[t] = 1.0 / first
+                continue
             dts = []
             for _ in range(2):
                 t0 = time.perf_counter()
@@ -451,7 +459,7 @@ def cpu_baseline(args, model_cpu, fm_cpu):
     rate, dt, agg_s = job(n, threads)
     # every core of the box, the same job on ONE batch (SURVEY §8d planned "all host cores"; on these boxes one thread per logical CPU is
     # an order of magnitude slower than the best count, so its sample is kept to one batch; pools are warm from the thread probe)
-    B_all = 32  # (64 images took 80 s with 256 threads on the round's first box)
+    B_all = 16  # (64 images took 80 s with 256 threads on the round's first box)
     if all_cores != threads:
         rate_all, dt_all, _ = job_b(B_all, all_cores)
         torch.set_num_threads(threads)
@@ -720,7 +728,7 @@ def config3_leg(dev, args):
         "one K3 launch; a collector's first batch runs layer by layer)",
         "BASELINE configs[3], full geometry: ViT-B/16 (random init) probed model, all 12 encoder blocks (B,197,768) fp32, "
         "aggregate_transformer_max, 7 262 208 B/image; embed = NativeSigLip at the SigLIP-so400m geometry (27 x 1152, 16 heads "
-        "of 72, MLP 4304, patch 14 -> 256 tokens, D = 1152), on the same stream", steps=8, B=B, check_n=B, overlap=False, keep_db=db,
+        "of 72, MLP 4304, patch 14 -> 256 tokens, D = 1152), on the same stream", steps=args.leg_steps or 8, B=B, check_n=B, overlap=False, keep_db=db,
         traffic_key="config3_full")
     assert all(v.shape == (768, args.k, 1152) for v in db.values()) and len(db) == 12
     agg_db = {name: v.mean(1) for name, v in db.items()}  # what a user hands text_probing (README: `concept_db[layer].mean(1)`)
@@ -814,7 +822,7 @@ def _config4_leg(dev, fm, args):
         "colreduce2 (K1, channels_last fp32 stage outputs: (B, S, C) with S = 3136 / 784 / 196 / 49, C = 192 / 384 / 768 / 1536)",
         "BASELINE configs[4] collect stage: ConvNeXt-L (random init) probed model, stages.0-3 outputs fp32 NCHW, aggregate_conv_max, "
         "4 515 840 B/image (the stage outputs arrive channels_last — the residual add takes its permuted branch's layout — so K1 "
-        "runs its component-contiguous kernel); embed = the headline's CLIP ViT-B/32, on the same stream", steps=4, B=B, check_n=B,
+        "runs its component-contiguous kernel); embed = the headline's CLIP ViT-B/32, on the same stream", steps=args.leg_steps or 4, B=B, check_n=B,
         keep_db=db, overlap=False, traffic_key="config4_full")
     widths = (192, 384, 768, 1536)
     assert all(db[n].shape == (c, args.k, 512) for n, c in zip(layers, widths))
@@ -826,7 +834,7 @@ def _config4_leg(dev, fm, args):
         dev, fm, args, model_nchw, layers, aggregators.aggregate_conv_max,
         "rowreduce (K1, NCHW-contiguous fp32 stage outputs: rows of S = 3136 / 784 / 196 / 49 floats)",
         "the same ConvNeXt-L weights with every block's residual sum written NCHW-contiguous (one transposing add per block)",
-        steps=4, B=B, check_n=B, overlap=False)
+        steps=args.leg_steps or 4, B=B, check_n=B, overlap=False)
     out["nchw_block_outputs"] = {k_: nchw[k_] for k_ in ("workload", "images_per_s", "roofline", "reduce_cache_policy") if k_ in nchw}
     out["nchw_block_outputs"]["self_check"] = nchw.get("self_check")
     del model_nchw, nchw

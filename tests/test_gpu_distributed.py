@@ -144,7 +144,7 @@ def test_bench_two_ranks_sharing_one_gpu_over_gloo():
     configs[3] / configs[4] collect legs with the cross-rank merge, text_probing with the query rows sharded, the scores with the
     component axis sharded, the CPU baseline (rank 0) and the oracle / single-process parity of each."""
     line = _bench_line({"SL_BENCH_BACKEND": "gloo", "SL_BENCH_SHARE_GPU": "1"}, ["--steps", "3", "--batches-per-step", "2", "--warmup", "1", "--batch", "64", "--min-warmup-seconds", "0.3",
-                                                                                 "--strong-images", "1500", "--strong-pool-batches", "4", "--cpu-images", "64"], 2)
+                                                                                 "--strong-images", "1500", "--strong-pool-batches", "4", "--cpu-images", "64", "--leg-steps", "2"], 2)
     assert line["strong_scaling"]["images"] == 1500 and line["strong_scaling"]["tie_mode"] == "total"  # (the default is the 1.28 M-image job: 200 s here)
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
     assert line["config"]["images_total"] == 2 * 3 * 2 * 64 and line["value"] > 0
@@ -155,9 +155,9 @@ def test_bench_two_ranks_sharing_one_gpu_over_gloo():
     assert tp["sharded_check"]["equals_single_process_bitwise"] and tp["sharded_check"]["max_abs_diff_vs_oracle_64_queries"] < 1e-4
     assert tp["from_prompts"]["n_gpus"] == 2 and tp["from_prompts"]["queries_per_s"] > 0
     c3, c4 = line["config3_full"], line["config4_full"]
-    assert c3["n_gpus"] == 2 and c3["images"] == 2 * 8 * 64 and c3["self_check"] == "ok" and c3["roofline"]["frac"] > 0
+    assert c3["n_gpus"] == 2 and c3["images"] == 2 * 2 * 64 and c3["self_check"] == "ok" and c3["roofline"]["frac"] > 0
     assert c3["text_probing_from_prompts"]["n_gpus"] == 2 and c3["text_probing_from_prompts"]["max_abs_diff_vs_oracle_64_queries"] < 1e-4
-    assert c4["n_gpus"] == 2 and c4["images"] == 2 * 4 * 64 and c4["self_check"] == "ok"
+    assert c4["n_gpus"] == 2 and c4["images"] == 2 * 2 * 64 and c4["self_check"] == "ok"
     assert c4["relevance_visualizer"]["n_gpus"] == 2 and c4["relevance_visualizer"]["images"] == 256
     sc = c4["scores_full_db"]
     assert sc["n_gpus"] == 2 and sc["sharded_equals_single_process"] is True and all(v < 1e-4 for v in sc["max_abs_diff_vs_oracle"].values())
