@@ -14,7 +14,7 @@ def load(path, counter):
     rows = []
     with open(path, newline="") as fh:
         for r in csv.DictReader(fh):
-            if r["Counter_Name"] == counter and "sl::" in r["Kernel_Name"] and "reduce" in r["Kernel_Name"]:
+            if r["Counter_Name"] == counter and "reduce" in r["Kernel_Name"] and "sl" in r["Kernel_Name"]:  # (_Float16 instances stay mangled)
                 rows.append((r["Kernel_Name"], r.get("Grid_Size", ""), float(r["MeanValue"])))
     return rows
 
@@ -27,7 +27,7 @@ def main(fetch_csv, write_csv):
         rd = 2.0 * kib * 1024.0
         shape, algo = min(SHAPES.items(), key=lambda kv: abs(kv[1] - rd))
         wr = write.get((name, grid), 0.0) * 1024.0
-        out[shape] = {"kernel": name.split("(")[0], "hbm_read_bytes": rd, "hbm_write_bytes": wr, "algorithmic_bytes": algo,
+        out[shape] = {"kernel": name.split("(")[0][:90], "hbm_read_bytes": rd, "hbm_write_bytes": wr, "algorithmic_bytes": algo,
                       "ratio": (rd + wr) / algo}
         tot_rd += rd + wr
         tot_algo += algo
