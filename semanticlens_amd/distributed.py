@@ -453,7 +453,7 @@ def eval_sharded(score_fn, concept_db, group=None):
         return one(concept_db)
     keys = list(concept_db)
     if len(keys) < 2 or not all(isinstance(concept_db[k], torch.Tensor) and concept_db[k].ndim == 3 and concept_db[k].shape[0] > 0
-                                and concept_db[k].is_cuda for k in keys):
+                                and concept_db[k].device == concept_db[keys[0]].device for k in keys):
         return {k: one(v) for k, v in concept_db.items()}
     from semanticlens_amd.scores import clarity_score
 

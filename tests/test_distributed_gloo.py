@@ -147,10 +147,31 @@ def _analysis_worker(rank, world, port, out_dir):
             out = sld.text_probing_sharded(fm, queries, db, templates=tpl, batch_size=4)
             np.savez(os.path.join(out_dir, f"probe_{'tpl' if tpl else 'plain'}_rank{rank}.npz"), **{k: v.numpy() for k, v in out.items()})
 
+        # resident query embeddings (bench.py's N > 1 text_probing leg): rows sharded, gathered or kept per rank
+        emb = torch.from_numpy(np.random.RandomState(8).randn(5, 16).astype(np.float32))
+        lo, hi = sld.shard_range(5, rank, world)
+        whole, mine = sld.probe_sharded(emb, db), sld.probe_sharded(emb, db, gather=False)
+        for k, v in db.items():
+            want = oracle.similarity(emb.numpy(), v.numpy())
+            assert np.array_equal(whole[k].numpy(), want) and np.array_equal(mine[k].numpy(), want[lo:hi]), (rank, k)
+
         V = torch.from_numpy(rng.randn(5, 6, 16).astype(np.float32))
         score = lambda v: torch.from_numpy(oracle.clarity(v.numpy()))
         sc = sld.eval_sharded(score, {"x": V})["x"]
         np.save(os.path.join(out_dir, f"clarity_rank{rank}.npy"), sc.numpy())
+        # several layers: ONE all-gather for all of them (blocks of ceil(C_l / R) rows per layer); "tiny" leaves ranks 1 and 2 empty
+        layers = {"wide": torch.from_numpy(rng.randn(8, 6, 16).astype(np.float32)), "tiny": torch.from_numpy(rng.randn(1, 6, 16).astype(np.float32)),
+                  "odd": torch.from_numpy(rng.randn(5, 6, 16).astype(np.float32))}
+        calls = []
+        real = sld.all_gather_rows
+        sld.all_gather_rows = lambda *a, **kw: (calls.append(1), real(*a, **kw))[1]
+        try:
+            multi = sld.eval_sharded(score, layers)
+        finally:
+            sld.all_gather_rows = real
+        assert len(calls) == 1 and list(multi) == list(layers)
+        np.savez(os.path.join(out_dir, f"clarity_multi_rank{rank}.npz"), **{k: v.numpy() for k, v in multi.items()},
+                 **{f"in_{k}": v.numpy() for k, v in layers.items()})
     finally:
         dist.destroy_process_group()
 
@@ -179,3 +200,6 @@ def test_sharded_probing_and_scores_three_ranks_gloo(tmp_path):
     V = rng.randn(5, 6, 16).astype(np.float32)
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"clarity_rank{r}.npy"), oracle.clarity(V))
+        got = np.load(tmp_path / f"clarity_multi_rank{r}.npz")
+        for k in ("wide", "tiny", "odd"):
+            assert got[k].shape == (got[f"in_{k}"].shape[0],) and np.array_equal(got[k], oracle.clarity(got[f"in_{k}"])), (r, k)
