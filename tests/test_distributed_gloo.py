@@ -148,8 +148,8 @@ def _analysis_worker(rank, world, port, out_dir):
             np.savez(os.path.join(out_dir, f"probe_{'tpl' if tpl else 'plain'}_rank{rank}.npz"), **{k: v.numpy() for k, v in out.items()})
 
         # resident query embeddings (bench.py's N > 1 text_probing leg): rows sharded, gathered or kept per rank
-        emb = torch.from_numpy(np.random.RandomState(8).randn(5, 16).astype(np.float32))
-        lo, hi = sld.shard_range(5, rank, world)
+        emb = torch.from_numpy(np.random.RandomState(8).randn(6, 16).astype(np.float32))  # (6 queries: no layer has 6 components — a
+        lo, hi = sld.shard_range(6, rank, world)                                          #  layer with C == Q takes the reference's shape quirk and stays whole)
         whole, mine = sld.probe_sharded(emb, db), sld.probe_sharded(emb, db, gather=False)
         for k, v in db.items():
             want = oracle.similarity(emb.numpy(), v.numpy())
