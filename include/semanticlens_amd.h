@@ -314,19 +314,6 @@ int sl_attention(const float* d_qkv, int64_t B, int64_t T, int64_t H, int64_t he
  * foundation_models/clip.py:103-135). */
 int sl_attention_bf16x3(const float* d_qkv, int64_t B, int64_t T, int64_t H, int64_t head_dim, int causal, float* d_out,
                         uint16_t* d_out_split, void* stream);
-/* The same two calls — packed QKV projection, then attention — for long non-causal sequences (more than four 32-query tiles:
- * image towers from 129 tokens up; `sl_attention_kv_supported`), with K and V leaving the projection ALREADY in the bytes the
- * attention kernel keeps in LDS (per image, head and chunk of 64 keys: bf16 hi / lo planes, V transposed) instead of fp32, so that
- * the attention kernel stages them by LDS-DMA two chunks ahead of its MFMAs.  d_q_out (B*T, H*head_dim) fp32 receives Q;
- * d_kv_image: `sl_attention_kv_image_bytes` bytes, 128-byte aligned, ZEROED ONCE by the caller (the calls never write its padding)
- * and reusable across layers of one geometry.  Results are bit-identical to sl_linear_bf16x3 + sl_attention_bf16x3.
- * (reference: the attention inside open_clip's towers, foundation_models/clip.py:103-135) */
-int sl_attention_kv_supported(int64_t T, int64_t head_dim, int causal);
-size_t sl_attention_kv_image_bytes(int64_t B, int64_t T, int64_t H, int64_t head_dim);
-int sl_linear_bf16x3_qkv(const uint16_t* d_x_split, int64_t M, int64_t K, const uint16_t* d_w_split, const float* d_bias, int64_t B,
-                         int64_t T, int64_t H, int64_t head_dim, float* d_q_out, void* d_kv_image, void* stream);
-int sl_attention_bf16x3_kv(const float* d_q, const void* d_kv_image, int64_t B, int64_t T, int64_t H, int64_t head_dim, float* d_out,
-                           uint16_t* d_out_split, void* stream);
 /* Attention pooling with one query per head (the MAP head of SigLIP image towers, clip.py:190-211 SigLipV2 /
  * open_clip attn_pool): out (B, H*head_dim) = softmax(q k_t / sqrt(head_dim)) v over the T tokens of each image.
  * d_q (H*head_dim) is the projected probe; key row (b, t) is d_kv + (b*T + t) * kv_row_stride, its value row v_offset

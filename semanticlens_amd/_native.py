@@ -89,10 +89,6 @@ SIGNATURES = {
     "sl_layernorm": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, ctypes.c_float, _vp, _vp, _i64, _vp]),
     "sl_attention": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp]),
     "sl_attention_bf16x3": (_int, [_vp, _i64, _i64, _i64, _i64, _int, _vp, _vp, _vp]),
-    "sl_attention_kv_supported": (_int, [_i64, _i64, _int]),
-    "sl_attention_kv_image_bytes": (_sz, [_i64, _i64, _i64, _i64]),
-    "sl_linear_bf16x3_qkv": (_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
-    "sl_attention_bf16x3_kv": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "sl_patchify": (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "sl_attention_pool": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
     "sl_attention_pool_q": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp]),
@@ -991,52 +987,6 @@ def attention(qkv, B, T, H, head_dim, causal, out=None, out_split: Split | None 
     with _on(qkv.device):
         rc = fn(_ptr(qkv), B, T, H, head_dim, 1 if causal else 0, _ptr(out), _split_ptr(out_split), _stream(qkv))
     _check(rc, "sl_attention_bf16x3" if bf16x3 else "sl_attention")
-    return out if out is not None else out_split
-
-
-def attention_kv_supported(T: int, head_dim: int, causal: bool) -> bool:
-    """Long non-causal sequences: the QKV projection can write K / V as the attention kernel's LDS image (``linear3_qkv`` +
-    ``attention_kv``, bit-identical to ``linear3`` + ``attention(bf16x3=True)``)."""
-    return bool(lib().sl_attention_kv_supported(T, head_dim, 1 if causal else 0))
-
-
-_KV_IMAGES: dict = {}
-
-
-def kv_image(B: int, T: int, H: int, head_dim: int, device) -> torch.Tensor:
-    """The zero-initialised K / V image buffer of one geometry (cached per device and stream: its padding is written once, here, and
-    every layer of a tower rewrites the same data positions)."""
-    dev = torch.device(device)
-    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream, B, T, H, head_dim)
-    buf = _KV_IMAGES.get(key)
-    if buf is None:
-        if len(_KV_IMAGES) >= 4:  # a handful of geometries per process (822 MB for so400m at B = 256); do not hoard HBM
-            _KV_IMAGES.pop(next(iter(_KV_IMAGES)))
-        nbytes = int(lib().sl_attention_kv_image_bytes(B, T, H, head_dim))
-        buf = _KV_IMAGES[key] = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
-    return buf
-
-
-def linear3_qkv(x: "Split", w: "Split", bias, B: int, T: int, H: int, head_dim: int, q_out: torch.Tensor, kv: torch.Tensor):
-    """Packed QKV projection in split-bf16 x3 arithmetic: Q -> ``q_out`` (B*T, H*head_dim) fp32, K / V -> the image ``kv``."""
-    _need_f32("linear3_qkv", q_out)
-    W = H * head_dim
-    if x.shape[0] != B * T or w.shape[0] != 3 * W or x.shape[1] != w.shape[1] or tuple(q_out.shape) != (B * T, W) or not q_out.is_contiguous():
-        raise ValueError("linear3_qkv: shapes do not fit")
-    with _on(q_out.device):
-        rc = lib().sl_linear_bf16x3_qkv(_ptr(x.buf), B * T, x.shape[1], _ptr(w.buf), _ptr(bias), B, T, H, head_dim, _ptr(q_out), _ptr(kv),
-                                        _stream(q_out))
-    _check(rc, "sl_linear_bf16x3_qkv")
-
-
-def attention_kv(q: torch.Tensor, kv: torch.Tensor, B, T, H, head_dim, out=None, out_split: "Split | None" = None):
-    """``attention(bf16x3=True)`` reading K / V from the image ``linear3_qkv`` wrote."""
-    _need_f32("attention_kv", q, out)
-    if out is None and out_split is None:
-        out = torch.empty((B * T, H * head_dim), dtype=torch.float32, device=q.device)
-    with _on(q.device):
-        rc = lib().sl_attention_bf16x3_kv(_ptr(q), _ptr(kv), B, T, H, head_dim, _ptr(out), _split_ptr(out_split), _stream(q))
-    _check(rc, "sl_attention_bf16x3_kv")
     return out if out is not None else out_split
 
 

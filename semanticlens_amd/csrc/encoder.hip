@@ -139,108 +139,6 @@ int run_linear3(ProfScope& prof, const uint16_t* xs, int64_t M, int64_t K, const
   return gemm3::launch_gemm3_nt(prof, xs, M, ws, N, K, epi, st);
 }
 
-// ---- QKV projection whose K and V halves leave as the attention kernel's LDS image (round 6) ----------------------------
-// `attention_bf16x3_kernel` spends 40 % of a long-sequence launch staging K and V: fp32 rows of the packed qkv matrix are
-// fetched, converted to bf16 hi / lo and (V) transposed through registers into LDS, and none of it overlaps the MFMAs (one
-// workgroup per CU).  Here the projection's epilogue writes K and V ONCE in exactly the bytes that kernel keeps in LDS — per
-// (image, head, chunk of `kKvChunk` keys): K rows [hi(DP) | pad] and [lo(DP) | pad], then V^T rows per dim with the keys of a
-// 32-key tile in `attn3_vpos` order, hi plane then lo plane — so `attention_bf16x3_kv_kernel` stages a chunk with LDS-DMA
-// (`global_load_lds`, no VALU, no registers) two chunks ahead of the MFMAs that read it.  Q stays fp32, (M, W) row-major.
-// Same values as the fp32 route: v = acc + bias is rounded to fp32 exactly as before, hi = bf16(v), lo = bf16(v - hi).
-// Padding (dims D .. DP - 1, V^T rows D .. 32 NT - 1, keys past T) is never written: the image buffer is zeroed once.
-constexpr int kKvChunk = 64;  // keys per chunk: two chunk images (2 x 50 KB at head_dim 72) fit the LDS beside each other
-__host__ __device__ constexpr int kv_dp(int D) { return (D + 15) / 16 * 16; }
-__host__ __device__ constexpr int kv_krow(int D) { return kv_dp(D) * 2 + 16; }
-__host__ __device__ constexpr int kv_vrow() { return kKvChunk * 2 + 16; }
-__host__ __device__ constexpr int kv_nt(int D) { return (D + 31) / 32; }
-__host__ __device__ constexpr int64_t kv_kplane(int D) { return (int64_t)kKvChunk * kv_krow(D); }
-__host__ __device__ constexpr int64_t kv_vplane(int D) { return (int64_t)kv_nt(D) * 32 * kv_vrow(); }
-__host__ __device__ constexpr int64_t kv_chunk_bytes(int D) { return 2 * kv_kplane(D) + 2 * kv_vplane(D); }  // a multiple of 1 KiB
-
-struct QkvEpi {
-  const float* bias;   // (3 W) or nullptr
-  float* q_out;        // (M, W) fp32
-  unsigned char* img;  // K / V images, see above
-  int64_t W;           // H * D
-  int64_t c0;          // column offset of a strip (gemm_bf16x3.hpp: column-strip split)
-  int T, H, D, nchunk;
-  uint32_t t_inv, d_inv;  // floor(2^32 / T), floor(2^32 / D)
-  int64_t kplane, vplane, chunk_bytes;
-  int krow;
-  static __device__ inline void divmod(uint32_t x, uint32_t by, uint32_t inv, uint32_t& q, uint32_t& rem) {
-    q = __umulhi(x, inv);
-    rem = x - q * by;
-    if (rem >= by) { q += 1; rem -= by; }
-    if (rem >= by) { q += 1; rem -= by; }
-  }
-  __device__ inline float column(int64_t col) const { return bias ? bias[col + c0] : 0.f; }
-  QkvEpi shifted(int64_t by) const {
-    QkvEpi e = *this;
-    e.c0 += by;
-    return e;
-  }
-  // four consecutive rows (row % 4 == 0) of one column: V leaves as two 8-byte stores (four keys of one dim are adjacent in V^T)
-  static constexpr bool kStores4 = true;
-  __device__ inline void store4(int64_t row, int64_t col, float a0, float a1, float a2, float a3, float b) const {
-#pragma clang fp contract(off)
-    const int64_t c = col + c0;
-    uint32_t bi, t;
-    divmod((uint32_t)row, (uint32_t)T, t_inv, bi, t);
-    if (c < 2 * W || t + 3 >= (uint32_t)T || (t & 3) != 0) {  // Q, K, or a group that straddles two images
-      store(row, col, a0, b), store(row + 1, col, a1, b), store(row + 2, col, a2, b), store(row + 3, col, a3, b);
-      return;
-    }
-    uint32_t h, d;
-    divmod((uint32_t)(c - 2 * W), (uint32_t)D, d_inv, h, d);
-    const uint32_t chunk = t / kKvChunk, tl = t % kKvChunk;
-    const uint32_t kk = tl & 31;
-    const uint32_t r = (kk & 3) + 4 * (kk >> 3), hh = (kk >> 2) & 1;
-    const uint32_t pos = (tl & ~31u) + (2 * (r >> 3) + hh) * 8 + (r & 7);  // attn3_vpos; keys tl .. tl + 3 sit at pos .. pos + 3
-    unsigned char* p = img + (((int64_t)bi * H + h) * nchunk + chunk) * chunk_bytes + 2 * kplane + (int64_t)d * kv_vrow() + pos * 2;
-    const float v[4] = {a0 + b, a1 + b, a2 + b, a3 + b};
-    uint16_t hi[4], lo[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const __bf16 hb = (__bf16)v[j];
-      hi[j] = __builtin_bit_cast(uint16_t, hb);
-      lo[j] = gemm3::bf16_bits_hw(v[j] - (float)hb);
-    }
-    *reinterpret_cast<uint2*>(p) = make_uint2((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16));
-    *reinterpret_cast<uint2*>(p + vplane) = make_uint2((uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16));
-  }
-  __device__ inline void store(int64_t row, int64_t col, float acc, float b) const {
-#pragma clang fp contract(off)
-    const float v = acc + b;
-    const int64_t c = col + c0;
-    if (c < W) {
-      q_out[row * W + c] = v;
-      return;
-    }
-    uint32_t cc = (uint32_t)(c - W);
-    const bool is_v = cc >= (uint32_t)W;
-    if (is_v) cc -= (uint32_t)W;
-    uint32_t h, d, bi, t;
-    divmod(cc, (uint32_t)D, d_inv, h, d);
-    divmod((uint32_t)row, (uint32_t)T, t_inv, bi, t);
-    const uint32_t chunk = t / kKvChunk, tl = t % kKvChunk;
-    unsigned char* base = img + (((int64_t)bi * H + h) * nchunk + chunk) * chunk_bytes;
-    const __bf16 hb = (__bf16)v;
-    const uint16_t hi = __builtin_bit_cast(uint16_t, hb), lo = gemm3::bf16_bits_hw(v - (float)hb);
-    if (!is_v) {
-      unsigned char* p = base + (int64_t)tl * krow + d * 2;
-      *reinterpret_cast<uint16_t*>(p) = hi;
-      *reinterpret_cast<uint16_t*>(p + kplane) = lo;
-    } else {
-      const uint32_t kk = tl & 31;
-      const uint32_t r = (kk & 3) + 4 * (kk >> 3), hh = (kk >> 2) & 1;
-      const uint32_t pos = (tl & ~31u) + (2 * (r >> 3) + hh) * 8 + (r & 7);  // attn3_vpos
-      unsigned char* p = base + 2 * kplane + (int64_t)d * kv_vrow() + pos * 2;
-      *reinterpret_cast<uint16_t*>(p) = hi;
-      *reinterpret_cast<uint16_t*>(p + vplane) = lo;
-    }
-  }
-};
-
 // ---- LayerNorm over the last dim: one wave per row -------------------------------------------------------------
 // Fast path (J > 0: cols % 4 == 0, cols <= 256 J, 16-byte aligned rows): the row is read once into registers (up to J
 // float4 per lane: J = 4 up to 1024 columns, J = 8 up to 2048 — SigLIP-so400m's 1152 took the three-pass path until round 4:
@@ -764,222 +662,6 @@ __global__ __launch_bounds__(64 * MAXW, (D <= 96 ? 2 : 1)) void attention_bf16x3
   }
 }
 
-// ---- the same attention fed from pre-split K / V images by LDS-DMA (round 6) ----------------------------------------------------
-// K and V arrive as the LDS image itself (QkvEpi above: per (image, head) a row of `nchunk` chunk images of 64 keys), so staging a
-// chunk is `chunk_bytes / 1024` wave-wide `global_load_lds` instructions — no VALU, no registers, no conversion — spread over the
-// workgroup's waves and issued TWO chunks ahead: chunk c + 2 goes into the slot chunk c was just read from, behind a raw barrier,
-// and is awaited with a counted `s_waitcnt vmcnt(n)` (n = the DMA instructions this wave issued for the chunk after it), so the only
-// exposed memory round trip of a workgroup is its first chunk.  The key-tile loop, the online softmax and the output path are those
-// of attention_bf16x3_kernel, in the same order per element: results are bit-identical to it (tests/test_gpu_native_clip.py).
-// Non-causal, one round or several (rounds re-stream the chunks).  Q: (B*T, H*D) fp32.
-__device__ __forceinline__ void wait_vmcnt_upto(int n) {  // at most n vector-memory operations of this wave still in flight
-  switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
-    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-  }
-}
-
-template <int D, int MAXW>
-__global__ __launch_bounds__(64 * MAXW, 2) void attention_bf16x3_kv_kernel(const float* __restrict__ qmat, const unsigned char* __restrict__ img,
-                                                                        int T, int H, int nchunk, float scale, float* __restrict__ out,
-                                                                        uint16_t* __restrict__ osp) {
-  constexpr int kDh = D;
-  constexpr int DP = attn3_dp(D), NS = DP / 16;
-  constexpr int NT = (D + 31) / 32;
-  constexpr int KROW = kv_krow(D);
-  constexpr int KC = kKvChunk;
-  constexpr int VROW = kv_vrow();
-  constexpr int64_t CB = kv_chunk_bytes(D);
-  constexpr int NI = (int)(CB / 1024);  // wave-wide DMA instructions per chunk
-  extern __shared__ __align__(1024) unsigned char smem3[];
-  const int Tp = (T + 31) & ~31;
-  const int tid = threadIdx.x;
-  const int nwaves = blockDim.x >> 6;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int li = lane & 31, lh = lane >> 5;
-  const int64_t b = blockIdx.x / H;
-  const int h = blockIdx.x % H;
-  const int64_t ldq = (int64_t)H * kDh;
-  const float* qbase = qmat + b * T * ldq + h * kDh;
-  const unsigned char* ibase = img + ((b * H + h) * (int64_t)nchunk) * CB;
-  const int nqt = Tp / 32;
-  const int my_ni = w < NI ? (NI - 1 - w) / nwaves + 1 : 0;  // DMA instructions of one chunk that this wave issues
-  typedef __attribute__((address_space(3))) void lds_void;
-  typedef const __attribute__((address_space(1))) void glb_void;
-  auto issue_chunk = [&](int c) __attribute__((always_inline)) {
-    const unsigned char* src = ibase + (int64_t)c * CB + lane * 16;
-    unsigned char* dst = smem3 + (size_t)(c & 1) * CB;
-    for (int i = w; i < NI; i += nwaves)
-      __builtin_amdgcn_global_load_lds((glb_void*)(src + (int64_t)i * 1024), (lds_void*)(dst + (size_t)i * 1024), 16, 0, 0);
-  };
-  auto raw_barrier = [&]() __attribute__((always_inline)) {
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto split8 = [](const float* v, abf16x8& hi, abf16x8& lo) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const __bf16 hb = (__bf16)v[j];
-      hi[j] = hb;
-      lo[j] = (__bf16)(v[j] - (float)hb);
-    }
-  };
-  for (int qt0 = 0; qt0 < nqt; qt0 += nwaves) {
-    const int qt = qt0 + w;
-    const bool active = qt < nqt;
-    const int q = qt * 32 + li;
-    // Q through hand-issued loads: the compiler's own wait for a load it tracks would be vmcnt(0) (it cannot count the DMA
-    // instructions issued behind it in a loop), i.e. a wait for chunk 1 as well.  The counted wait below covers them (they are older
-    // than every DMA instruction), and the empty asm statements behind it keep every use of the registers after that wait.
-    gemm8::f32x4 qraw[NS][2];
-    {
-      const float* qp = qbase + (int64_t)(q < T ? q : T - 1) * ldq;
-#pragma unroll
-      for (int s = 0; s < NS; ++s)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const int d0 = 16 * s + 8 * lh + 4 * c;
-          qraw[s][c] = gemm8::f32x4{0.f, 0.f, 0.f, 0.f};
-          if (d0 < D) asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(qraw[s][c]) : "v"(qp + d0) : "memory");
-        }
-    }
-    issue_chunk(0);
-    if (nchunk > 1) issue_chunk(1);
-    abf16x8 qh[NS], ql[NS];
-    afloatx16 o[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
-    float m = -__builtin_huge_valf(), l = 0.f;
-    for (int c = 0; c < nchunk; ++c) {
-      // chunk c has landed once at most the instructions of the chunk issued after it are still in flight (the Q loads are older)
-      wait_vmcnt_upto(c + 1 < nchunk ? my_ni : 0);
-      raw_barrier();  // ... for every wave's share of it
-      if (c == 0) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-          asm volatile("" : "+v"(qraw[s][0]), "+v"(qraw[s][1]));
-          const float v[8] = {qraw[s][0][0] * scale, qraw[s][0][1] * scale, qraw[s][0][2] * scale, qraw[s][0][3] * scale,
-                              qraw[s][1][0] * scale, qraw[s][1][1] * scale, qraw[s][1][2] * scale, qraw[s][1][3] * scale};
-          split8(v, qh[s], ql[s]);
-        }
-      }
-      const unsigned char* sKh = smem3 + (size_t)(c & 1) * CB;
-      const unsigned char* sKl = sKh + (size_t)KC * KROW;
-      const unsigned char* sVh = sKl + (size_t)KC * KROW;
-      const unsigned char* sVl = sVh + (size_t)(NT * 32) * VROW;
-      const int kt_first = c * (KC / 32);
-      const int kt_end = !active ? kt_first : (kt_first + KC / 32 < nqt ? kt_first + KC / 32 : nqt);
-      for (int kt = kt_first; kt < kt_end; ++kt) {
-        const int kl = (kt - kt_first) * 32;
-        afloatx16 st;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) st[e] = 0.f;
-        const unsigned char* kph = sKh + (size_t)(kl + li) * KROW + lh * 16;
-        const unsigned char* kpl = sKl + (size_t)(kl + li) * KROW + lh * 16;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-          const abf16x8 kh = *reinterpret_cast<const abf16x8*>(kph + s * 32);
-          const abf16x8 klo = *reinterpret_cast<const abf16x8*>(kpl + s * 32);
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(klo, qh[s], st, 0, 0, 0);
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[s], st, 0, 0, 0);
-          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[s], st, 0, 0, 0);
-        }
-        float mx = -__builtin_huge_valf();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          st[r] = key >= T ? -__builtin_huge_valf() : st[r];
-          mx = fmaxf(mx, st[r]);
-        }
-        mx = fmaxf(mx, xhalf(mx));
-        const float mn = fmaxf(m, mx);
-        const float alpha = exp_neg(m - mn);
-        float ps = 0.f;
-        float pv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          pv[r] = exp_neg(st[r] - mn);
-          ps += pv[r];
-        }
-        ps += xhalf(ps);
-        l = l * alpha + ps;
-        if (!__all(mn == m)) {
-#pragma unroll
-          for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
-        }
-        m = mn;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          abf16x8 ph, pl;
-          split8(pv + 8 * s2, ph, pl);
-          const size_t col = (size_t)(kl + (2 * s2 + lh) * 8) * 2;
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const abf16x8 vh = *reinterpret_cast<const abf16x8*>(sVh + (size_t)(32 * t + li) * VROW + col);
-            const abf16x8 vl = *reinterpret_cast<const abf16x8*>(sVl + (size_t)(32 * t + li) * VROW + col);
-            o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, o[t], 0, 0, 0);
-            o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, o[t], 0, 0, 0);
-            o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o[t], 0, 0, 0);
-          }
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the slot are retired
-      raw_barrier();                                      // ... and every other wave's: the slot may be refilled
-      if (c + 2 < nchunk) issue_chunk(c + 2);
-    }
-    // output through LDS, as in attention_bf16x3_kernel (both slots are free: the last barrier above)
-    {
-      constexpr int SROW = D * 4 + 16;
-      unsigned char* stage = smem3 + (size_t)w * 32 * SROW;
-      const float inv = 1.f / l;
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int d = 32 * t + 8 * g + 4 * lh;
-          if (d < D)
-            *reinterpret_cast<float4*>(stage + (size_t)li * SROW + d * 4) =
-                make_float4(o[t][4 * g] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
-        }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      constexpr int CPR = D / 4;
-      if (active) {
-        for (int e = lane; e < 32 * CPR; e += 64) {
-          const int row = e / CPR, c = e % CPR;
-          const int qq = qt * 32 + row;
-          if (qq < T) {
-            const float4 v = *reinterpret_cast<const float4*>(stage + (size_t)row * SROW + c * 16);
-            if (out) *reinterpret_cast<float4*>(out + (b * T + qq) * (int64_t)H * kDh + h * kDh + c * 4) = v;
-            if (osp) store_split4(v, b * T + qq, h * kDh + c * 4, split_kp((int64_t)H * kDh), osp);
-          }
-        }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    raw_barrier();  // the next round's DMA may overwrite the staging area
-  }
-}
-
 // ---- patch extraction: (B, C, Hi, Wi) -> (B * gh * gw, C * P * P), k = c*P*P + py*P + px (conv weight order) --
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, int64_t B, int C, int Hi, int Wi,
                                                         int P, float* __restrict__ out, uint16_t* __restrict__ osp) {
@@ -1283,82 +965,6 @@ SL_API int sl_attention_bf16x3(const float* d_qkv, int64_t B, int64_t T, int64_t
     default: break;
   }
   SL_REQUIRE(false, "sl_attention_bf16x3: head_dim=%lld (built: 32, 64, 72, 80, 88, 96, 104, 128)", (long long)head_dim);
-}
-
-// ---- QKV projection into (Q fp32, K / V images) + the attention that reads them -----------------------------------------------
-SL_API int sl_attention_kv_supported(int64_t T, int64_t head_dim, int causal) {
-  const int64_t nqt = (T + 31) / 32;
-  const bool built = head_dim == 32 || head_dim == 64 || head_dim == 72 || head_dim == 80 || head_dim == 88 || head_dim == 96;
-  return (built && !causal && nqt > 4 && T < (1 << 20)) ? 1 : 0;  // short sequences are one chunk: nothing to run ahead of
-}
-
-SL_API size_t sl_attention_kv_image_bytes(int64_t B, int64_t T, int64_t H, int64_t head_dim) {
-  if (B <= 0 || T <= 0 || H <= 0 || head_dim <= 0) return 0;
-  const int64_t nchunk = (T + kKvChunk - 1) / kKvChunk;
-  return (size_t)(B * H * nchunk) * (size_t)kv_chunk_bytes((int)head_dim);
-}
-
-SL_API int sl_linear_bf16x3_qkv(const uint16_t* d_x_split, int64_t M, int64_t K, const uint16_t* d_w_split, const float* d_bias,
-                                int64_t B, int64_t T, int64_t H, int64_t head_dim, float* d_q_out, void* d_kv_image, void* stream) {
-  SL_REQUIRE(M >= 0 && K >= 0 && B >= 0 && T >= 1 && H >= 1 && head_dim >= 1, "sl_linear_bf16x3_qkv: bad shape");
-  SL_REQUIRE(M == B * T, "sl_linear_bf16x3_qkv: M = %lld rows, B * T = %lld", (long long)M, (long long)(B * T));
-  SL_REQUIRE(sl_attention_kv_supported(T, head_dim, 0), "sl_linear_bf16x3_qkv: T = %lld, head_dim = %lld not supported "
-             "(sl_attention_kv_supported)", (long long)T, (long long)head_dim);
-  if (M == 0) return 0;
-  SL_REQUIRE(d_x_split && d_w_split && d_q_out && d_kv_image, "sl_linear_bf16x3_qkv: null pointer");
-  SL_REQUIRE((((uintptr_t)d_x_split | (uintptr_t)d_w_split | (uintptr_t)d_kv_image) & 127) == 0,
-             "sl_linear_bf16x3_qkv: split matrices and the K / V image must be 128-byte aligned");
-  SL_REQUIRE(M < (1ll << 32), "sl_linear_bf16x3_qkv: rows are indexed with 32 bits");
-  const int D = (int)head_dim;
-  const int64_t W = H * head_dim;
-  hipStream_t st = (hipStream_t)stream;
-  ProfScope prof(SL_PROF_GEMM, st, 2.0 * (double)M * (double)(3 * W) * (double)K);
-  QkvEpi epi;
-  epi.bias = d_bias, epi.q_out = d_q_out, epi.img = (unsigned char*)d_kv_image, epi.W = W, epi.c0 = 0;
-  epi.T = (int)T, epi.H = (int)H, epi.D = D, epi.nchunk = (int)((T + kKvChunk - 1) / kKvChunk);
-  epi.t_inv = T > 1 ? (uint32_t)((1ull << 32) / (uint64_t)T) : 0xFFFFFFFFu;
-  epi.d_inv = D > 1 ? (uint32_t)((1ull << 32) / (uint64_t)D) : 0xFFFFFFFFu;
-  epi.kplane = kv_kplane(D), epi.vplane = kv_vplane(D), epi.chunk_bytes = kv_chunk_bytes(D), epi.krow = kv_krow(D);
-  return gemm3::launch_gemm3_nt(prof, d_x_split, M, d_w_split, 3 * W, K, epi, st);
-}
-
-template <int D>
-static int launch_attention_kv(const float* q, const unsigned char* img, int64_t B, int64_t T, int64_t H, float* out, uint16_t* osp,
-                               hipStream_t st) {
-  const int nchunk = (int)((T + kKvChunk - 1) / kKvChunk);
-  size_t smem = 2 * (size_t)kv_chunk_bytes(D);
-  const size_t stage = (size_t)8 * 32 * (D * 4 + 16);
-  if (stage > smem) smem = stage;
-  static const hipError_t allowed = hipFuncSetAttribute((const void*)attention_bf16x3_kv_kernel<D, 8>,
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-  if (allowed != hipSuccess) return hip_fail(allowed, "hipFuncSetAttribute(attention_bf16x3_kv_kernel)");
-  const float scale = (float)(1.0 / sqrt((double)D));
-  hipLaunchKernelGGL((attention_bf16x3_kv_kernel<D, 8>), dim3((unsigned)(B * H)), dim3(512), smem, st, q, img, (int)T, (int)H, nchunk,
-                     scale, out, osp);
-  SL_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-
-SL_API int sl_attention_bf16x3_kv(const float* d_q, const void* d_kv_image, int64_t B, int64_t T, int64_t H, int64_t head_dim,
-                                  float* d_out, uint16_t* d_out_split, void* stream) {
-  SL_REQUIRE(B >= 0 && T >= 1 && H >= 1, "sl_attention_bf16x3_kv: bad shape");
-  SL_REQUIRE(sl_attention_kv_supported(T, head_dim, 0), "sl_attention_bf16x3_kv: T = %lld, head_dim = %lld not supported",
-             (long long)T, (long long)head_dim);
-  if (B == 0) return 0;
-  SL_REQUIRE(d_q && d_kv_image && (d_out || d_out_split), "sl_attention_bf16x3_kv: null pointer");
-  SL_REQUIRE(B * H < (1ll << 31), "sl_attention_bf16x3_kv: too many heads");
-  hipStream_t st = (hipStream_t)stream;
-  const unsigned char* img = (const unsigned char*)d_kv_image;
-  switch (head_dim) {
-    case 32: return launch_attention_kv<32>(d_q, img, B, T, H, d_out, d_out_split, st);
-    case 64: return launch_attention_kv<64>(d_q, img, B, T, H, d_out, d_out_split, st);
-    case 72: return launch_attention_kv<72>(d_q, img, B, T, H, d_out, d_out_split, st);
-    case 80: return launch_attention_kv<80>(d_q, img, B, T, H, d_out, d_out_split, st);
-    case 88: return launch_attention_kv<88>(d_q, img, B, T, H, d_out, d_out_split, st);
-    case 96: return launch_attention_kv<96>(d_q, img, B, T, H, d_out, d_out_split, st);
-    default: break;
-  }
-  SL_REQUIRE(false, "sl_attention_bf16x3_kv: head_dim=%lld (built: 32, 64, 72, 80, 88, 96)", (long long)head_dim);
 }
 
 static int attention_pool_impl(const char* fn, const float* d_q, int64_t q_batch_stride, const float* d_kv, int64_t kv_row_stride,

@@ -21,18 +21,6 @@ struct EpiFetches<E, decltype((void)E::kFetches)> {
   static constexpr bool value = E::kFetches;
 };
 
-// An epilogue that can use FOUR CONSECUTIVE ROWS of one column at once (the accumulator registers 4 g .. 4 g + 3 of a lane: rows
-// row0 + 8 g + 0..3) exposes `static constexpr bool kStores4 = true` and `store4(row, col, a0, a1, a2, a3, column_value)`
-// == four `store` calls (encoder.hip QkvEpi: V leaves transposed, four keys of one dim are 8 contiguous bytes).
-template <class E, class = void>
-struct EpiStores4 {
-  static constexpr bool value = false;
-};
-template <class E>
-struct EpiStores4<E, decltype((void)E::kStores4)> {
-  static constexpr bool value = E::kStores4;
-};
-
 // One 32 x 32 MFMA accumulator tile (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).
 // row0 = first row of the tile + 4 (lane >> 5); col = this lane's column.  CHECK: rows / columns may lie past the edge.
 template <bool CHECK, class Epi, class Acc16>
@@ -51,18 +39,6 @@ __device__ __forceinline__ void store_mfma_tile(const Epi& epi, int64_t row0, in
     for (int r = 0; r < 16; ++r) {
       const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
       if (!CHECK || row < M) epi.store_fetched(row, col, acc[r], cv, pre[r]);
-    }
-  } else if constexpr (EpiStores4<Epi>::value) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int64_t row = row0 + 8 * g;
-      if (!CHECK || row + 3 < M) {
-        epi.store4(row, col, acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], cv);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (row + j < M) epi.store(row + j, col, acc[4 * g + j], cv);
-      }
     }
   } else {
 #pragma unroll

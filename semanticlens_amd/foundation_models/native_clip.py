@@ -204,9 +204,6 @@ def _project(pooled: torch.Tensor, w: torch.Tensor | None, b: torch.Tensor | Non
     return N.linear3(N.Split.of(pooled), s_w, b)
 
 
-KV_ROUTE = True  # tests flip it to compare the two routes bit for bit
-
-
 class _Tower:
     """L residual blocks over a (B*T, W) fp32 token matrix (the residual stream stays fp32 in both modes)."""
 
@@ -226,37 +223,22 @@ class _Tower:
         Each GEMM row depends on its own input row only, so the pooled rows are bit-identical either way."""
         M, W = x.shape
         F = self.blocks[0].w_fc.shape[0]
-        # long non-causal sequences (image towers from 129 tokens) in the split arithmetic: K and V leave the QKV projection as the
-        # attention kernel's LDS image and are staged by LDS-DMA ahead of its MFMAs (round 6; same bits as the fp32 route)
-        kv_route = self.split and KV_ROUTE and N.attention_kv_supported(T, self.blocks[0].head_dim, causal)
-        qkv = torch.empty((M, W if kv_route else 3 * W), dtype=torch.float32, device=x.device)
+        qkv = torch.empty((M, 3 * W), dtype=torch.float32, device=x.device)
         last = len(self.blocks) - 1
         if self.split:
             h, att, hid = N.Split(M, W, x.device), N.Split(M, W, x.device), N.Split(M, F, x.device)
-            if kv_route:
-                q_only = qkv
-                kv = N.kv_image(B, T, self.heads, self.blocks[0].head_dim, x.device)
             for i, blk in enumerate(self.blocks):
                 N.layernorm(x, *blk.ln1, out_split=h)
-                if kv_route:
-                    N.linear3_qkv(h, blk.s_qkv, blk.b_qkv, B, T, blk.heads, blk.head_dim, q_only, kv)
-                    if i == last and pool_rows is not None:
-                        att32 = N.attention_kv(q_only, kv, B, T, blk.heads, blk.head_dim)
-                    else:
-                        N.attention_kv(q_only, kv, B, T, blk.heads, blk.head_dim, out_split=att)
-                else:
-                    N.linear3(h, blk.s_qkv, blk.b_qkv, out=qkv)
-                    if i == last and pool_rows is not None:
-                        att32 = N.attention(qkv, B, T, blk.heads, blk.head_dim, causal, bf16x3=True)
-                    else:
-                        N.attention(qkv, B, T, blk.heads, blk.head_dim, causal, out_split=att, bf16x3=True)  # both products split-bf16 x3
+                N.linear3(h, blk.s_qkv, blk.b_qkv, out=qkv)
                 if i == last and pool_rows is not None:
+                    att32 = N.attention(qkv, B, T, blk.heads, blk.head_dim, causal, bf16x3=True)
                     xp = N.gather_rows(x, pool_rows, check=False)
                     N.linear3(N.Split.of(N.gather_rows(att32, pool_rows, check=False)), blk.s_o, blk.b_o, residual=xp, out=xp)
                     hp = N.layernorm(xp, *blk.ln2, out_split=N.Split(B, W, x.device))
                     hidp = N.linear3(hp, blk.s_fc, blk.b_fc, act=blk.act, out_split=N.Split(B, F, x.device))
                     N.linear3(hidp, blk.s_pr, blk.b_pr, residual=xp, out=xp)
                     return xp
+                N.attention(qkv, B, T, blk.heads, blk.head_dim, causal, out_split=att, bf16x3=True)  # both products split-bf16 x3
                 N.linear3(att, blk.s_o, blk.b_o, residual=x, out=x)  # x += out_proj(attn)
                 N.layernorm(x, *blk.ln2, out_split=h)
                 N.linear3(h, blk.s_fc, blk.b_fc, act=blk.act, out_split=hid)  # GELU output leaves as split bf16
