@@ -369,35 +369,41 @@ def cpu_baseline(args, model_cpu, fm_cpu):
 
     B = 64
     # pick the torch thread count that is fastest on this box (containers often expose more logical CPUs than their quota
-    # sustains: on the MI355X boxes 16-32 threads beat 256 by 3x): ResNet-50 forward of 64 images, best of 2 after a warm-up
-    # call, per candidate; the all-cores figure is reported beside the best one
-    probe = synth.normalize_u8(synth.synth_images_u8(torch.arange(64)), synth.IMAGENET_MEAN, synth.IMAGENET_STD)
+    # sustains: on the MI355X boxes 8-32 threads beat 256 by 20-70x) for ONE BATCH'S COMPUTE of the job — ResNet-50 forward + CLIP
+    # encode of 32 images after an 8-image call of both (the forward alone picked 2 threads on one box of round 6: 32 images/s for
+    # the forward, 10 for the job).  Counts past the first one that falls below half of the best are not probed (a 64-image forward
+    # with one thread per logical CPU of a 256-CPU box costs minutes); all cores get a 4-image probe in that case.
+    probe_u8 = synth.synth_images_u8(torch.arange(10**7, 10**7 + 32))
     try:
         all_cores = len(os.sched_getaffinity(0))
     except AttributeError:
         all_cores = os.cpu_count() or torch.get_num_threads()
-    best_t, best_dt = torch.get_num_threads(), float("inf")
-    cands = sorted({t for t in (2, 4, 8, 16, 32, 64, 128, all_cores) if t <= all_cores})  # 2 and 4: the grid must bracket its best (round 4: best = its smallest, 8)
+    best_t, best_rate = torch.get_num_threads(), 0.0
+    cands = sorted({t for t in (2, 4, 8, 16, 32, 64, 128, all_cores) if t <= all_cores})
     thread_probe = {}
+
+    def batch_compute(u8):
+        model_cpu(synth.normalize_u8(u8, synth.IMAGENET_MEAN, synth.IMAGENET_STD))
+        fm_cpu.encode_image(fm_cpu.preprocess(u8))
+
+    stop = False
     with torch.no_grad():
         for t in cands:
-            torch.set_num_threads(t)
-            t0 = time.perf_counter()
-            model_cpu(probe[:16])
-            first = (time.perf_counter() - t0) / 16  # seconds per image of the first (16-image) call
-            if first > 3.0 * best_dt / 64:
-                # hopeless already (one thread per logical CPU of a 256-CPU box runs 15-20x below the best count: two more 64-image
-                # forwards there cost 90 s of the leg): its first call is its figure
-                thread_probe[t] = 1.0 / first
+            if stop and t != all_cores:
                 continue
-            dts = []
-            for _ in range(2):
+            torch.set_num_threads(t)
+            if stop:  # all cores, known to be far off: four images, no warm-up call
                 t0 = time.perf_counter()
-                model_cpu(probe)
-                dts.append(time.perf_counter() - t0)
-            thread_probe[t] = 64 / min(dts)
-            if min(dts) < best_dt:
-                best_t, best_dt = t, min(dts)
+                batch_compute(probe_u8[:4])
+                thread_probe[t] = 4 / (time.perf_counter() - t0)
+                continue
+            batch_compute(probe_u8[:8])
+            t0 = time.perf_counter()
+            batch_compute(probe_u8)
+            thread_probe[t] = 32 / (time.perf_counter() - t0)
+            if thread_probe[t] > best_rate:
+                best_t, best_rate = t, thread_probe[t]
+            stop = thread_probe[t] < 0.5 * best_rate
     bytes_per_img = 2809856  # ResNet-50 layer2+3+4 fp32 activations per image
 
     def job(n, threads, warm=True):
@@ -459,7 +465,7 @@ def cpu_baseline(args, model_cpu, fm_cpu):
     rate, dt, agg_s = job(n, threads)
     # every core of the box, the same job on ONE batch (SURVEY §8d planned "all host cores"; on these boxes one thread per logical CPU is
     # an order of magnitude slower than the best count, so its sample is kept to one batch; pools are warm from the thread probe)
-    B_all = 16  # (64 images took 80 s with 256 threads on the round's first box)
+    B_all = 8  # (64 images took 80 s with 256 threads on the round's first box, 16 images 73 s on its third)
     if all_cores != threads:
         rate_all, dt_all, _ = job_b(B_all, all_cores)
         torch.set_num_threads(threads)
@@ -476,14 +482,14 @@ def cpu_baseline(args, model_cpu, fm_cpu):
         "value": rate, "unit": "images/s", "cores": threads, "threads": threads,
         "all_cores": {"value": rate_all, "unit": "images/s", "cores": all_cores,
                       "sample": f"{B_all if all_cores != threads else n} images (one batch), the same job, {dt_all:.1f} s",
-                      "forward_images_per_s": thread_probe.get(all_cores)},
+                      "probe_images_per_s": thread_probe.get(all_cores)},
         "host_cores": os.cpu_count(), "host_cores_affinity": affinity, "kind": "port",
         "sample": f"{n} synthetic images (batch {B}), same models/layers/k, torch-CPU forward + oracle collect "
                   f"(ATen tie order) + CPU CLIP encode + gather; {dt:.1f} s",
         "collect_only_GBps": n * bytes_per_img / agg_s / 1e9,
         "collect_only_seconds": agg_s,
-        # ResNet-50 forward alone, images/s per thread count tried (64 images, best of 2): how `cores` was chosen
-        "thread_probe_forward_images_per_s": {str(k_): v for k_, v in thread_probe.items()},
+        # one batch's compute (ResNet-50 forward + CLIP encode, 32 images), images/s per thread count tried: how `cores` was chosen
+        "thread_probe_images_per_s": {str(k_): v for k_, v in thread_probe.items()},
     }
 
 
