@@ -392,10 +392,10 @@ def cpu_baseline(args, model_cpu, fm_cpu):
             if stop and t != all_cores:
                 continue
             torch.set_num_threads(t)
-            if stop:  # all cores, known to be far off: four images, no warm-up call
+            if stop:  # all cores, known to be far off (18 s PER IMAGE on one box of round 6): two images, no warm-up call
                 t0 = time.perf_counter()
-                batch_compute(probe_u8[:4])
-                thread_probe[t] = 4 / (time.perf_counter() - t0)
+                batch_compute(probe_u8[:2])
+                thread_probe[t] = 2 / (time.perf_counter() - t0)
                 continue
             batch_compute(probe_u8[:8])
             t0 = time.perf_counter()
@@ -466,12 +466,18 @@ def cpu_baseline(args, model_cpu, fm_cpu):
     # every core of the box, the same job on ONE batch (SURVEY §8d planned "all host cores"; on these boxes one thread per logical CPU is
     # an order of magnitude slower than the best count, so its sample is kept to one batch; pools are warm from the thread probe)
     B_all = 8  # (64 images took 80 s with 256 threads on the round's first box, 16 images 73 s on its third)
-    if all_cores != threads:
+    all_sample = None
+    if all_cores == threads:
+        rate_all, dt_all = rate, dt
+    elif stop:
+        # one thread per logical CPU already measured far below half of the best count by the probe: its probe figure (forward +
+        # encode of two images) stands for it — the whole job there would add minutes to the line for a number nobody can use
+        rate_all, dt_all = thread_probe[all_cores], 2 / thread_probe[all_cores]
+        all_sample = f"2 images, ResNet-50 forward + CLIP encode only (the thread probe), {dt_all:.1f} s"
+    else:
         rate_all, dt_all, _ = job_b(B_all, all_cores)
         torch.set_num_threads(threads)
         oracle.set_threads(threads)
-    else:
-        rate_all, dt_all = rate, dt
     try:
         affinity = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -481,7 +487,7 @@ def cpu_baseline(args, model_cpu, fm_cpu):
         # `host_cores` = what the box has (logical CPUs / CPUs this process may run on).  Best count and all cores side by side:
         "value": rate, "unit": "images/s", "cores": threads, "threads": threads,
         "all_cores": {"value": rate_all, "unit": "images/s", "cores": all_cores,
-                      "sample": f"{B_all if all_cores != threads else n} images (one batch), the same job, {dt_all:.1f} s",
+                      "sample": all_sample or f"{B_all if all_cores != threads else n} images (one batch), the same job, {dt_all:.1f} s",
                       "probe_images_per_s": thread_probe.get(all_cores)},
         "host_cores": os.cpu_count(), "host_cores_affinity": affinity, "kind": "port",
         "sample": f"{n} synthetic images (batch {B}), same models/layers/k, torch-CPU forward + oracle collect "
