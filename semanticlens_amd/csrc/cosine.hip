@@ -366,7 +366,6 @@ int cosine_matrix_multi(const float* X, int64_t Q, int64_t K, const float* const
     xsrc.start[0] = 0;
     xsrc.start[1] = Q;
     xsrc.n = 1;
-    if (int rc = launch_norm_split(xsrc, K, 1e-12f, xs, st)) return rc;
     MultiEpi epi{};
     RowSources ysrc{};
     epi.n = 0;
@@ -384,7 +383,24 @@ int cosine_matrix_multi(const float* X, int64_t Q, int64_t K, const float* const
     ysrc.start[epi.n] = off;
     ysrc.n = epi.n;
     if (Q * off == 0) return 0;
-    if (int rc = launch_norm_split(ysrc, K, 1e-12f, ys, st)) return rc;
+    // Round 6: when the y operand starts right behind the x operand's last row (no alignment gap) the query and every layer are
+    // rows [0, Q) and [Q, Q + sum C) of ONE split buffer: one normalise + split launch instead of two (the same per-row arithmetic)
+    const size_t x_bytes = gemm3::split_elems(Q, K) * 2;
+    if (epi.n + 1 <= kMaxFusedLayers && split_bytes(Q, K) == x_bytes) {
+      RowSources all{};
+      all.ptr[0] = X;
+      all.start[0] = 0;
+      for (int i = 0; i < epi.n; ++i) {
+        all.ptr[i + 1] = ysrc.ptr[i];
+        all.start[i + 1] = Q + ysrc.start[i];
+      }
+      all.start[epi.n + 1] = Q + off;
+      all.n = epi.n + 1;
+      if (int rc = launch_norm_split(all, K, 1e-12f, xs, st)) return rc;
+    } else {
+      if (int rc = launch_norm_split(xsrc, K, 1e-12f, xs, st)) return rc;
+      if (int rc = launch_norm_split(ysrc, K, 1e-12f, ys, st)) return rc;
+    }
     ProfScope prof(SL_PROF_GEMM, st, 2.0 * (double)Q * (double)off * (double)K);
     return gemm3::launch_gemm3_nt(prof, xs, Q, ys, off, K, epi, st);
   }
