@@ -368,6 +368,20 @@ class ActMaxCache(ActCache):
     def __getitem__(self, layer_name: str) -> ActMax:
         return self.cache[layer_name]
 
+    def _register_hooks(self, model: torch.nn.Module):
+        super()._register_hooks(model)
+        if self._grouping:
+            # a forward BOUNDARY (round 6, advisor): groups are planned when the first forward is over — every in-place edit of that
+            # forward has bumped its tensor's version by then — and nothing stashed or queued outlives the forward that produced it
+            self.handles.append(model.register_forward_hook(self._end_of_forward))
+
+    def _end_of_forward(self, module, ins, outs):
+        if self._probe is not None:
+            if self._probe:
+                self._plan_groups()  # also drops the first batch's tensor references
+            return
+        self._flush_deferred()  # a forward that did not reach every member of a group; queued merges
+
     def __iter__(self):
         return iter(self.cache.values())
 

@@ -77,7 +77,7 @@ def standins(monkeypatch):
     return log
 
 
-def _stream(model, layers, batches, log, k=4, before_batch=None, after_batch=None, edited=None):
+def _stream(model, layers, batches, log, k=4, before_batch=None, after_batch=None, edited=None, direct=False):
     cache = ActMaxCache(layers, agg.aggregate_transformer_max, n_collect=k, tie_mode="aten")
     cache._group_device_types = ("cpu",)
     mods = dict(model.named_modules())
@@ -89,7 +89,9 @@ def _stream(model, layers, batches, log, k=4, before_batch=None, after_batch=Non
             if before_batch:
                 before_batch(bi, cache)
             n_before = {n: len(taps[n]) for n in layers}
-            model(x)
+            # direct: `model.forward(x)` skips the ROOT module's hooks (the forward-boundary hook of round 6), the hooked layers'
+            # own hooks still fire — the lazy bookkeeping (flush on the next forward / on a state read) must hold up alone
+            (model.forward if direct else model)(x)
             for n in layers:
                 if len(taps[n]) > n_before[n]:
                     a = oracle.agg_tokens(taps[n][-1] * (edited or {}).get((bi, n), 1.0), "max")
@@ -126,8 +128,9 @@ def test_groups_are_planned_after_the_first_batch_and_launched_when_complete(sta
     assert cache._k3_last == "odd" and not cache._k3_queue
 
 
+@pytest.mark.parametrize("direct", [False, True])
 @pytest.mark.parametrize("batch_k3", ["0", "1"])
-def test_state_read_and_unfinished_forward_flush_the_stash_layer_by_layer(standins, monkeypatch, batch_k3):
+def test_state_read_and_unfinished_forward_flush_the_stash_layer_by_layer(standins, monkeypatch, batch_k3, direct):
     monkeypatch.setenv("SEMANTICLENS_AMD_BATCH_K3", batch_k3)
     torch.manual_seed(1)
     model = _Blocks().eval()
@@ -138,17 +141,20 @@ def test_state_read_and_unfinished_forward_flush_the_stash_layer_by_layer(standi
 
     def after(bi, cache):
         if bi == 2:
-            assert set(cache._groups[0]["stash"]) == {"blocks.0", "blocks.1"}
-            cache.cache["blocks.1"].flush()  # a state read: the whole stash is collected, layer by layer
-            assert not cache._groups[0]["stash"]
+            if direct:  # no forward boundary seen: the two outputs wait in the stash ...
+                assert set(cache._groups[0]["stash"]) == {"blocks.0", "blocks.1"}
+                cache.cache["blocks.1"].flush()  # ... until a state read: the whole stash is collected, layer by layer
+            assert not cache._groups[0]["stash"]  # model(x): the end of the forward already collected them
 
-    _stream(model, layers, _batches(5), standins, before_batch=before, after_batch=after)
+    cache = _stream(model, layers, _batches(5), standins, before_batch=before, after_batch=after, direct=direct)
     model.stop_after = None
     assert standins.count(("reduce_multi", 4)) == 3  # batches 2, 4, 5
+    assert cache._probe is None and [g["layers"] for g in cache._groups] == [layers]
 
 
+@pytest.mark.parametrize("direct", [False, True])
 @pytest.mark.parametrize("batch_k3", ["0", "1"])
-def test_a_forward_that_stops_early_is_finished_by_the_next_one(standins, monkeypatch, batch_k3):
+def test_a_forward_that_stops_early_is_finished_by_the_next_one(standins, monkeypatch, batch_k3, direct):
     monkeypatch.setenv("SEMANTICLENS_AMD_BATCH_K3", batch_k3)
     torch.manual_seed(2)
     model = _Blocks().eval()
@@ -157,7 +163,7 @@ def test_a_forward_that_stops_early_is_finished_by_the_next_one(standins, monkey
     def before(bi, cache):
         model.stop_after = 2 if bi == 1 else None  # batch 2 never reaches blocks.3; batch 3 finds blocks.0 still stashed
 
-    _stream(model, layers, _batches(4), standins, before_batch=before)
+    _stream(model, layers, _batches(4), standins, before_batch=before, direct=direct)
     model.stop_after = None
 
 
