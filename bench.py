@@ -392,10 +392,10 @@ def cpu_baseline(args, model_cpu, fm_cpu):
             if stop and t != all_cores:
                 continue
             torch.set_num_threads(t)
-            if stop:  # all cores, known to be far off (18 s PER IMAGE on one box of round 6): two images, no warm-up call
+            if stop:  # all cores, known to be far off (18-36 s PER IMAGE on the boxes of round 6): one image, no warm-up call
                 t0 = time.perf_counter()
-                batch_compute(probe_u8[:2])
-                thread_probe[t] = 2 / (time.perf_counter() - t0)
+                batch_compute(probe_u8[:1])
+                thread_probe[t] = 1 / (time.perf_counter() - t0)
                 continue
             batch_compute(probe_u8[:8])
             t0 = time.perf_counter()
@@ -471,9 +471,9 @@ def cpu_baseline(args, model_cpu, fm_cpu):
         rate_all, dt_all = rate, dt
     elif stop:
         # one thread per logical CPU already measured far below half of the best count by the probe: its probe figure (forward +
-        # encode of two images) stands for it — the whole job there would add minutes to the line for a number nobody can use
-        rate_all, dt_all = thread_probe[all_cores], 2 / thread_probe[all_cores]
-        all_sample = f"2 images, ResNet-50 forward + CLIP encode only (the thread probe), {dt_all:.1f} s"
+        # encode of one image) stands for it — the whole job there would add minutes to the line for a number nobody can use
+        rate_all, dt_all = thread_probe[all_cores], 1 / thread_probe[all_cores]
+        all_sample = f"1 image, ResNet-50 forward + CLIP encode only (the thread probe), {dt_all:.1f} s"
     else:
         rate_all, dt_all, _ = job_b(B_all, all_cores)
         torch.set_num_threads(threads)
