@@ -622,6 +622,34 @@ def test_gather_rows(golden):
         N.gather_rows(emb, torch.tensor([emb.shape[0]]))
 
 
+@pytest.mark.parametrize("D", [4, 20, 252, 256, 260, 512, 768, 1024, 1152, 1536, 1792, 2048, 2052, 30])
+def test_gather_rows_every_width_class_and_the_sharded_form(D):
+    """K5's wave-per-row kernel (round 6) has one instance per 256 floats of row width (1-8 pieces of 16 bytes per lane), a row-group
+    size per instance, and two fall-backs (fewer than 64 ids, rows that are not whole 16-byte pieces or longer than 2 048 floats: the
+    element-indexed kernel): every class against `emb[ids]`, negative ids wrapping, ragged id counts around the row-group sizes, and
+    the sharded form (rows another shard holds come back as zeros; the shards' sum is the full gather)."""
+    rng = np.random.RandomState(D)
+    n_rows = 777
+    e = rng.randn(n_rows, D).astype(np.float32)
+    emb = torch.from_numpy(e).to(DEV)
+    for n_ids in (1, 63, 64, 65, 67, 1000, 4099):
+        ids = rng.randint(-n_rows, n_rows, size=n_ids)
+        want = oracle.gather_rows(e, ids)
+        out = N.gather_rows(emb, torch.from_numpy(ids))
+        assert np.array_equal(out.cpu().numpy(), want), (D, n_ids)
+        if n_ids in (65, 4099):
+            total = np.zeros_like(want)
+            for lo, hi in ((0, 300), (300, 301), (301, n_rows)):
+                part = N.gather_rows_shard(emb[lo:hi].contiguous(), torch.from_numpy(ids), lo, n_rows).cpu().numpy()
+                src = np.where(ids < 0, ids + n_rows, ids)
+                mine = (src >= lo) & (src < hi)
+                assert np.array_equal(part[mine], want[mine]) and not part[~mine].any(), (D, n_ids, lo)
+                total += part
+            assert np.array_equal(total, want)
+    with pytest.raises(IndexError):
+        N.gather_rows(emb, torch.arange(n_rows - 70, n_rows + 1))  # the wave kernel's path: 71 ids, the last one out of range
+
+
 # ------------------------------------------------------------------------------------------ K6..K10
 def test_scores_goldens(golden):
     g = golden("scores")
